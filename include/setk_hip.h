@@ -1,0 +1,190 @@
+/*
+ * setk_hip.h -- C ABI of libsetk_hip.so: the MI355X (gfx950) implementation of
+ * setk's mask-based adaptive-beamformer hot path
+ *
+ *     STFT -> masked spatial covariance -> MVDR/GEV/PMWF/MPDR weights
+ *          -> beamform -> iSTFT (+ max-abs renorm)
+ *
+ * The reference (funcwj/setk) has no FFI for this path: the seam is the python
+ * call surface of scripts/sptk/libs/{utils,beamformer}.py.  Each entry point
+ * below names the reference function it replaces; the python mirror in
+ * setk_amd/libs binds them through ctypes (see INTEGRATION.md for the stub a
+ * maintainer would add on the reference side).
+ *
+ * Conventions
+ *   - plain C, no exceptions; every call returns an int status:
+ *       0            SETK_OK
+ *       < 0          API misuse / unsupported  (python: ValueError/RuntimeError)
+ *       > 0          never returned; numerical failures are reported per
+ *                    frequency bin / per utterance through `status` arrays
+ *                    (python: numpy.linalg.LinAlgError)
+ *   - all data pointers are caller-owned and contiguous.  Every pointer may be
+ *     DEVICE memory (hipMalloc / torch tensor data_ptr) or ordinary HOST
+ *     memory; the library detects which (hipPointerGetAttributes) and stages
+ *     host buffers through its own device arena.  setk_enhance_batch takes
+ *     device pointers only.
+ *   - complex values are interleaved float pairs (numpy complex64).
+ *   - spectrogram layout is "time major": X[c][t][f], f fastest, F = n_fft/2+1.
+ *     (numpy view of the reference's N x F x T array:
+ *      np.ascontiguousarray(obs.transpose(0, 2, 1)))
+ *   - masks are T x F row major (the layout apply_adaptive_beamformer.py
+ *     normalises to, :146-151), covariances F x C x C, weights F x C.
+ *   - all work is enqueued on the hipStream_t passed as `stream` (NULL = the
+ *     default stream).  When any OUTPUT pointer is host memory the call
+ *     synchronises the stream before returning; otherwise it is asynchronous.
+ *   - a handle is used by one host thread at a time; no global state.
+ */
+#ifndef SETK_HIP_H_
+#define SETK_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SETK_ABI_VERSION 1
+
+/* return codes */
+#define SETK_OK 0
+#define SETK_ERR_INVALID (-1)     /* bad argument / shape mismatch            */
+#define SETK_ERR_UNSUPPORTED (-2) /* valid request outside the built kernels  */
+#define SETK_ERR_HIP (-3)         /* HIP runtime error, see setk_last_error   */
+#define SETK_ERR_NOMEM (-4)
+
+/* per-bin / per-utterance numerical status values (written to status arrays) */
+#define SETK_NUM_OK 0
+#define SETK_NUM_SINGULAR 1 /* noise covariance not positive definite        */
+#define SETK_NUM_NOCONV 2   /* Jacobi sweep limit reached                    */
+#define SETK_NUM_NONFINITE 3
+
+/* beamformer kinds (apply_adaptive_beamformer.py:22, --beamformer) */
+#define SETK_BF_MVDR 0
+#define SETK_BF_GEVD 1
+#define SETK_BF_PMWF 2        /* beta / ref channel / rank1 via setk_bf_opts */
+#define SETK_BF_MPDR 3
+#define SETK_BF_MPDR_WHITEN 4
+
+/* rank-1 approximation of Rs for PMWF (libs/beamformer.py:66-84, 642-645) */
+#define SETK_RANK1_NONE 0
+#define SETK_RANK1_EIG 1
+#define SETK_RANK1_GEV 2
+
+/* flags */
+#define SETK_FLAG_BAN 0x1        /* blind analytic normalisation, do_ban      */
+#define SETK_FLAG_CLAMP_MASK 0x2 /* speech mask <- min(mask, 1)   (:141)      */
+#define SETK_FLAG_POST_MASK 0x4  /* enh <- enh * mask^T           (:174-175)  */
+#define SETK_FLAG_NO_GAUGE 0x8   /* leave eigenvector phase as computed       */
+#define SETK_FLAG_OUT_PCM16 0x10 /* enhance_batch writes int16 PCM, not f32   */
+
+typedef struct setk_context* setk_handle_t;
+
+typedef struct setk_bf_opts {
+    int kind;        /* SETK_BF_*                                            */
+    int flags;       /* SETK_FLAG_*                                          */
+    float pmwf_beta; /* 0 -> pmwf-0, 1 -> pmwf-1                             */
+    int pmwf_ref;    /* < 0: pick the channel with max estimated SNR         */
+    int rank1;       /* SETK_RANK1_*                                         */
+} setk_bf_opts;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int setk_abi_version(void);
+int setk_create(setk_handle_t* out, int device_ordinal);
+int setk_destroy(setk_handle_t h);
+/* text of the last error on this handle (never NULL) */
+const char* setk_last_error(setk_handle_t h);
+
+/* ---- STFT plan ---------------------------------------------------------
+ * Mirrors the arguments of forward_stft / inverse_stft
+ * (scripts/sptk/libs/utils.py:96-173) after the host resolved
+ * n_fft = nextpow2(frame_len) | frame_len and evaluated the window
+ * (scipy.signal.get_window(name, frame_len, fftbins=True) or sqrt-hann).
+ * `window` = frame_len host floats, NULL = periodic hann.
+ * n_fft must be a power of two in [64, 4096]; n_fft == 512 selects the
+ * register/LDS radix-16 kernels, other sizes a generic LDS radix-2 kernel. */
+int setk_stft_plan(setk_handle_t h, int frame_len, int frame_hop, int n_fft,
+                   int center, const float* window);
+/* frames produced for `num_samples` input samples, < 0 on error */
+int setk_stft_num_frames(setk_handle_t h, int num_samples);
+/* samples produced by the inverse for `num_frames` frames (nsamps < 0: the
+ * librosa default length) */
+int setk_istft_num_samples(setk_handle_t h, int num_frames, int nsamps);
+
+/* ---- modular operators -------------------------------------------------- */
+
+/* forward_stft per channel (libs/utils.py:96-138; SpectrogramReader._load,
+ * libs/data_handler.py:492-503).  audio[C][N] float32 -> spec[C][T][F]. */
+int setk_stft(setk_handle_t h, const float* audio, int num_channels,
+              int num_samples, float* spec, void* stream);
+
+/* inverse_stft (libs/utils.py:142-173) for `batch` independent spectrograms
+ * spec[B][T][F] -> wave[B][L], L = setk_istft_num_samples(h, T, nsamps).
+ * norm: NULL or B floats; norm[b] > 0 rescales wave b to that max-abs
+ * (samps * norm / (max|samps| + eps), :166-168). */
+int setk_istft(setk_handle_t h, const float* spec, int batch, int num_frames,
+               int nsamps, const float* norm, float* wave, void* stream);
+
+/* compute_covar (libs/beamformer.py:87-103):
+ * covar[f] = sum_t m[t][f] x x^H / max(sum_t m[t][f], 1e-6).
+ * spec[C][T][F], mask[T][F] -> covar[F][C][C] complex64.  1 <= C <= 8. */
+int setk_covar(setk_handle_t h, const float* spec, const float* mask,
+               int num_channels, int num_frames, int num_bins, float* covar,
+               void* stream);
+
+/* solve_pevd (libs/beamformer.py:31-63): principal eigenvector of Rs (Rn NULL)
+ * or of the pencil (Rs, Rn).  Output pvec[F][C] complex64, unit 2-norm
+ * (Rn NULL) or Rn-normalised v^H Rn v = 1.  Gauge (unless SETK_FLAG_NO_GAUGE):
+ * component 0 real >= 0; for the pencil the rule applies to y = L^H v,
+ * Rn = L L^H.  status[F] (may be NULL) receives SETK_NUM_*. */
+int setk_pevd(setk_handle_t h, const float* Rs, const float* Rn, int num_bins,
+              int num_channels, int flags, float* pvec, int* status,
+              void* stream);
+
+/* {Mvdr,Gevd,Pmwf,Mpdr}Beamformer.weight (+ do_ban), libs/beamformer.py:
+ * 14-28, 527-539, 555-571, 632-659, 674-682.  Rs, Rn: [F][C][C]; Ry only for
+ * MPDR kinds (covariance of the all-ones mask).  weight[F][C] complex64.
+ * status[F] may be NULL.  ref_out (may be NULL) receives the PMWF reference
+ * channel actually used. */
+int setk_weights(setk_handle_t h, const setk_bf_opts* opts, const float* Rs,
+                 const float* Rn, const float* Ry, int num_bins,
+                 int num_channels, float* weight, int* status, int* ref_out,
+                 void* stream);
+
+/* Beamformer.beamform (libs/beamformer.py:220-234):
+ * out[t][f] = sum_c conj(w[f][c]) spec[c][t][f]. */
+int setk_beamform(setk_handle_t h, const float* weight, const float* spec,
+                  int num_channels, int num_frames, int num_bins, float* out,
+                  void* stream);
+
+/* ---- fused hot path ------------------------------------------------------
+ * The compute body of apply_adaptive_beamformer.py:130-178 for a batch of
+ * utterances that share the channel count, in four kernel stages:
+ *   1. windowed rFFT + masked outer-product accumulation (never stores X)
+ *   2. batched per-bin weight solve
+ *   3. rFFT recompute + w^H x + irFFT + overlap-add
+ *   4. max-abs renorm (to max|input|) and emit float32 (or PCM16)
+ * audio[u]   device float32 [C][num_samples[u]]
+ * mask_s[u]  device float32 [T_u][F]
+ * mask_n     NULL, or per-utterance interferer masks (--itf-mask)
+ * wave[u]    device float32 (or int16) [hop*(T_u-1)] when center, see
+ *            setk_istft_num_samples
+ * status[u]  host int, SETK_NUM_* (worst bin of the utterance)
+ * The pointer tables and num_samples are HOST arrays of n_utts entries.
+ * Requires the n_fft = 512 plan and 1 <= C <= 8. */
+int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts,
+                       int num_channels, const float* const* audio,
+                       const int* num_samples, const float* const* mask_s,
+                       const float* const* mask_n, void* const* wave,
+                       int* status, void* stream);
+
+/* Stage timings (ms, hipEvent on `stream`) of the most recent
+ * setk_enhance_batch when profiling was enabled with setk_set_profiling(h,1):
+ * out[0..3] = stft+covar, solve, beamform+istft, renorm.  */
+int setk_set_profiling(setk_handle_t h, int enable);
+int setk_last_stage_ms(setk_handle_t h, float out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SETK_HIP_H_ */

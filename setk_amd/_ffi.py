@@ -1,0 +1,274 @@
+"""
+ctypes binding of libsetk_hip.so (include/setk_hip.h).
+
+There is no CPU fallback: if the HIP library has not been built or no GPU is
+visible, every operator raises.  PyTorch is imported first so that its bundled
+HIP runtime (same SONAME, libamdhip64.so.7) is the one the library binds to --
+torch tensors and this library then share one runtime, one device context and
+torch's streams.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_float, c_int, c_void_p)
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsetk_hip.so")
+
+SETK_OK = 0
+ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM = -1, -2, -3, -4
+NUM_OK, NUM_SINGULAR, NUM_NOCONV, NUM_NONFINITE = 0, 1, 2, 3
+BF_MVDR, BF_GEVD, BF_PMWF, BF_MPDR, BF_MPDR_WHITEN = 0, 1, 2, 3, 4
+RANK1_NONE, RANK1_EIG, RANK1_GEV = 0, 1, 2
+FLAG_BAN, FLAG_CLAMP_MASK, FLAG_POST_MASK, FLAG_NO_GAUGE, FLAG_OUT_PCM16 = 1, 2, 4, 8, 16
+
+
+class BfOpts(ctypes.Structure):
+    _fields_ = [("kind", c_int), ("flags", c_int), ("pmwf_beta", c_float),
+                ("pmwf_ref", c_int), ("rank1", c_int)]
+
+
+class SetkError(RuntimeError):
+    pass
+
+
+class SetkUnsupported(SetkError, NotImplementedError):
+    pass
+
+
+_lib = None
+
+
+def exported_symbols():
+    """Names declared in include/setk_hip.h (checked by the CPU test-suite)."""
+    return [
+        "setk_abi_version", "setk_create", "setk_destroy", "setk_last_error",
+        "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
+        "setk_stft", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
+        "setk_beamform", "setk_enhance_batch", "setk_set_profiling",
+        "setk_last_stage_ms"
+    ]
+
+
+def load_library():
+    """dlopen libsetk_hip.so and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SetkError(
+            f"{LIB_PATH} is missing: build it with `python -m setk_amd.build` "
+            "(there is no CPU fallback)")
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first)
+    except Exception:  # pragma: no cover - torch is plumbing, not required
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    H = c_void_p
+    fp = c_void_p  # raw data pointers (host or device)
+    lib.setk_abi_version.restype = c_int
+    lib.setk_create.argtypes = [POINTER(H), c_int]
+    lib.setk_destroy.argtypes = [H]
+    lib.setk_last_error.argtypes = [H]
+    lib.setk_last_error.restype = c_char_p
+    lib.setk_set_profiling.argtypes = [H, c_int]
+    lib.setk_last_stage_ms.argtypes = [H, POINTER(c_float)]
+    lib.setk_stft_plan.argtypes = [H, c_int, c_int, c_int, c_int, fp]
+    lib.setk_stft_num_frames.argtypes = [H, c_int]
+    lib.setk_istft_num_samples.argtypes = [H, c_int, c_int]
+    lib.setk_stft.argtypes = [H, fp, c_int, c_int, fp, c_void_p]
+    lib.setk_istft.argtypes = [H, fp, c_int, c_int, c_int, fp, fp, c_void_p]
+    lib.setk_covar.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, c_void_p]
+    lib.setk_pevd.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, fp, c_void_p]
+    lib.setk_weights.argtypes = [H, POINTER(BfOpts), fp, fp, fp, c_int, c_int,
+                                 fp, fp, POINTER(c_int), c_void_p]
+    lib.setk_beamform.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, c_void_p]
+    lib.setk_enhance_batch.argtypes = [
+        H, POINTER(BfOpts), c_int, c_int, POINTER(c_void_p), POINTER(c_int),
+        POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int),
+        c_void_p
+    ]
+    for name in exported_symbols():
+        fn = getattr(lib, name)
+        if fn.restype is not c_char_p:
+            fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(x):
+    """Raw address of a numpy array (host) or torch tensor (host/device)."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        if not x.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return x.data_ptr()
+    raise TypeError(f"unsupported buffer type {type(x)}")
+
+
+def current_stream_ptr():
+    """torch's current HIP stream as a raw hipStream_t (0 = default stream)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.current_stream().cuda_stream
+    except Exception:
+        pass
+    return 0
+
+
+class Context:
+    """Owns one setk_handle_t (one GPU, one host thread at a time)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = c_void_p()
+        rc = self._lib.setk_create(ctypes.byref(self._h), int(device))
+        if rc != SETK_OK:
+            self._h = None
+            raise SetkError(
+                f"setk_create(device={device}) failed with {rc}: no usable MI355X / "
+                "HIP runtime (the product path needs the GPU; there is no CPU fallback)")
+        self.device = int(device)
+        self.plan = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.setk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc == SETK_OK:
+            return
+        msg = self._lib.setk_last_error(self._h)
+        msg = msg.decode() if msg else ""
+        if rc == ERR_INVALID:
+            raise ValueError(msg)
+        if rc == ERR_UNSUPPORTED:
+            raise SetkUnsupported(msg)
+        raise SetkError(f"libsetk_hip error {rc}: {msg}")
+
+    # -- plan ---------------------------------------------------------------
+    def stft_plan(self, frame_len, frame_hop, n_fft, center, window=None):
+        key = (int(frame_len), int(frame_hop), int(n_fft), bool(center),
+               None if window is None else window.tobytes())
+        if self.plan == key:
+            return
+        wp = None
+        if window is not None:
+            window = np.ascontiguousarray(window, dtype=np.float32)
+            if window.shape != (frame_len,):
+                raise ValueError("window must have frame_len entries")
+            wp = window.ctypes.data
+        self.check(
+            self._lib.setk_stft_plan(self._h, frame_len, frame_hop, n_fft,
+                                     1 if center else 0, wp))
+        self.plan = key
+
+    def num_frames(self, num_samples):
+        r = self._lib.setk_stft_num_frames(self._h, int(num_samples))
+        if r < 0:
+            self.check(r)
+        return r
+
+    def istft_num_samples(self, num_frames, nsamps=-1):
+        r = self._lib.setk_istft_num_samples(self._h, int(num_frames),
+                                             -1 if nsamps is None else int(nsamps))
+        if r < 0:
+            self.check(r)
+        return r
+
+    # -- modular operators (numpy in / numpy out, or device tensors) ---------
+    def stft(self, audio, out, stream=None):
+        C, N = audio.shape
+        self.check(
+            self._lib.setk_stft(self._h, _ptr(audio), C, N, _ptr(out),
+                                current_stream_ptr() if stream is None else stream))
+
+    def istft(self, spec, batch, num_frames, nsamps, norm, out, stream=None):
+        self.check(
+            self._lib.setk_istft(self._h, _ptr(spec), batch, num_frames,
+                                 -1 if nsamps is None else int(nsamps), _ptr(norm),
+                                 _ptr(out),
+                                 current_stream_ptr() if stream is None else stream))
+
+    def covar(self, spec, mask, C, T, F, out, stream=None):
+        self.check(
+            self._lib.setk_covar(self._h, _ptr(spec), _ptr(mask), C, T, F, _ptr(out),
+                                 current_stream_ptr() if stream is None else stream))
+
+    def pevd(self, Rs, Rn, F, C, flags, out, status, stream=None):
+        self.check(
+            self._lib.setk_pevd(self._h, _ptr(Rs), _ptr(Rn), F, C, flags, _ptr(out),
+                                _ptr(status),
+                                current_stream_ptr() if stream is None else stream))
+
+    def weights(self, opts, Rs, Rn, Ry, F, C, out, status, stream=None):
+        ref = c_int(-1)
+        self.check(
+            self._lib.setk_weights(self._h, ctypes.byref(opts), _ptr(Rs), _ptr(Rn),
+                                   _ptr(Ry), F, C, _ptr(out), _ptr(status),
+                                   ctypes.byref(ref),
+                                   current_stream_ptr() if stream is None else stream))
+        return ref.value
+
+    def beamform(self, weight, spec, C, T, F, out, stream=None):
+        self.check(
+            self._lib.setk_beamform(self._h, _ptr(weight), _ptr(spec), C, T, F,
+                                    _ptr(out),
+                                    current_stream_ptr() if stream is None else stream))
+
+    # -- fused hot path ---------------------------------------------------------
+    def enhance_batch(self, opts, num_channels, audio_ptrs, num_samples, mask_ptrs,
+                      itf_ptrs, wave_ptrs, want_status=True, stream=None):
+        n = len(audio_ptrs)
+        A = (c_void_p * n)(*audio_ptrs)
+        M = (c_void_p * n)(*mask_ptrs)
+        W = (c_void_p * n)(*wave_ptrs)
+        I = (c_void_p * n)(*itf_ptrs) if itf_ptrs is not None else None
+        NS = (c_int * n)(*[int(v) for v in num_samples])
+        ST = (c_int * n)() if want_status else None
+        self.check(
+            self._lib.setk_enhance_batch(
+                self._h, ctypes.byref(opts), n, int(num_channels), A, NS, M, I, W, ST,
+                current_stream_ptr() if stream is None else stream))
+        return list(ST) if want_status else None
+
+    def set_profiling(self, on):
+        self.check(self._lib.setk_set_profiling(self._h, 1 if on else 0))
+
+    def last_stage_ms(self):
+        out = (c_float * 4)()
+        self.check(self._lib.setk_last_stage_ms(self._h, out))
+        return list(out)
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Process-wide context for the python API mirror (one per device)."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get(
+            "SETK_DEVICE") is None else int(os.environ["SETK_DEVICE"])
+        try:
+            import torch
+            if torch.cuda.is_available():
+                device = torch.cuda.current_device()
+        except Exception:
+            pass
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

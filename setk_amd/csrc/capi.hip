@@ -1,0 +1,824 @@
+// capi.hip -- the extern "C" front end of libsetk_hip.so (include/setk_hip.h).
+// Host-side orchestration only: argument checking, staging of host buffers,
+// work-list construction and kernel launches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/setk_hip.h"
+#include "common.h"
+
+using namespace setk;
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr int kKindPevd = 100;
+
+struct Block {
+    char* ptr = nullptr;
+    size_t cap = 0;
+    size_t off = 0;
+};
+
+}  // namespace
+
+struct setk_context {
+    int device = 0;
+    std::string err;
+    // STFT plan
+    bool planned = false;
+    int frame_len = 0, hop = 0, n_fft = 0, center = 0;
+    float* d_window = nullptr;  // [n_fft] padded analysis/synthesis window
+    float* d_winsq = nullptr;   // [n_fft]
+    float2* d_tw256 = nullptr;  // [256]
+    float2* d_tw512 = nullptr;  // [129]
+    // device arena (bump allocated per call, blocks reused across calls)
+    std::vector<Block> blocks;
+    // descriptor cache of the fused path
+    std::vector<char> desc_cache;
+    char* d_desc = nullptr;
+    size_t d_desc_cap = 0;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float stage_ms[4] = {0, 0, 0, 0};
+    bool stage_valid = false;
+    // tunables
+    int p1_items = 1024;
+    int p2_items = 1024;
+};
+
+namespace {
+
+int fail(setk_handle_t h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                              \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return fail(h, SETK_ERR_HIP,                                              \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+void arena_reset(setk_handle_t h) {
+    for (auto& b : h->blocks) b.off = 0;
+}
+
+void* arena_alloc(setk_handle_t h, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    for (auto& b : h->blocks) {
+        if (b.cap - b.off >= bytes) {
+            void* p = b.ptr + b.off;
+            b.off += bytes;
+            return p;
+        }
+    }
+    size_t cap = std::max(bytes, (size_t)64 << 20);
+    if (!h->blocks.empty()) cap = std::max(cap, h->blocks.back().cap);
+    Block nb;
+    if (hipMalloc(reinterpret_cast<void**>(&nb.ptr), cap) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    nb.cap = cap;
+    nb.off = bytes;
+    h->blocks.push_back(nb);
+    return nb.ptr;
+}
+
+// Stage an input: device pointers pass through, host data is copied.
+template <typename T>
+int stage_in(setk_handle_t h, const T* src, size_t count, hipStream_t s, const T** out) {
+    if (is_device_ptr(src)) {
+        *out = src;
+        return SETK_OK;
+    }
+    void* d = arena_alloc(h, count * sizeof(T));
+    if (!d) return fail(h, SETK_ERR_NOMEM, "device arena allocation failed");
+    HIP_TRY(h, hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    *out = static_cast<const T*>(d);
+    return SETK_OK;
+}
+
+// Prepare an output: device pointers are written in place, host outputs get a
+// device twin that copy_back() drains.
+struct OutBuf {
+    void* user = nullptr;
+    void* dev = nullptr;
+    size_t bytes = 0;
+    bool host = false;
+};
+
+int stage_out(setk_handle_t h, void* dst, size_t bytes, OutBuf* ob) {
+    ob->user = dst;
+    ob->bytes = bytes;
+    if (is_device_ptr(dst)) {
+        ob->dev = dst;
+        ob->host = false;
+        return SETK_OK;
+    }
+    ob->dev = arena_alloc(h, bytes);
+    ob->host = true;
+    if (!ob->dev) return fail(h, SETK_ERR_NOMEM, "device arena allocation failed");
+    return SETK_OK;
+}
+
+int copy_back(setk_handle_t h, const OutBuf& ob, hipStream_t s) {
+    if (ob.host && ob.bytes)
+        HIP_TRY(h, hipMemcpyAsync(ob.user, ob.dev, ob.bytes, hipMemcpyDeviceToHost, s));
+    return SETK_OK;
+}
+
+int upload(setk_handle_t h, const void* src, size_t bytes, hipStream_t s, void** out) {
+    void* d = arena_alloc(h, bytes);
+    if (!d) return fail(h, SETK_ERR_NOMEM, "device arena allocation failed");
+    HIP_TRY(h, hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s));
+    *out = d;
+    return SETK_OK;
+}
+
+int pitch_of(int F) { return (F == kBins) ? kBinsPad : ((F + 7) / 8) * 8; }
+
+StftGeom geom_of(setk_handle_t h) {
+    StftGeom g;
+    g.hop = h->hop;
+    g.center = h->center;
+    g.pad = h->center ? h->n_fft / 2 : 0;
+    g.keep = (h->n_fft + h->hop - 1) / h->hop - 1;
+    return g;
+}
+
+int require_plan512(setk_handle_t h) {
+    if (!h->planned) return fail(h, SETK_ERR_INVALID, "setk_stft_plan has not been called");
+    if (h->n_fft != kNfft)
+        return fail(h, SETK_ERR_UNSUPPORTED,
+                    "only the n_fft = 512 kernels are built (n_fft = " + std::to_string(h->n_fft) +
+                        ")");
+    if (h->hop > h->n_fft) return fail(h, SETK_ERR_UNSUPPORTED, "frame_hop > n_fft");
+    if (geom_of(h).keep > kMaxKeep)
+        return fail(h, SETK_ERR_UNSUPPORTED, "frame_hop < 64 is not supported");
+    return SETK_OK;
+}
+
+// split [0, T) into ranges of about `target` frames, multiples of `quant`
+void split_frames(int T, int target, int quant, std::vector<std::pair<int, int>>* out) {
+    int nparts = std::max(1, (T + target - 1) / target);
+    int fw = (T + nparts - 1) / nparts;
+    fw = ((fw + quant - 1) / quant) * quant;
+    for (int t = 0; t < T; t += fw) out->push_back({t, std::min(T, t + fw)});
+}
+
+}  // namespace
+
+extern "C" {
+
+int setk_abi_version(void) { return SETK_ABI_VERSION; }
+
+int setk_create(setk_handle_t* out, int device_ordinal) {
+    if (!out) return SETK_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return SETK_ERR_HIP;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) return SETK_ERR_INVALID;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return SETK_ERR_HIP;
+    setk_context* h = new setk_context();
+    h->device = device_ordinal;
+    if (const char* e = getenv("SETK_P1_ITEMS")) h->p1_items = std::max(1, atoi(e));
+    if (const char* e = getenv("SETK_P2_ITEMS")) h->p2_items = std::max(1, atoi(e));
+    *out = h;
+    return SETK_OK;
+}
+
+int setk_destroy(setk_handle_t h) {
+    if (!h) return SETK_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto& b : h->blocks) (void)hipFree(b.ptr);
+    if (h->d_window) (void)hipFree(h->d_window);
+    if (h->d_winsq) (void)hipFree(h->d_winsq);
+    if (h->d_tw256) (void)hipFree(h->d_tw256);
+    if (h->d_tw512) (void)hipFree(h->d_tw512);
+    if (h->d_desc) (void)hipFree(h->d_desc);
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete h;
+    return SETK_OK;
+}
+
+const char* setk_last_error(setk_handle_t h) { return h ? h->err.c_str() : "null handle"; }
+
+int setk_set_profiling(setk_handle_t h, int enable) {
+    if (!h) return SETK_ERR_INVALID;
+    h->profiling = enable != 0;
+    if (h->profiling)
+        for (auto& e : h->ev)
+            if (!e) HIP_TRY(h, hipEventCreate(&e));
+    return SETK_OK;
+}
+
+int setk_last_stage_ms(setk_handle_t h, float out[4]) {
+    if (!h || !out) return SETK_ERR_INVALID;
+    if (!h->stage_valid) return fail(h, SETK_ERR_INVALID, "no profiled run available");
+    for (int i = 0; i < 4; ++i) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventSynchronize(h->ev[i + 1]));
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        out[i] = ms;
+    }
+    return SETK_OK;
+}
+
+int setk_stft_plan(setk_handle_t h, int frame_len, int frame_hop, int n_fft, int center,
+                   const float* window) {
+    if (!h) return SETK_ERR_INVALID;
+    if (frame_len <= 0 || frame_hop <= 0 || n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)))
+        return fail(h, SETK_ERR_INVALID, "n_fft must be a power of two in [64, 4096]");
+    if (frame_len > n_fft) return fail(h, SETK_ERR_INVALID, "frame_len > n_fft");
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<float> w(n_fft, 0.f), w2(n_fft, 0.f);
+    const int lpad = (n_fft - frame_len) / 2;
+    for (int i = 0; i < frame_len; ++i) {
+        double v = window ? (double)window[i] : 0.5 - 0.5 * std::cos(2.0 * kPi * i / frame_len);
+        w[lpad + i] = (float)v;
+        w2[lpad + i] = (float)(v * v);
+    }
+    std::vector<float2> t256(256), t512(129);
+    for (int q = 0; q < 16; ++q)
+        for (int la = 0; la < 16; ++la) {
+            const double ang = -2.0 * kPi * (double)(la * q) / 256.0;
+            t256[q * 16 + la] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+    for (int k = 0; k <= 128; ++k) {
+        const double ang = -2.0 * kPi * (double)k / 512.0;
+        t512[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (h->d_window) (void)hipFree(h->d_window);
+    if (h->d_winsq) (void)hipFree(h->d_winsq);
+    h->d_window = h->d_winsq = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_window), n_fft * sizeof(float)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_winsq), n_fft * sizeof(float)));
+    if (!h->d_tw256) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tw256), 256 * sizeof(float2)));
+    if (!h->d_tw512) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tw512), 129 * sizeof(float2)));
+    HIP_TRY(h, hipMemcpy(h->d_window, w.data(), n_fft * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_winsq, w2.data(), n_fft * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_tw256, t256.data(), 256 * sizeof(float2), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_tw512, t512.data(), 129 * sizeof(float2), hipMemcpyHostToDevice));
+    h->frame_len = frame_len;
+    h->hop = frame_hop;
+    h->n_fft = n_fft;
+    h->center = center ? 1 : 0;
+    h->planned = true;
+    h->desc_cache.clear();
+    return SETK_OK;
+}
+
+int setk_stft_num_frames(setk_handle_t h, int num_samples) {
+    if (!h || !h->planned) return SETK_ERR_INVALID;
+    if (h->center) {
+        if (num_samples < h->n_fft / 2 + 1)
+            return fail(h, SETK_ERR_INVALID, "signal shorter than n_fft/2+1 (reflect padding)");
+        return 1 + num_samples / h->hop;
+    }
+    if (num_samples < h->n_fft) return fail(h, SETK_ERR_INVALID, "signal shorter than n_fft");
+    return 1 + (num_samples - h->n_fft) / h->hop;
+}
+
+int setk_istft_num_samples(setk_handle_t h, int num_frames, int nsamps) {
+    if (!h || !h->planned || num_frames <= 0) return SETK_ERR_INVALID;
+    if (nsamps >= 0) return nsamps;
+    return h->center ? h->hop * (num_frames - 1) : h->n_fft + h->hop * (num_frames - 1);
+}
+
+int setk_stft(setk_handle_t h, const float* audio, int num_channels, int num_samples,
+              float* spec, void* stream) {
+    if (!h || !audio || !spec || num_channels <= 0) return fail(h, SETK_ERR_INVALID, "bad args");
+    int rc = require_plan512(h);
+    if (rc) return rc;
+    const int T = setk_stft_num_frames(h, num_samples);
+    if (T < 0) return T;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h);
+    const float* d_audio;
+    rc = stage_in(h, audio, (size_t)num_channels * num_samples, s, &d_audio);
+    if (rc) return rc;
+    OutBuf ob;
+    rc = stage_out(h, spec, (size_t)num_channels * T * kBins * sizeof(float2), &ob);
+    if (rc) return rc;
+    for (int c0 = 0; c0 < num_channels; c0 += kMaxChannels) {
+        const int C = std::min(kMaxChannels, num_channels - c0);
+        UttDesc ud;
+        memset(&ud, 0, sizeof(ud));
+        ud.audio = d_audio + (size_t)c0 * num_samples;
+        ud.num_samples = num_samples;
+        ud.num_frames = T;
+        std::vector<std::pair<int, int>> ranges;
+        split_frames(T, 64, 32, &ranges);
+        std::vector<WorkItem> items;
+        for (auto& r : ranges) items.push_back({0, r.first, r.second, 0, r.second == T});
+        void *d_ud, *d_items;
+        rc = upload(h, &ud, sizeof(ud), s, &d_ud);
+        if (rc) return rc;
+        rc = upload(h, items.data(), items.size() * sizeof(WorkItem), s, &d_items);
+        if (rc) return rc;
+        Pass1Args a;
+        memset(&a, 0, sizeof(a));
+        a.utts = static_cast<const UttDesc*>(d_ud);
+        a.items = static_cast<const WorkItem*>(d_items);
+        a.window = h->d_window;
+        a.tw256 = h->d_tw256;
+        a.tw512 = h->d_tw512;
+        a.spec_dump = static_cast<float*>(ob.dev) + (size_t)c0 * T * kBins * 2;
+        a.g = geom_of(h);
+        HIP_TRY(h, launch_pass1(C, true, a, (int)items.size(), s));
+    }
+    rc = copy_back(h, ob, s);
+    if (rc) return rc;
+    if (ob.host) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
+int setk_istft(setk_handle_t h, const float* spec, int batch, int num_frames, int nsamps,
+               const float* norm, float* wave, void* stream) {
+    if (!h || !spec || !wave || batch <= 0 || num_frames <= 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    int rc = require_plan512(h);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h);
+    const int T = num_frames, F = kBins;
+    const int L = setk_istft_num_samples(h, T, nsamps);
+    int T_eff = T;
+    if (nsamps >= 0) {
+        const long padded = (long)nsamps + (h->center ? h->n_fft : 0);
+        T_eff = (int)std::min<long>(T, (padded + h->hop - 1) / h->hop);
+        if (T_eff < 1) T_eff = 1;
+    }
+    const float* d_spec;
+    rc = stage_in(h, spec, (size_t)batch * T * F * 2, s, &d_spec);
+    if (rc) return rc;
+    OutBuf ob;
+    rc = stage_out(h, wave, (size_t)batch * L * sizeof(float), &ob);
+    if (rc) return rc;
+    if (L > 0) HIP_TRY(h, hipMemsetAsync(ob.dev, 0, (size_t)batch * L * sizeof(float), s));
+    std::vector<float> hn(batch, -1.f);
+    if (norm) {
+        if (is_device_ptr(norm))
+            HIP_TRY(h, hipMemcpy(hn.data(), norm, batch * sizeof(float), hipMemcpyDeviceToHost));
+        else
+            memcpy(hn.data(), norm, batch * sizeof(float));
+    }
+    void* d_norm;
+    rc = upload(h, hn.data(), batch * sizeof(float), s, &d_norm);
+    if (rc) return rc;
+    std::vector<UttDesc> uds(batch);
+    std::vector<WorkItem> items;
+    for (int b = 0; b < batch; ++b) {
+        UttDesc& ud = uds[b];
+        memset(&ud, 0, sizeof(ud));
+        ud.audio = d_spec + (size_t)b * T * F * 2;  // ISTFT mode: per-item spectrogram
+        ud.num_frames = T_eff;
+        ud.out_len = L;
+        ud.wave_f32 = static_cast<float*>(ob.dev) + (size_t)b * L;
+        ud.wave_out = ud.wave_f32;
+        std::vector<std::pair<int, int>> ranges;
+        split_frames(T_eff, 128, kSuperTile, &ranges);
+        for (auto& r : ranges) items.push_back({b, r.first, r.second, 0, r.second == T_eff});
+    }
+    void *d_ud, *d_items, *d_omax;
+    rc = upload(h, uds.data(), uds.size() * sizeof(UttDesc), s, &d_ud);
+    if (rc) return rc;
+    rc = upload(h, items.data(), items.size() * sizeof(WorkItem), s, &d_items);
+    if (rc) return rc;
+    d_omax = arena_alloc(h, batch * sizeof(unsigned));
+    if (!d_omax) return fail(h, SETK_ERR_NOMEM, "arena");
+    HIP_TRY(h, hipMemsetAsync(d_omax, 0, batch * sizeof(unsigned), s));
+    Pass2Args a;
+    memset(&a, 0, sizeof(a));
+    a.utts = static_cast<const UttDesc*>(d_ud);
+    a.items = static_cast<const WorkItem*>(d_items);
+    a.window = h->d_window;
+    a.synwin = h->d_window;
+    a.winsq = h->d_winsq;
+    a.tw256 = h->d_tw256;
+    a.tw512 = h->d_tw512;
+    a.outmax_bits = static_cast<unsigned*>(d_omax);
+    a.g = geom_of(h);
+    HIP_TRY(h, launch_pass2(1, true, a, (int)items.size(), s));
+    if (norm) {
+        ScaleArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.utts = a.utts;
+        sa.outmax_bits = a.outmax_bits;
+        sa.norm_override = static_cast<const float*>(d_norm);
+        HIP_TRY(h, launch_scale(sa, batch, L, s));
+    }
+    rc = copy_back(h, ob, s);
+    if (rc) return rc;
+    if (ob.host) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
+int setk_covar(setk_handle_t h, const float* spec, const float* mask, int num_channels,
+               int num_frames, int num_bins, float* covar, void* stream) {
+    if (!h || !spec || !mask || !covar || num_frames <= 0 || num_bins <= 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    if (num_channels < 1 || num_channels > kMaxChannels)
+        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h);
+    const int C = num_channels, T = num_frames, F = num_bins;
+    const float *d_spec, *d_mask;
+    int rc = stage_in(h, spec, (size_t)C * T * F * 2, s, &d_spec);
+    if (rc) return rc;
+    rc = stage_in(h, mask, (size_t)T * F, s, &d_mask);
+    if (rc) return rc;
+    OutBuf ob;
+    rc = stage_out(h, covar, (size_t)F * C * C * sizeof(float2), &ob);
+    if (rc) return rc;
+    const int split = std::max(1, std::min(64, (T + 31) / 32));
+    const int pitch = ((F + 7) / 8) * 8;
+    float* d_part =
+        static_cast<float*>(arena_alloc(h, (size_t)split * (2 * npairs(C) + 1) * pitch * 4));
+    if (!d_part) return fail(h, SETK_ERR_NOMEM, "arena");
+    const int per = (T + split - 1) / split;
+    const int used = (T + per - 1) / per;
+    HIP_TRY(h, launch_covar_spec(C, d_spec, d_mask, T, F, d_part, split, s));
+    HIP_TRY(h, launch_covar_spec_finalize(C, d_part, used, F, static_cast<float*>(ob.dev), s));
+    rc = copy_back(h, ob, s);
+    if (rc) return rc;
+    if (ob.host) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
+static int run_weights(setk_handle_t h, const setk_bf_opts& o, int kind, const float* Rs,
+                       const float* Rn, const float* Ry, int F, int C, float* weight, int* status,
+                       int* ref_out, hipStream_t s) {
+    const int NP = npairs(C);
+    const int pitch = pitch_of(F);
+    const bool mpdr = (kind == SETK_BF_MPDR || kind == SETK_BF_MPDR_WHITEN);
+    const int planes = mpdr ? 6 * NP : (Rn ? 4 * NP : 2 * NP);
+    arena_reset(h);
+    const float *d_Rs, *d_Rn = nullptr, *d_Ry = nullptr;
+    const size_t nmat = (size_t)F * C * C * 2;
+    int rc = stage_in(h, Rs, nmat, s, &d_Rs);
+    if (rc) return rc;
+    if (Rn) {
+        rc = stage_in(h, Rn, nmat, s, &d_Rn);
+        if (rc) return rc;
+    }
+    if (Ry) {
+        rc = stage_in(h, Ry, nmat, s, &d_Ry);
+        if (rc) return rc;
+    }
+    float* d_planes = static_cast<float*>(arena_alloc(h, (size_t)planes * pitch * 4));
+    float* d_w = static_cast<float*>(arena_alloc(h, (size_t)C * pitch * 8));
+    int* d_bin = static_cast<int*>(arena_alloc(h, (size_t)F * 4));
+    if (!d_planes || !d_w || !d_bin) return fail(h, SETK_ERR_NOMEM, "arena");
+    HIP_TRY(h, hipMemsetAsync(d_planes, 0, (size_t)planes * pitch * 4, s));
+    HIP_TRY(h, launch_pack_covar(d_Rs, F, C, d_planes, 0, s));
+    if (d_Rn) HIP_TRY(h, launch_pack_covar(d_Rn, F, C, d_planes, 2 * NP, s));
+    if (d_Ry) HIP_TRY(h, launch_pack_covar(d_Ry, F, C, d_planes, 4 * NP, s));
+    OutBuf ob;
+    rc = stage_out(h, weight, (size_t)F * C * sizeof(float2), &ob);
+    if (rc) return rc;
+    SolveArgs a;
+    memset(&a, 0, sizeof(a));
+    a.covar = d_planes;
+    a.weight = d_w;
+    a.bin_status = d_bin;
+    a.n_utts = 1;
+    a.num_bins = F;
+    a.num_channels = C;
+    a.planes = planes;
+    a.kind = kind;
+    a.flags = o.flags;
+    a.rank1 = o.rank1;
+    a.pmwf_ref = o.pmwf_ref;
+    a.pmwf_beta = o.pmwf_beta;
+    int* d_ref = nullptr;
+    if (kind == SETK_BF_PMWF && o.pmwf_ref < 0) {
+        a.snr_acc = static_cast<double*>(arena_alloc(h, (size_t)C * 2 * sizeof(double)));
+        a.wmat = static_cast<float*>(arena_alloc(h, (size_t)F * C * C * 8));
+        d_ref = static_cast<int*>(arena_alloc(h, sizeof(int)));
+        if (!a.snr_acc || !a.wmat || !d_ref) return fail(h, SETK_ERR_NOMEM, "arena");
+        HIP_TRY(h, hipMemsetAsync(a.snr_acc, 0, (size_t)C * 2 * sizeof(double), s));
+    }
+    HIP_TRY(h, launch_solve(a, s));
+    if (kind == SETK_BF_PMWF && o.pmwf_ref < 0) HIP_TRY(h, launch_pmwf_select(a, d_ref, s));
+    HIP_TRY(h, launch_unpack_weight(d_w, F, C, static_cast<float*>(ob.dev), s));
+    rc = copy_back(h, ob, s);
+    if (rc) return rc;
+    if (status) {
+        if (is_device_ptr(status))
+            HIP_TRY(h, hipMemcpyAsync(status, d_bin, F * 4, hipMemcpyDeviceToDevice, s));
+        else
+            HIP_TRY(h, hipMemcpyAsync(status, d_bin, F * 4, hipMemcpyDeviceToHost, s));
+    }
+    if (ref_out) {
+        if (d_ref)
+            HIP_TRY(h, hipMemcpyAsync(ref_out, d_ref, 4, hipMemcpyDeviceToHost, s));
+        else
+            *ref_out = o.pmwf_ref;
+    }
+    if (ob.host || (status && !is_device_ptr(status)) || ref_out)
+        HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
+int setk_pevd(setk_handle_t h, const float* Rs, const float* Rn, int num_bins, int num_channels,
+              int flags, float* pvec, int* status, void* stream) {
+    if (!h || !Rs || !pvec || num_bins <= 0) return fail(h, SETK_ERR_INVALID, "bad args");
+    if (num_channels < 1 || num_channels > kMaxChannels)
+        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    HIP_TRY(h, hipSetDevice(h->device));
+    setk_bf_opts o;
+    memset(&o, 0, sizeof(o));
+    o.flags = flags & SETK_FLAG_NO_GAUGE;
+    return run_weights(h, o, kKindPevd, Rs, Rn, nullptr, num_bins, num_channels, pvec, status,
+                       nullptr, static_cast<hipStream_t>(stream));
+}
+
+int setk_weights(setk_handle_t h, const setk_bf_opts* opts, const float* Rs, const float* Rn,
+                 const float* Ry, int num_bins, int num_channels, float* weight, int* status,
+                 int* ref_out, void* stream) {
+    if (!h || !opts || !Rs || !weight || num_bins <= 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    if (num_channels < 1 || num_channels > kMaxChannels)
+        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    const int kind = opts->kind;
+    if (kind < SETK_BF_MVDR || kind > SETK_BF_MPDR_WHITEN)
+        return fail(h, SETK_ERR_INVALID, "unknown beamformer kind");
+    const bool mpdr = (kind == SETK_BF_MPDR || kind == SETK_BF_MPDR_WHITEN);
+    if (mpdr && !Ry) return fail(h, SETK_ERR_INVALID, "MPDR needs Ry");
+    if (kind != SETK_BF_MPDR && !Rn) return fail(h, SETK_ERR_INVALID, "Rn is required");
+    if (kind == SETK_BF_MPDR && (opts->flags & SETK_FLAG_BAN))
+        return fail(h, SETK_ERR_INVALID, "BAN needs a noise covariance (mpdr without whiten)");
+    if (kind == SETK_BF_PMWF && opts->pmwf_ref >= num_channels)
+        return fail(h, SETK_ERR_INVALID, "Reference channel ID exceeds total channels");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return run_weights(h, *opts, kind, Rs, Rn, Ry, num_bins, num_channels, weight, status,
+                       ref_out, static_cast<hipStream_t>(stream));
+}
+
+int setk_beamform(setk_handle_t h, const float* weight, const float* spec, int num_channels,
+                  int num_frames, int num_bins, float* out, void* stream) {
+    if (!h || !weight || !spec || !out || num_channels <= 0 || num_frames <= 0 || num_bins <= 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h);
+    const int C = num_channels, T = num_frames, F = num_bins;
+    const float *d_w, *d_spec;
+    int rc = stage_in(h, weight, (size_t)F * C * 2, s, &d_w);
+    if (rc) return rc;
+    rc = stage_in(h, spec, (size_t)C * T * F * 2, s, &d_spec);
+    if (rc) return rc;
+    OutBuf ob;
+    rc = stage_out(h, out, (size_t)T * F * sizeof(float2), &ob);
+    if (rc) return rc;
+    HIP_TRY(h, launch_beamform_spec(d_w, d_spec, C, T, F, static_cast<float*>(ob.dev), s));
+    rc = copy_back(h, ob, s);
+    if (rc) return rc;
+    if (ob.host) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
+int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, int num_channels,
+                       const float* const* audio, const int* num_samples,
+                       const float* const* mask_s, const float* const* mask_n,
+                       void* const* wave, int* status, void* stream) {
+    if (!h || !opts || n_utts <= 0 || !audio || !num_samples || !mask_s || !wave)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    int rc = require_plan512(h);
+    if (rc) return rc;
+    const int C = num_channels;
+    if (C < 1 || C > kMaxChannels) return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    const int kind = opts->kind;
+    if (kind < SETK_BF_MVDR || kind > SETK_BF_MPDR_WHITEN)
+        return fail(h, SETK_ERR_INVALID, "unknown beamformer kind");
+    const bool mpdr = (kind == SETK_BF_MPDR || kind == SETK_BF_MPDR_WHITEN);
+    if (mpdr && mask_n)
+        return fail(h, SETK_ERR_UNSUPPORTED,
+                    "fused MPDR derives Ry from mask_s + (1 - mask_s); use the modular API "
+                    "with an interferer mask");
+    if (kind == SETK_BF_MPDR && (opts->flags & SETK_FLAG_BAN))
+        return fail(h, SETK_ERR_INVALID, "BAN needs a noise covariance (mpdr without whiten)");
+    if (kind == SETK_BF_PMWF && opts->pmwf_ref >= C)
+        return fail(h, SETK_ERR_INVALID, "Reference channel ID exceeds total channels");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h);
+    const bool pcm16 = (opts->flags & SETK_FLAG_OUT_PCM16) != 0;
+    const int NP = npairs(C);
+    const StftGeom g = geom_of(h);
+
+    // ---- descriptors and work lists ----
+    std::vector<UttDesc> uds(n_utts);
+    std::vector<WorkItem> items1, items2;
+    long total_frames = 0;
+    int max_len = 0;
+    size_t f32_scratch = 0;
+    for (int u = 0; u < n_utts; ++u) {
+        const int T = setk_stft_num_frames(h, num_samples[u]);
+        if (T < 0) return T;
+        total_frames += T;
+    }
+    constexpr int TBq[9] = {0, 32, 16, 10, 8, 6, 5, 4, 4};
+    const int target1 = (int)std::max<long>(TBq[C] * 8, (total_frames + h->p1_items - 1) / h->p1_items);
+    const int target2 = (int)std::max<long>(kSuperTile * 4, (total_frames + h->p2_items - 1) / h->p2_items);
+    int nparts_total = 0;
+    for (int u = 0; u < n_utts; ++u) {
+        UttDesc& ud = uds[u];
+        memset(&ud, 0, sizeof(ud));
+        if (!audio[u] || !mask_s[u] || !wave[u] || (mask_n && !mask_n[u]))
+            return fail(h, SETK_ERR_INVALID, "null utterance pointer");
+        ud.audio = audio[u];
+        ud.mask_s = mask_s[u];
+        ud.mask_n = mask_n ? mask_n[u] : nullptr;
+        ud.num_samples = num_samples[u];
+        ud.num_frames = setk_stft_num_frames(h, num_samples[u]);
+        ud.out_len = setk_istft_num_samples(h, ud.num_frames, -1);
+        ud.wave_out = wave[u];
+        max_len = std::max(max_len, ud.out_len);
+        std::vector<std::pair<int, int>> r1, r2;
+        split_frames(ud.num_frames, target1, TBq[C], &r1);
+        split_frames(ud.num_frames, target2, kSuperTile, &r2);
+        ud.part0 = nparts_total;
+        ud.nparts = (int)r1.size();
+        for (auto& r : r1)
+            items1.push_back({u, r.first, r.second, nparts_total++, r.second == ud.num_frames});
+        for (auto& r : r2) items2.push_back({u, r.first, r.second, 0, r.second == ud.num_frames});
+        f32_scratch += ((size_t)ud.out_len * 4 + 255) & ~(size_t)255;
+    }
+    float* d_f32 = nullptr;
+    if (pcm16) {
+        d_f32 = static_cast<float*>(arena_alloc(h, f32_scratch));
+        if (!d_f32) return fail(h, SETK_ERR_NOMEM, "arena");
+    }
+    {
+        size_t off = 0;
+        for (int u = 0; u < n_utts; ++u) {
+            if (pcm16) {
+                uds[u].wave_f32 = reinterpret_cast<float*>(reinterpret_cast<char*>(d_f32) + off);
+                off += ((size_t)uds[u].out_len * 4 + 255) & ~(size_t)255;
+            } else {
+                uds[u].wave_f32 = static_cast<float*>(wave[u]);
+            }
+        }
+    }
+    // descriptors: [uds | items1 | items2], cached on the device while unchanged
+    const size_t b_ud = uds.size() * sizeof(UttDesc);
+    const size_t b_i1 = items1.size() * sizeof(WorkItem);
+    const size_t b_i2 = items2.size() * sizeof(WorkItem);
+    std::vector<char> blob(b_ud + b_i1 + b_i2);
+    memcpy(blob.data(), uds.data(), b_ud);
+    memcpy(blob.data() + b_ud, items1.data(), b_i1);
+    memcpy(blob.data() + b_ud + b_i1, items2.data(), b_i2);
+    if (blob != h->desc_cache) {
+        if (blob.size() > h->d_desc_cap) {
+            HIP_TRY(h, hipStreamSynchronize(s));
+            if (h->d_desc) (void)hipFree(h->d_desc);
+            h->d_desc = nullptr;
+            h->d_desc_cap = 0;
+            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_desc), blob.size() * 2));
+            h->d_desc_cap = blob.size() * 2;
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->d_desc, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        h->desc_cache.swap(blob);
+    }
+    const UttDesc* d_uds = reinterpret_cast<const UttDesc*>(h->d_desc);
+    const WorkItem* d_items1 = reinterpret_cast<const WorkItem*>(h->d_desc + b_ud);
+    const WorkItem* d_items2 = reinterpret_cast<const WorkItem*>(h->d_desc + b_ud + b_i1);
+
+    // ---- scratch ----
+    const int planes_out = mpdr ? 6 * NP : 4 * NP;
+    float* d_part = static_cast<float*>(
+        arena_alloc(h, (size_t)nparts_total * nplanes_partial(C) * kBinsPad * 4));
+    float* d_covar = static_cast<float*>(arena_alloc(h, (size_t)n_utts * planes_out * kBinsPad * 4));
+    float* d_w = static_cast<float*>(arena_alloc(h, (size_t)n_utts * C * kBinsPad * 8));
+    unsigned* d_small = static_cast<unsigned*>(arena_alloc(h, (size_t)n_utts * 3 * 4));
+    if (!d_part || !d_covar || !d_w || !d_small) return fail(h, SETK_ERR_NOMEM, "arena");
+    unsigned* d_norm = d_small;
+    unsigned* d_omax = d_small + n_utts;
+    int* d_status = reinterpret_cast<int*>(d_small + 2 * n_utts);
+    HIP_TRY(h, hipMemsetAsync(d_small, 0, (size_t)n_utts * 3 * 4, s));
+
+    const bool prof = h->profiling;
+    h->stage_valid = false;
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[0], s));
+
+    // ---- stage 1: STFT + covariance partials, finalize ----
+    Pass1Args p1;
+    memset(&p1, 0, sizeof(p1));
+    p1.utts = d_uds;
+    p1.items = d_items1;
+    p1.partials = d_part;
+    p1.window = h->d_window;
+    p1.tw256 = h->d_tw256;
+    p1.tw512 = h->d_tw512;
+    p1.norm_bits = d_norm;
+    p1.g = g;
+    p1.flags = opts->flags;
+    HIP_TRY(h, launch_pass1(C, false, p1, (int)items1.size(), s));
+    FinalizeArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.utts = d_uds;
+    fa.partials = d_part;
+    fa.covar = d_covar;
+    fa.num_channels = C;
+    fa.with_ry = mpdr ? 1 : 0;
+    HIP_TRY(h, launch_finalize(fa, n_utts, s));
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[1], s));
+
+    // ---- stage 2: weights ----
+    SolveArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.covar = d_covar;
+    sa.weight = d_w;
+    sa.status = d_status;
+    sa.n_utts = n_utts;
+    sa.num_bins = kBins;
+    sa.num_channels = C;
+    sa.planes = planes_out;
+    sa.kind = kind;
+    sa.flags = opts->flags;
+    sa.rank1 = opts->rank1;
+    sa.pmwf_ref = opts->pmwf_ref;
+    sa.pmwf_beta = opts->pmwf_beta;
+    if (kind == SETK_BF_PMWF && opts->pmwf_ref < 0) {
+        sa.snr_acc = static_cast<double*>(arena_alloc(h, (size_t)n_utts * C * 2 * sizeof(double)));
+        sa.wmat = static_cast<float*>(arena_alloc(h, (size_t)n_utts * kBins * C * C * 8));
+        if (!sa.snr_acc || !sa.wmat) return fail(h, SETK_ERR_NOMEM, "arena");
+        HIP_TRY(h, hipMemsetAsync(sa.snr_acc, 0, (size_t)n_utts * C * 2 * sizeof(double), s));
+    }
+    HIP_TRY(h, launch_solve(sa, s));
+    if (kind == SETK_BF_PMWF && opts->pmwf_ref < 0) HIP_TRY(h, launch_pmwf_select(sa, nullptr, s));
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[2], s));
+
+    // ---- stage 3: beamform + iSTFT ----
+    Pass2Args p2;
+    memset(&p2, 0, sizeof(p2));
+    p2.utts = d_uds;
+    p2.items = d_items2;
+    p2.weight = d_w;
+    p2.window = h->d_window;
+    p2.synwin = h->d_window;
+    p2.winsq = h->d_winsq;
+    p2.tw256 = h->d_tw256;
+    p2.tw512 = h->d_tw512;
+    p2.outmax_bits = d_omax;
+    p2.g = g;
+    p2.flags = opts->flags;
+    HIP_TRY(h, launch_pass2(C, false, p2, (int)items2.size(), s));
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[3], s));
+
+    // ---- stage 4: renorm ----
+    ScaleArgs sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.utts = d_uds;
+    sc.norm_bits = d_norm;
+    sc.outmax_bits = d_omax;
+    sc.pcm16 = pcm16 ? 1 : 0;
+    HIP_TRY(h, launch_scale(sc, n_utts, max_len, s));
+    if (prof) {
+        HIP_TRY(h, hipEventRecord(h->ev[4], s));
+        h->stage_valid = true;
+    }
+    if (status) {
+        HIP_TRY(h, hipMemcpyAsync(status, d_status, (size_t)n_utts * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+    }
+    return SETK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// common.h -- argument blocks and launcher prototypes shared by the kernel
+// translation units and the C-ABI front end (capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace setk {
+
+constexpr int kNfft = 512;        // fused kernels are specialised for n_fft = 512
+constexpr int kBins = 257;        // n_fft / 2 + 1
+constexpr int kBinsPad = 264;     // row pitch of per-bin planes (multiple of 8)
+constexpr int kMaxChannels = 8;   // register-resident covariance accumulators
+constexpr int kSuperTile = 16;    // frames per inverse-transform batch (pass 2)
+constexpr int kMaxKeep = 7;       // ceil(512 / hop) - 1 for hop >= 64
+
+// number of Hermitian pairs (i <= j)
+__host__ __device__ constexpr int npairs(int c) { return c * (c + 1) / 2; }
+// planes of one packed covariance pair set: [s.re | s.im | n.re | n.im | sums(2)]
+__host__ __device__ constexpr int nplanes_partial(int c) { return 4 * npairs(c) + 2; }
+// upper-triangular row-major pair index, i <= j
+__host__ __device__ constexpr int pair_index(int i, int j, int c) {
+    return i * c - i * (i - 1) / 2 + (j - i);
+}
+
+struct UttDesc {
+    const float* audio;   // [C][num_samples]
+    const float* mask_s;  // [T][F]
+    const float* mask_n;  // [T][F] or null
+    float* wave_f32;      // pass-2 float output [out_len]
+    void* wave_out;       // final output (float32 or int16), may alias wave_f32
+    int num_samples;
+    int num_frames;
+    int out_len;
+    int part0;   // first partial slab of this utterance
+    int nparts;  // number of partial slabs
+    int pad_;
+};
+
+struct WorkItem {
+    int utt;
+    int t0, t1;  // frame range [t0, t1)
+    int part;    // partial slab index (pass 1) / unused (pass 2)
+    int last;    // 1 if t1 == num_frames
+};
+
+struct StftGeom {
+    int hop;
+    int pad;      // n_fft/2 when center else 0
+    int center;
+    int keep;     // ceil(n_fft / hop) - 1
+};
+
+struct Pass1Args {
+    const UttDesc* utts;
+    const WorkItem* items;
+    float* partials;        // [nparts_total][nplanes][kBinsPad]
+    const float* window;    // [512] analysis window (padded, centred)
+    const float2* tw256;    // [16][16]  exp(-2 pi i la q / 256) at [q*16+la]
+    const float2* tw512;    // [129]     exp(-2 pi i k / 512)
+    unsigned* norm_bits;    // [n_utts] max |audio| as float bits (atomicMax)
+    float* spec_dump;       // DUMP mode: [C][T][F]
+    StftGeom g;
+    int flags;
+};
+
+struct FinalizeArgs {
+    const UttDesc* utts;
+    const float* partials;
+    float* covar;  // [n_utts][4*NP (+2*NP when with_ry)][kBinsPad]
+    int num_channels;
+    int with_ry;   // also emit Ry = (Rs_num + Rn_num) / T  (MPDR)
+};
+
+struct SolveArgs {
+    const float* covar;   // packed planes, see FinalizeArgs
+    float* weight;        // [n_utts][C][kBinsPad] float2
+    int* status;          // [n_utts] (atomicMax) or per-bin when per_bin != 0
+    int* bin_status;      // [n_problems] or null
+    double* snr_acc;      // PMWF ref<0: [n_utts][C][2] (ps, pn)
+    float* wmat;          // PMWF ref<0: [n_problems][C][C] float2 (column major)
+    int n_utts;
+    int num_bins;
+    int num_channels;
+    int planes;           // planes per utterance in covar
+    int kind, flags, rank1, pmwf_ref;
+    float pmwf_beta;
+};
+
+struct Pass2Args {
+    const UttDesc* utts;
+    const WorkItem* items;
+    const float* weight;     // [n_utts][C][kBinsPad] float2
+    const float* spec_in;    // ISTFT mode: [B][T][F] float2
+    const float* window;     // analysis window [512]
+    const float* synwin;     // synthesis window [512] (same padded window)
+    const float* winsq;      // window^2 [512]
+    const float2* tw256;
+    const float2* tw512;
+    unsigned* outmax_bits;   // [n_utts]
+    StftGeom g;
+    int flags;
+};
+
+struct ScaleArgs {
+    const UttDesc* utts;
+    const unsigned* norm_bits;
+    const unsigned* outmax_bits;
+    const float* norm_override;  // istft API: per-batch norm (<=0: none) or null
+    int pcm16;
+};
+
+// launchers (implemented in the kernel TUs)
+hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s);
+hipError_t launch_finalize(const FinalizeArgs& a, int n_utts, hipStream_t s);
+hipError_t launch_solve(const SolveArgs& a, hipStream_t s);
+hipError_t launch_pmwf_select(const SolveArgs& a, int* ref_out, hipStream_t s);
+hipError_t launch_pass2(int C, bool istft_only, const Pass2Args& a, int n_items, hipStream_t s);
+hipError_t launch_scale(const ScaleArgs& a, int n_utts, int max_len, hipStream_t s);
+size_t pass2_lds_bytes(int C, int keep);
+
+// modular helpers
+hipError_t launch_covar_spec(int C, const float* spec, const float* mask, int T, int F,
+                             float* partials, int t_split, hipStream_t s);
+hipError_t launch_covar_spec_finalize(int C, const float* partials, int nparts, int F,
+                                      float* covar_fcc, hipStream_t s);
+hipError_t launch_pack_covar(const float* fcc, int F, int C, float* planes, int plane0,
+                             hipStream_t s);
+hipError_t launch_unpack_weight(const float* wplanes, int F, int C, float* w_fc, hipStream_t s);
+hipError_t launch_beamform_spec(const float* w_fc, const float* spec, int C, int T, int F,
+                                float* out, hipStream_t s);
+
+}  // namespace setk

@@ -1,0 +1,130 @@
+// fft512.h -- real FFT-512 building blocks for gfx950 (wave64, LDS).
+//
+// A 512-point real transform is computed as a 256-point complex transform of
+// z[n] = x[2n] + i x[2n+1] plus a Hermitian split.  The 256-point transform
+// runs on a "quad-row" of 16 lanes: each lane keeps 16 complex points in
+// registers, so the whole transform is two in-register radix-16 butterflies
+// and ONE 16x16 transpose through LDS (XOR-swizzled, bank-conflict free for
+// ds_write_b64 / ds_read_b64).  A wavefront therefore carries 4 independent
+// transforms, a 256-thread workgroup 16.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace setk {
+
+typedef float2 cf;
+
+#define SETK_DEV __device__ __forceinline__
+
+SETK_DEV cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+SETK_DEV cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+SETK_DEV cf cmul(cf a, cf b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * conj(b)
+SETK_DEV cf cmulc(cf a, cf b) {
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+SETK_DEV cf cconj(cf a) { return make_float2(a.x, -a.y); }
+SETK_DEV cf cscale(cf a, float s) { return make_float2(a.x * s, a.y * s); }
+
+// position of output index q after dft16 (digit swap, an involution)
+__host__ __device__ constexpr int dft16_pos(int q) { return (q >> 2) + 4 * (q & 3); }
+
+// 4-point DFT, DIR = -1 forward (e^{-i..}), +1 inverse (unscaled)
+template <int DIR>
+SETK_DEV void dft4(cf& a, cf& b, cf& c, cf& d) {
+    cf s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = csub(b, d);
+    cf r3 = DIR < 0 ? make_float2(s3.y, -s3.x) : make_float2(-s3.y, s3.x);
+    a = cadd(s0, s2);
+    c = csub(s0, s2);
+    b = cadd(s1, r3);
+    d = csub(s1, r3);
+}
+
+// multiply by exp(DIR * 2*pi*i * M / 16), M compile time
+template <int DIR, int M>
+SETK_DEV cf twid16(cf v) {
+    constexpr float C1 = 0.92387953251128673848f;  // cos(pi/8)
+    constexpr float S1 = 0.38268343236508978178f;  // sin(pi/8)
+    constexpr float R2 = 0.70710678118654752440f;
+    constexpr float D = (float)DIR;
+    if constexpr (M == 1) return cmul(v, make_float2(C1, D * S1));
+    if constexpr (M == 2) return make_float2(R2 * (v.x - D * v.y), R2 * (D * v.x + v.y));
+    if constexpr (M == 3) return cmul(v, make_float2(S1, D * C1));
+    if constexpr (M == 4) return make_float2(-D * v.y, D * v.x);
+    if constexpr (M == 6) return make_float2(R2 * (-v.x - D * v.y), R2 * (D * v.x - v.y));
+    if constexpr (M == 9) return cmul(v, make_float2(-C1, -D * S1));
+    return v;
+}
+
+// In-register 16-point DFT.  On return v[dft16_pos(q)] = X[q].
+template <int DIR>
+SETK_DEV void dft16(cf (&v)[16]) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4<DIR>(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    // v[4c+b] = u_b[c]; twiddle W16^{bc}
+    v[4 * 1 + 1] = twid16<DIR, 1>(v[4 * 1 + 1]);
+    v[4 * 2 + 1] = twid16<DIR, 2>(v[4 * 2 + 1]);
+    v[4 * 3 + 1] = twid16<DIR, 3>(v[4 * 3 + 1]);
+    v[4 * 1 + 2] = twid16<DIR, 2>(v[4 * 1 + 2]);
+    v[4 * 2 + 2] = twid16<DIR, 4>(v[4 * 2 + 2]);
+    v[4 * 3 + 2] = twid16<DIR, 6>(v[4 * 3 + 2]);
+    v[4 * 1 + 3] = twid16<DIR, 3>(v[4 * 1 + 3]);
+    v[4 * 2 + 3] = twid16<DIR, 6>(v[4 * 2 + 3]);
+    v[4 * 3 + 3] = twid16<DIR, 9>(v[4 * 3 + 3]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        dft4<DIR>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+}
+
+// ---- 256-point complex transform on 16 lanes ------------------------------
+// Stage A: lane `la` holds v[j] = z[la + 16 j].  Radix-16 over j, twiddle by
+// W256^{la q}, store transposed into the 256-entry LDS slot (XOR swizzle).
+// tw: LDS table tw[q*16 + la] = exp(-2 pi i la q / 256).
+template <int DIR>
+SETK_DEV void fft256_stage_a(cf (&v)[16], cf* slot, const cf* tw, int la) {
+    dft16<DIR>(v);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        cf t = v[dft16_pos(q)];
+        if (q) {
+            cf w = tw[q * 16 + la];
+            if (DIR > 0) w.y = -w.y;
+            t = cmul(t, w);
+        }
+        slot[q * 16 + (la ^ q)] = t;
+    }
+}
+
+// Stage B (after a barrier): lane `la` gathers sub-transform `la`, radix-16,
+// leaves Z[la + 16 kb] in v[dft16_pos(kb)].
+template <int DIR>
+SETK_DEV void fft256_stage_b(cf (&v)[16], const cf* slot, int la) {
+#pragma unroll
+    for (int n = 0; n < 16; ++n) v[n] = slot[la * 16 + (n ^ la)];
+    dft16<DIR>(v);
+}
+
+// Hermitian split of the packed transform: from Zk = Z[k], Zm = Z[256-k]
+// (Z[256] == Z[0]) produce X[k] and X[256-k] of the 512-point real DFT.
+// w = exp(-2 pi i k / 512).
+SETK_DEV void rfft_split(cf Zk, cf Zm, cf w, cf& Xk, cf& Xm) {
+    cf A = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));   // E[k]
+    cf O = make_float2(0.5f * (Zk.y + Zm.y), -0.5f * (Zk.x - Zm.x));  // O[k]
+    cf B = cmul(w, O);
+    Xk = cadd(A, B);
+    Xm = make_float2(A.x - B.x, -(A.y - B.y));
+}
+
+// Inverse of rfft_split: from Y[k], Y[256-k] build Z[k], Z[256-k] of the
+// packed inverse transform.  w = exp(-2 pi i k / 512) (conjugated inside).
+SETK_DEV void irfft_merge(cf Yk, cf Ym, cf w, cf& Zk, cf& Zm) {
+    cf E = make_float2(0.5f * (Yk.x + Ym.x), 0.5f * (Yk.y - Ym.y));
+    cf D = make_float2(0.5f * (Yk.x - Ym.x), 0.5f * (Yk.y + Ym.y));
+    cf O = cmulc(D, w);  // D * conj(w)
+    Zk = make_float2(E.x - O.y, E.y + O.x);   // E + i O
+    Zm = make_float2(E.x + O.y, -E.y + O.x);  // conj(E) + i conj(O)
+}
+
+}  // namespace setk

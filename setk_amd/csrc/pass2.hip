@@ -1,0 +1,394 @@
+// pass2.hip -- rFFT recompute + w^H x + irFFT + overlap-add, and the renorm.
+//
+// Replaces (funcwj/setk): Beamformer.beamform (libs/beamformer.py:220-234),
+// post-masking (apply_adaptive_beamformer.py:174-175) and inverse_stft
+// (libs/utils.py:142-173 -> librosa.istft 0.8.1: irfft, * window, overlap-add,
+// / sum(window^2) where > tiny, trim n_fft/2, inf-norm rescale).
+//
+// The STFT is recomputed from the audio (15 MB/utt, Infinity-Cache sized)
+// instead of being stored in pass 1 (31 MB write + 31 MB read).  A workgroup
+// walks its frame range in super-tiles of 16 frames; for every channel the 16
+// quad-rows transform 16 frames at once and each thread folds conj(w_c) X_c
+// into register accumulators (beamforming is a sum over channels, so only one
+// channel's spectrum is ever resident in LDS).  The accumulated Y is merged
+// into the packed inverse form, transformed back by the same quad-rows, and the
+// windowed frames are overlap-added out of LDS with coalesced stores.
+#include "common.h"
+#include "fft512.h"
+
+namespace setk {
+
+SETK_DEV int reflect_index2(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+SETK_DEV void load_frame2(cf (&v)[16], const float* __restrict__ x, int n_samp, int s, int la,
+                          const float* win, bool valid) {
+    const float2* w2 = reinterpret_cast<const float2*>(win);
+    if (!valid) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = make_float2(0.f, 0.f);
+        return;
+    }
+    const bool interior = (s >= 0) && (s + kNfft <= n_samp) &&
+                          ((reinterpret_cast<uintptr_t>(x + s) & 7) == 0);
+    if (interior) {
+        const float2* p = reinterpret_cast<const float2*>(x + s);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int n = la + 16 * j;
+            const float2 d = p[n];
+            const float2 w = w2[n];
+            v[j] = make_float2(d.x * w.x, d.y * w.y);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int n = la + 16 * j;
+            const float d0 = x[reflect_index2(s + 2 * n, n_samp)];
+            const float d1 = x[reflect_index2(s + 2 * n + 1, n_samp)];
+            const float2 w = w2[n];
+            v[j] = make_float2(d0 * w.x, d1 * w.y);
+        }
+    }
+}
+
+// LDS plan (bytes): slots (16+keep)*2048 | wtab C*257*8 (BF mode) | tw 2048 |
+// win 2048 | synwin 2048 | winsq 2048 | red 16
+size_t pass2_lds_bytes(int C, int keep) {
+    size_t wt = ((size_t)C * kBins * sizeof(cf) + 15) & ~(size_t)15;
+    return (size_t)(kSuperTile + keep) * 2048 + wt + 4 * 2048 + 64;
+}
+
+// ISTFT_ONLY: Y comes from a[].spec_in (spec[b][t][f]) instead of being
+// beamformed from audio.
+template <int C, bool ISTFT_ONLY>
+__global__ __launch_bounds__(256) void beamform_istft_kernel(Pass2Args a) {
+    constexpr int F = kBins;
+    constexpr int ST = kSuperTile;
+    constexpr int R = ST / 2;  // pair items per thread (16 frames x 128 / 256)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int keep = a.g.keep;
+    cf* slots = reinterpret_cast<cf*>(smem);  // [(keep + 16)][256]
+    char* p = smem + (size_t)(ST + keep) * 2048;
+    cf* wtab = reinterpret_cast<cf*>(p);  // [C][257]
+    p += ((size_t)C * F * sizeof(cf) + 15) & ~(size_t)15;
+    cf* tw = reinterpret_cast<cf*>(p);
+    p += 2048;
+    float* win = reinterpret_cast<float*>(p);
+    p += 2048;
+    float* synwin = reinterpret_cast<float*>(p);
+    p += 2048;
+    float* winsq = reinterpret_cast<float*>(p);
+    p += 2048;
+    float* red = reinterpret_cast<float*>(p);
+
+    const int tid = threadIdx.x;
+    const int la = tid & 15, grp = tid >> 4;
+    const int k = tid & 127;
+    const WorkItem wi = a.items[blockIdx.x];
+    const UttDesc ud = a.utts[wi.utt];
+    const int n_samp = ud.num_samples;
+    const int T = ud.num_frames;
+    const int hop = a.g.hop;
+    const bool post_mask = (a.flags & 0x4) != 0;
+    const bool clamp = (a.flags & 0x2) != 0;
+
+    tw[tid] = a.tw256[tid];
+    for (int i = tid; i < kNfft; i += 256) {
+        win[i] = a.window[i];
+        synwin[i] = a.synwin[i];
+        winsq[i] = a.winsq[i];
+    }
+    if (!ISTFT_ONLY) {
+        const cf* wsrc = reinterpret_cast<const cf*>(a.weight) + (size_t)wi.utt * C * kBinsPad;
+        for (int i = tid; i < C * F; i += 256) {
+            const int c = i / F, f = i - c * F;
+            wtab[i] = wsrc[c * kBinsPad + f];
+        }
+    }
+    const cf wsplit = a.tw512[k];
+    float omax = 0.f;
+
+    // frames needed to complete the first output position of this range
+    const int t_first = max(wi.t0 - keep, 0);
+    // zero the carried-over slots so that positions before t_first*hop are inert
+    for (int i = tid; i < keep * 256; i += 256) slots[i] = make_float2(0.f, 0.f);
+
+    for (int ts = t_first; ts < wi.t1; ts += ST) {
+        cf* cur = slots + keep * 256;  // 16 slots of this super-tile
+        cf Yk[R], Ym[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            Yk[r] = make_float2(0.f, 0.f);
+            Ym[r] = make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+        if (ISTFT_ONLY) {
+            const cf* spec = reinterpret_cast<const cf*>(ud.audio);  // per-item spectrogram
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int g = (tid >> 7) + 2 * r;
+                const int t = ts + g;
+                if (t < T) {
+                    const cf* row = spec + (size_t)t * F;
+                    if (k == 0) {
+                        Yk[r] = make_float2(row[0].x, row[256].x);
+                        Ym[r] = row[128];
+                    } else {
+                        Yk[r] = row[k];
+                        Ym[r] = row[256 - k];
+                    }
+                }
+            }
+        } else {
+            for (int c = 0; c < C; ++c) {
+                {
+                    const int t = ts + grp;
+                    cf v[16];
+                    load_frame2(v, ud.audio + (size_t)c * n_samp, n_samp, t * hop - a.g.pad, la,
+                                win, t < T);
+                    fft256_stage_a<-1>(v, cur + grp * 256, tw, la);
+                }
+                __syncthreads();
+                {
+                    cf v[16];
+                    cf* slot = cur + grp * 256;
+                    fft256_stage_b<-1>(v, slot, la);
+#pragma unroll
+                    for (int kb = 0; kb < 16; ++kb) slot[la + 16 * kb] = v[dft16_pos(kb)];
+                }
+                __syncthreads();
+                const cf* wc = wtab + c * F;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int g = (tid >> 7) + 2 * r;
+                    const cf* slot = cur + g * 256;
+                    const cf Zk = slot[k];
+                    const cf Zm = slot[(256 - k) & 255];
+                    cf Xk, Xm;
+                    rfft_split(Zk, Zm, wsplit, Xk, Xm);
+                    if (k == 0) {
+                        // X[0], X[256] are real and only Re Y[0], Re Y[256]
+                        // reach the inverse (numpy irfft drops their imag)
+                        Yk[r].x = fmaf(wc[0].x, Xk.x, Yk[r].x);
+                        Yk[r].y = fmaf(wc[256].x, Xm.x, Yk[r].y);
+                        const cf Z128 = slot[128];
+                        const cf X128 = make_float2(Z128.x, -Z128.y);
+                        const cf t128 = cmulc(X128, wc[128]);
+                        Ym[r] = cadd(Ym[r], t128);
+                    } else {
+                        Yk[r] = cadd(Yk[r], cmulc(Xk, wc[k]));
+                        Ym[r] = cadd(Ym[r], cmulc(Xm, wc[256 - k]));
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- optional post-mask, merge into the packed inverse input ----
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int g = (tid >> 7) + 2 * r;
+            const int t = ts + g;
+            cf* slot = cur + g * 256;
+            cf yk = Yk[r], ym = Ym[r];
+            if (post_mask && t < T) {
+                const float* mrow = ud.mask_s + (size_t)t * F;
+                if (k == 0) {
+                    float m0 = mrow[0], m256 = mrow[256], m128 = mrow[128];
+                    if (clamp) { m0 = fminf(m0, 1.f); m256 = fminf(m256, 1.f); m128 = fminf(m128, 1.f); }
+                    yk.x *= m0;
+                    yk.y *= m256;
+                    ym = cscale(ym, m128);
+                } else {
+                    float mk = mrow[k], mm = mrow[256 - k];
+                    if (clamp) { mk = fminf(mk, 1.f); mm = fminf(mm, 1.f); }
+                    yk = cscale(yk, mk);
+                    ym = cscale(ym, mm);
+                }
+            }
+            if (k == 0) {
+                slot[0] = make_float2(0.5f * (yk.x + yk.y), 0.5f * (yk.x - yk.y));
+                slot[128] = make_float2(ym.x, -ym.y);
+            } else {
+                cf Zk, Zm;
+                irfft_merge(yk, ym, wsplit, Zk, Zm);
+                slot[k] = Zk;
+                slot[256 - k] = Zm;
+            }
+        }
+        __syncthreads();
+        // ---- inverse transform of frame ts + grp ----
+        {
+            cf v[16];
+            cf* slot = cur + grp * 256;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = slot[la + 16 * j];
+            fft256_stage_a<+1>(v, slot, tw, la);
+        }
+        __syncthreads();
+        {
+            cf v[16];
+            cf* slot = cur + grp * 256;
+            fft256_stage_b<+1>(v, slot, la);
+            const bool valid = (ts + grp) < T;
+            const float sc = valid ? (1.f / 256.f) : 0.f;
+            const float2* sw = reinterpret_cast<const float2*>(synwin);
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) {
+                const int n = la + 16 * kb;
+                const cf z = v[dft16_pos(kb)];
+                const float2 w = sw[n];
+                slot[n] = make_float2(z.x * sc * w.x, z.y * sc * w.y);
+            }
+        }
+        __syncthreads();
+        // ---- overlap-add: padded positions [pos0, pos1) are now complete ----
+        {
+            const float* frames = reinterpret_cast<const float*>(slots);  // [(keep+16)][512]
+            int pos0 = max(ts, wi.t0) * hop;
+            int pos1 = min(ts + ST, wi.t1) * hop;
+            if (wi.last && ts + ST >= wi.t1) pos1 = (T - 1) * hop + kNfft;
+            for (int n = pos0 + tid; n < pos1; n += 256) {
+                // frames t with t*hop <= n < t*hop + 512
+                int t_hi = min(n / hop, T - 1);
+                int t_lo = max((n - kNfft) / hop + 1, 0);
+                if (n < kNfft) t_lo = 0;
+                float v = 0.f, wss = 0.f;
+                for (int t = t_lo; t <= t_hi; ++t) {
+                    const int off = n - t * hop;
+                    const int sl = t - ts + keep;  // slot of frame t
+                    v += frames[sl * kNfft + off];
+                    wss += winsq[off];
+                }
+                if (wss > 1.17549435e-38f) v /= wss;
+                const int o = n - a.g.pad;
+                if (o >= 0 && o < ud.out_len) {
+                    ud.wave_f32[o] = v;
+                    omax = fmaxf(omax, fabsf(v));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- carry the last `keep` frames over to the next super-tile ----
+        {
+            float4* dst = reinterpret_cast<float4*>(slots);
+            const float4* src = reinterpret_cast<const float4*>(slots + ST * 256);
+            float4 tmp[4];
+            const int n4 = keep * 128;  // float4 per slot = 128
+            // keep <= 7 -> at most 896 float4, <= 4 per thread
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (tid + 256 * q < n4) tmp[q] = src[tid + 256 * q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (tid + 256 * q < n4) dst[tid + 256 * q] = tmp[q];
+        }
+    }
+    // ---- max |out| for the renorm ----
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = omax;
+    __syncthreads();
+    if (tid == 0) {
+        const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(a.outmax_bits + wi.utt, __float_as_uint(m));
+    }
+}
+
+template <int C, bool IO>
+static hipError_t launch_pass2_t(const Pass2Args& a, int n_items, hipStream_t s) {
+    const size_t lds = pass2_lds_bytes(IO ? 1 : C, a.g.keep);
+    auto k = beamform_istft_kernel<C, IO>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(n_items), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pass2(int C, bool istft_only, const Pass2Args& a, int n_items, hipStream_t s) {
+    if (istft_only) return launch_pass2_t<1, true>(a, n_items, s);
+    switch (C) {
+        case 1: return launch_pass2_t<1, false>(a, n_items, s);
+        case 2: return launch_pass2_t<2, false>(a, n_items, s);
+        case 3: return launch_pass2_t<3, false>(a, n_items, s);
+        case 4: return launch_pass2_t<4, false>(a, n_items, s);
+        case 5: return launch_pass2_t<5, false>(a, n_items, s);
+        case 6: return launch_pass2_t<6, false>(a, n_items, s);
+        case 7: return launch_pass2_t<7, false>(a, n_items, s);
+        case 8: return launch_pass2_t<8, false>(a, n_items, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
+// renorm: samps * norm / (max|samps| + eps)   (libs/utils.py:166-168), float32
+// or PCM16 (libsndfile float->short: lrint(x * 32767)) output.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_kernel(ScaleArgs a) {
+    const int u = blockIdx.y;
+    const UttDesc ud = a.utts[u];
+    float norm;
+    if (a.norm_override)
+        norm = a.norm_override[u];
+    else
+        norm = __uint_as_float(a.norm_bits[u]);
+    const float omax = __uint_as_float(a.outmax_bits[u]);
+    const float eps = 1.1920928955078125e-07f;
+    const float sc = (norm > 0.f) ? norm / (omax + eps) : 1.f;
+    const int n = ud.out_len;
+    const float* src = ud.wave_f32;
+    if (a.pcm16) {
+        int16_t* dst = reinterpret_cast<int16_t*>(ud.wave_out);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+            const float v = rintf(src[i] * sc * 32767.f);
+            dst[i] = (int16_t)(int)v;
+        }
+    } else {
+        float* dst = reinterpret_cast<float*>(ud.wave_out);
+        if (sc == 1.f && dst == src) return;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+            dst[i] = src[i] * sc;
+    }
+}
+
+hipError_t launch_scale(const ScaleArgs& a, int n_utts, int max_len, hipStream_t s) {
+    int bx = (max_len + 256 * 8 - 1) / (256 * 8);
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(scale_kernel, dim3(bx, n_utts), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// modular Beamformer.beamform on a stored spectrogram (any F, C <= 16):
+// out[t][f] = sum_c conj(w[f][c]) spec[c][t][f]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void beamform_spec_kernel(const cf* __restrict__ w,
+                                                            const cf* __restrict__ spec, int C,
+                                                            int T, int F, cf* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)T * F;
+    if (i >= n) return;
+    const int f = (int)(i % F);
+    cf acc = make_float2(0.f, 0.f);
+    for (int c = 0; c < C; ++c) acc = cadd(acc, cmulc(spec[(size_t)c * n + i], w[f * C + c]));
+    out[i] = acc;
+}
+
+hipError_t launch_beamform_spec(const float* w_fc, const float* spec, int C, int T, int F,
+                                float* out, hipStream_t s) {
+    const size_t n = (size_t)T * F;
+    hipLaunchKernelGGL(beamform_spec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const cf*>(w_fc), reinterpret_cast<const cf*>(spec), C, T,
+                       F, reinterpret_cast<cf*>(out));
+    return hipGetLastError();
+}
+
+}  // namespace setk

@@ -1,0 +1,603 @@
+// solve.hip -- batched per-bin weight solve (C x C complex, C <= 8), fp64.
+//
+// Replaces (funcwj/setk): solve_pevd (libs/beamformer.py:31-63: numpy eigh /
+// scipy eigh(A, B) in a python loop over bins), MvdrBeamformer.weight
+// (:527-539), GevdBeamformer.weight (:674-682), PmwfBeamformer.weight
+// (:632-659) + rank1_constraint (:66-84), MpdrBeamformer.weight (:555-571) and
+// do_ban (:14-28).
+//
+// One problem = one (utterance, bin).  8 lanes cooperate on a problem (lane j
+// owns column j), 8 problems per wavefront, one wavefront per workgroup:
+//   * principal eigenvectors: one-sided (Hestenes) Jacobi on the columns, the
+//     7 round-robin rounds of a sweep exchange columns with __shfl (width 8);
+//   * Cholesky of the (noise) covariance cooperatively in LDS (row per lane),
+//     triangular solves per lane (each lane its own right-hand side);
+//   * the generalised problem is reduced with the Cholesky factor
+//     (C~ = L^-1 Rs L^-H), solved by the same Jacobi and back-substituted.
+// The kernel is latency bound and negligible in bytes/flops next to the two
+// streaming passes; fp64 keeps it at least as accurate as the reference's
+// LAPACK c64/c128 calls.
+#include "common.h"
+#include <hip/hip_runtime.h>
+#include "../../include/setk_hip.h"
+
+namespace setk {
+
+typedef double2 cd;
+
+#define SD __device__ __forceinline__
+
+SD cd zadd(cd a, cd b) { return make_double2(a.x + b.x, a.y + b.y); }
+SD cd zsub(cd a, cd b) { return make_double2(a.x - b.x, a.y - b.y); }
+SD cd zmul(cd a, cd b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// a * conj(b)
+SD cd zmulc(cd a, cd b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+// conj(a) * b
+SD cd zcmul(cd a, cd b) { return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x); }
+SD cd zscale(cd a, double s) { return make_double2(a.x * s, a.y * s); }
+SD cd zdiv(cd a, cd b) {
+    const double d = b.x * b.x + b.y * b.y;
+    return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+SD double zabs2(cd a) { return a.x * a.x + a.y * a.y; }
+SD cd zshfl(cd v, int src) { return make_double2(__shfl(v.x, src, 8), __shfl(v.y, src, 8)); }
+
+constexpr int kKindPevd = 100;  // internal: plain solve_pevd(Rs[, Rn])
+constexpr double kEpsF32 = 1.1920928955078125e-07;
+
+// round-robin partner of lane j in round r (8 players, 7 rounds)
+SD int rr_partner(int r, int j) {
+    if (j == 7) return r;
+    int k = (2 * r - j) % 7;
+    if (k < 0) k += 7;
+    return (k == j) ? 7 : k;
+}
+
+// One-sided Jacobi on the columns of a Hermitian PSD matrix: lane j passes
+// column j in g.  Returns the principal eigenvector replicated in `out`
+// (unit 2-norm), its eigenvalue, and raises `noconv` on sweep exhaustion.
+template <int C>
+SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
+    cd v[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) v[i] = make_double2((i == j) ? 1.0 : 0.0, 0.0);
+    const double tol2 = 1e-24;  // |g_p^H g_q| <= 1e-12 |g_p||g_q|
+    bool done = false;
+    for (int sweep = 0; sweep < 40 && !done; ++sweep) {
+        bool rot = false;
+        for (int r = 0; r < 7; ++r) {
+            const int p = rr_partner(r, j);
+            cd gp[C], vp[C];
+            double m = 0.0, o = 0.0;
+            cd d = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                gp[i] = zshfl(g[i], p);
+                vp[i] = zshfl(v[i], p);
+                m += zabs2(g[i]);
+                o += zabs2(gp[i]);
+                d = zadd(d, zcmul(g[i], gp[i]));
+            }
+            const double dd = zabs2(d);
+            if (dd > tol2 * m * o && dd > 0.0) {
+                const double absd = sqrt(dd);
+                const double sigma = (j < p) ? 1.0 : -1.0;
+                const double zeta = sigma * (o - m) / (2.0 * absd);
+                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t);
+                const double sn = cs * t;
+                const double f = sigma * sn / absd;
+                const cd ph = make_double2(d.x * f, -d.y * f);  // sigma*sn*conj(d)/|d|
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    g[i] = zsub(zscale(g[i], cs), zmul(ph, gp[i]));
+                    v[i] = zsub(zscale(v[i], cs), zmul(ph, vp[i]));
+                }
+                rot = true;
+            }
+        }
+        done = !__any(rot);
+    }
+    if (!done) noconv = 1;
+    double m = 0.0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) m += zabs2(g[i]);
+    // argmax over the 8 lanes of the group (lowest lane wins ties)
+    double best = m;
+    int bj = j;
+#pragma unroll
+    for (int s = 1; s < 8; s <<= 1) {
+        const double ob = __shfl_xor(best, s, 8);
+        const int oj = __shfl_xor(bj, s, 8);
+        if (ob > best || (ob == best && oj < bj)) {
+            best = ob;
+            bj = oj;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < C; ++i) out[i] = zshfl(v[i], bj);
+    lam = sqrt(best);
+}
+
+template <int C>
+SD void fix_gauge(cd (&v)[C]) {
+    const double a = sqrt(zabs2(v[0]));
+    if (a > 0.0) {
+        const cd ph = make_double2(v[0].x / a, -v[0].y / a);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = zmul(v[i], ph);
+        v[0].y = 0.0;
+    }
+}
+
+// Cooperative Cholesky M = L L^H in LDS (column-major C x C, lane j = row j).
+// Returns 0 on success, 1 when a pivot is not positive.
+template <int C>
+SD int chol_lds(const cd* M, cd* L, double* piv, int j) {
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        cd s = make_double2(0.0, 0.0);
+        if (j >= k && j < C) {
+            s = M[k * C + j];  // M[j][k]
+            for (int m = 0; m < k; ++m) s = zsub(s, zmulc(L[m * C + j], L[m * C + k]));
+        }
+        if (j == k) *piv = s.x;
+        __syncthreads();
+        const double d = *piv;
+        if (!(d > 0.0)) bad = 1;
+        const double rd = (d > 0.0) ? 1.0 / sqrt(d) : 0.0;
+        if (j >= k && j < C) L[k * C + j] = (j == k) ? make_double2(d * rd, 0.0) : zscale(s, rd);
+        __syncthreads();
+    }
+    return bad;
+}
+
+// L y = b (in place on b)
+template <int C>
+SD void fwd_solve(const cd* L, cd (&b)[C]) {
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const double r = 1.0 / L[k * C + k].x;
+        b[k] = zscale(b[k], r);
+#pragma unroll
+        for (int i = k + 1; i < C; ++i) b[i] = zsub(b[i], zmul(L[k * C + i], b[k]));
+    }
+}
+// L^H x = y (in place on y)
+template <int C>
+SD void bwd_solve(const cd* L, cd (&y)[C]) {
+#pragma unroll
+    for (int k = C - 1; k >= 0; --k) {
+        cd s = y[k];
+#pragma unroll
+        for (int i = k + 1; i < C; ++i) s = zsub(s, zcmul(L[k * C + i], y[i]));
+        y[k] = zscale(s, 1.0 / L[k * C + k].x);
+    }
+}
+
+SD double group_sum(double v) {
+#pragma unroll
+    for (int s = 1; s < 8; s <<= 1) v += __shfl_xor(v, s, 8);
+    return v;
+}
+
+// generalised principal eigenvector of (Rs, Rn) with L = chol(Rn) already in
+// LDS: returns v = L^-H y, ||y|| = 1 (so v^H Rn v = 1), gauge on y.
+template <int C>
+SD void gev_vector(const cd* Rs, const cd* L, cd* Wk, int j, bool gauge, cd (&vout)[C],
+                   int& noconv) {
+    cd x[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) x[i] = (j < C) ? Rs[j * C + i] : make_double2(0.0, 0.0);
+    fwd_solve<C>(L, x);  // column j of X = L^-1 Rs
+    __syncthreads();
+    if (j < C) {
+#pragma unroll
+        for (int i = 0; i < C; ++i) Wk[j * C + i] = x[i];
+    }
+    __syncthreads();
+    cd c[C];
+#pragma unroll
+    for (int m = 0; m < C; ++m) {
+        const cd t = (j < C) ? Wk[m * C + j] : make_double2(0.0, 0.0);  // X[j][m]
+        c[m] = make_double2(t.x, -t.y);
+    }
+    fwd_solve<C>(L, c);  // column j of C~ = L^-1 X^H
+    if (j >= C) {
+#pragma unroll
+        for (int i = 0; i < C; ++i) c[i] = make_double2(0.0, 0.0);
+    }
+    cd y[C];
+    double lam;
+    jacobi_pevd<C>(c, j, y, lam, noconv);
+    if (gauge) fix_gauge<C>(y);
+    bwd_solve<C>(L, y);
+#pragma unroll
+    for (int i = 0; i < C; ++i) vout[i] = y[i];
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch) {
+    constexpr int NP = npairs(C);
+    __shared__ cd sRs[8][C * C];
+    __shared__ cd sRn[8][C * C];
+    __shared__ cd sRy[8][C * C];
+    __shared__ cd sL[8][C * C];
+    __shared__ cd sWk[8][C * C];
+    __shared__ double sPiv[8];
+
+    const int tid = threadIdx.x;
+    const int j = tid & 7, q = tid >> 3;
+    const int F = a.num_bins;
+    const long n_prob = (long)a.n_utts * F;
+    long prob = (long)blockIdx.x * 8 + q;
+    const bool live = prob < n_prob;
+    if (!live) prob = n_prob - 1;  // keep the lanes in step; no stores
+    const int u = (int)(prob / F), f = (int)(prob % F);
+
+    cd* Rs = sRs[q];
+    cd* Rn = sRn[q];
+    cd* Ry = sRy[q];
+    cd* L = sL[q];
+    cd* Wk = sWk[q];
+    double* piv = &sPiv[q];
+
+    const int kind = a.kind;
+    const bool gauge = (a.flags & SETK_FLAG_NO_GAUGE) == 0;
+    const bool need_rn = !(kind == kKindPevd && a.planes < 4 * NP) && kind != SETK_BF_MPDR;
+    const bool need_ry = (kind == SETK_BF_MPDR || kind == SETK_BF_MPDR_WHITEN);
+
+    // ---- load column j of each matrix from the packed planes ----
+    const float* base = a.covar + (size_t)u * a.planes * pitch + f;
+    bool finite = true;
+    if (j < C) {
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const int e = pair_index(lo, hi, C);
+            const double sgn = (i <= j) ? 1.0 : -1.0;  // (i,j) stored for i<=j
+            const float sr = base[(size_t)(0 * NP + e) * pitch];
+            const float si = base[(size_t)(1 * NP + e) * pitch];
+            Rs[j * C + i] = make_double2(sr, (i == j) ? 0.0 : sgn * si);
+            finite = finite && isfinite(sr) && isfinite(si);
+            if (need_rn || kind == SETK_BF_MPDR_WHITEN) {
+                const float nr = base[(size_t)(2 * NP + e) * pitch];
+                const float ni = base[(size_t)(3 * NP + e) * pitch];
+                Rn[j * C + i] = make_double2(nr, (i == j) ? 0.0 : sgn * ni);
+                finite = finite && isfinite(nr) && isfinite(ni);
+            }
+            if (need_ry) {
+                const float yr = base[(size_t)(4 * NP + e) * pitch];
+                const float yi = base[(size_t)(5 * NP + e) * pitch];
+                Ry[j * C + i] = make_double2(yr, (i == j) ? 0.0 : sgn * yi);
+                finite = finite && isfinite(yr) && isfinite(yi);
+            }
+        }
+    }
+    __syncthreads();
+
+    int st_sing = 0, st_noconv = 0;
+    cd w[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) w[i] = make_double2(0.0, 0.0);
+    const cd* ban_mat = Rn;
+
+    if (kind == kKindPevd && !need_rn) {
+        cd g[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) g[i] = (j < C) ? Rs[j * C + i] : make_double2(0.0, 0.0);
+        double lam;
+        jacobi_pevd<C>(g, j, w, lam, st_noconv);
+        if (gauge) fix_gauge<C>(w);
+    } else if (kind == kKindPevd || kind == SETK_BF_GEVD) {
+        st_sing |= chol_lds<C>(Rn, L, piv, j);
+        gev_vector<C>(Rs, L, Wk, j, gauge, w, st_noconv);
+    } else if (kind == SETK_BF_MVDR) {
+        cd g[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) g[i] = (j < C) ? Rs[j * C + i] : make_double2(0.0, 0.0);
+        cd d[C];
+        double lam;
+        jacobi_pevd<C>(g, j, d, lam, st_noconv);
+        if (gauge) fix_gauge<C>(d);
+        st_sing |= chol_lds<C>(Rn, L, piv, j);
+        cd num[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) num[i] = d[i];
+        fwd_solve<C>(L, num);
+        bwd_solve<C>(L, num);
+        cd den = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < C; ++i) den = zadd(den, zcmul(d[i], num[i]));
+#pragma unroll
+        for (int i = 0; i < C; ++i) w[i] = zdiv(num[i], den);
+    } else if (kind == SETK_BF_MPDR || kind == SETK_BF_MPDR_WHITEN) {
+        cd sv[C];
+        if (kind == SETK_BF_MPDR) {
+            cd g[C];
+#pragma unroll
+            for (int i = 0; i < C; ++i) g[i] = (j < C) ? Rs[j * C + i] : make_double2(0.0, 0.0);
+            double lam;
+            jacobi_pevd<C>(g, j, sv, lam, st_noconv);
+            if (gauge) fix_gauge<C>(sv);
+        } else {
+            st_sing |= chol_lds<C>(Rn, L, piv, j);
+            cd v[C];
+            gev_vector<C>(Rs, L, Wk, j, gauge, v, st_noconv);
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                cd s = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int m = 0; m < C; ++m) s = zadd(s, zmul(Rn[m * C + i], v[m]));
+                sv[i] = s;
+            }
+            __syncthreads();
+        }
+        st_sing |= chol_lds<C>(Ry, L, piv, j);
+        cd num[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) num[i] = sv[i];
+        fwd_solve<C>(L, num);
+        bwd_solve<C>(L, num);
+        cd den = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < C; ++i) den = zadd(den, zcmul(sv[i], num[i]));
+#pragma unroll
+        for (int i = 0; i < C; ++i) w[i] = zdiv(num[i], den);
+    } else if (kind == SETK_BF_PMWF) {
+        st_sing |= chol_lds<C>(Rn, L, piv, j);
+        if (a.rank1 != SETK_RANK1_NONE) {
+            cd pv[C];
+            if (a.rank1 == SETK_RANK1_EIG) {
+                cd g[C];
+#pragma unroll
+                for (int i = 0; i < C; ++i)
+                    g[i] = (j < C) ? Rs[j * C + i] : make_double2(0.0, 0.0);
+                double lam;
+                jacobi_pevd<C>(g, j, pv, lam, st_noconv);
+            } else {
+                cd v[C];
+                gev_vector<C>(Rs, L, Wk, j, false, v, st_noconv);
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    cd s = make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int m = 0; m < C; ++m) s = zadd(s, zmul(Rn[m * C + i], v[m]));
+                    pv[i] = s;
+                }
+            }
+            double tr = 0.0, pn = 0.0;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                tr += Rs[i * C + i].x;
+                pn += zabs2(pv[i]);
+            }
+            const double sc = tr / fmax(pn, kEpsF32);
+            __syncthreads();
+            if (j < C) {
+                cd pj = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int i = 0; i < C; ++i)
+                    if (i == j) pj = pv[i];
+#pragma unroll
+                for (int i = 0; i < C; ++i) Rs[j * C + i] = zscale(zmulc(pv[i], pj), sc);
+            }
+            __syncthreads();
+        }
+        cd x[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) x[i] = (j < C) ? Rs[j * C + i] : make_double2(0.0, 0.0);
+        fwd_solve<C>(L, x);
+        bwd_solve<C>(L, x);  // column j of Rn^-1 Rs
+        cd diag = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < C; ++i)
+            if (i == j) diag = x[i];
+        cd den = make_double2(group_sum(diag.x) + (double)a.pmwf_beta, group_sum(diag.y));
+#pragma unroll
+        for (int i = 0; i < C; ++i) x[i] = zdiv(x[i], den);
+        if (a.pmwf_ref >= 0) {
+#pragma unroll
+            for (int i = 0; i < C; ++i) w[i] = zshfl(x[i], a.pmwf_ref);
+        } else {
+            // estimated SNR of every candidate column (libs/beamformer.py:620-630)
+            cd us[C], un[C];
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                cd s1 = make_double2(0.0, 0.0), s2 = s1;
+#pragma unroll
+                for (int m = 0; m < C; ++m) {
+                    s1 = zadd(s1, zmul(Rs[m * C + i], x[m]));
+                    s2 = zadd(s2, zmul(Rn[m * C + i], x[m]));
+                }
+                us[i] = s1;
+                un[i] = s2;
+            }
+            double ps = 0.0, pn = 0.0;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                ps += zcmul(x[i], us[i]).x;
+                pn += zcmul(x[i], un[i]).x;
+            }
+            if (live && j < C) {
+                atomicAdd(&a.snr_acc[((size_t)u * C + j) * 2 + 0], ps);
+                atomicAdd(&a.snr_acc[((size_t)u * C + j) * 2 + 1], pn);
+                float2* wm = reinterpret_cast<float2*>(a.wmat) + ((size_t)prob * C + j) * C;
+#pragma unroll
+                for (int i = 0; i < C; ++i) wm[i] = make_float2((float)x[i].x, (float)x[i].y);
+            }
+        }
+    }
+
+    // ---- blind analytic normalisation (do_ban) ----
+    if ((a.flags & SETK_FLAG_BAN) && !(kind == SETK_BF_PMWF && a.pmwf_ref < 0)) {
+        cd uj = make_double2(0.0, 0.0);
+        cd wj = make_double2(0.0, 0.0);
+        if (j < C) {
+#pragma unroll
+            for (int m = 0; m < C; ++m) uj = zadd(uj, zmul(ban_mat[m * C + j], w[m]));
+#pragma unroll
+            for (int i = 0; i < C; ++i)
+                if (i == j) wj = w[i];
+        }
+        const double nom = group_sum(zabs2(uj));
+        const double den = group_sum(zcmul(wj, uj).x);
+        const double filt = sqrt(nom) / fmax(den, kEpsF32);
+#pragma unroll
+        for (int i = 0; i < C; ++i) w[i] = zscale(w[i], filt);
+    }
+
+    // ---- store ----
+    int st = SETK_NUM_OK;
+    if (st_noconv) st = SETK_NUM_NOCONV;
+    if (st_sing) st = SETK_NUM_SINGULAR;
+    bool wfin = true;
+#pragma unroll
+    for (int i = 0; i < C; ++i) wfin = wfin && isfinite(w[i].x) && isfinite(w[i].y);
+    if (!__all(finite) || !wfin) st = (st == SETK_NUM_OK) ? SETK_NUM_NONFINITE : st;
+    if (live) {
+        if (j < C && !(kind == SETK_BF_PMWF && a.pmwf_ref < 0)) {
+            cd wj = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int i = 0; i < C; ++i)
+                if (i == j) wj = w[i];
+            float2* dst = reinterpret_cast<float2*>(a.weight) + ((size_t)u * C + j) * pitch + f;
+            *dst = make_float2((float)wj.x, (float)wj.y);
+        }
+        if (j == 0) {
+            if (a.bin_status) a.bin_status[prob] = st;
+            if (a.status && st) atomicMax(a.status + u, st);
+        }
+    }
+}
+
+hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
+    const long n_prob = (long)a.n_utts * a.num_bins;
+    const int blocks = (int)((n_prob + 7) / 8);
+    const int pitch = (a.num_bins == kBins) ? kBinsPad : ((a.num_bins + 7) / 8) * 8;
+#define SETK_CASE(c)                                                                   \
+    case c:                                                                            \
+        hipLaunchKernelGGL(solve_kernel<c>, dim3(blocks), dim3(64), 0, s, a, pitch);   \
+        break;
+    switch (a.num_channels) {
+        SETK_CASE(1)
+        SETK_CASE(2)
+        SETK_CASE(3)
+        SETK_CASE(4)
+        SETK_CASE(5)
+        SETK_CASE(6)
+        SETK_CASE(7)
+        SETK_CASE(8)
+        default:
+            return hipErrorInvalidValue;
+    }
+#undef SETK_CASE
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// PMWF with SNR-selected reference channel: pick argmax_c ps/max(eps, pn) per
+// utterance (libs/beamformer.py:650-653), copy that column out, optional BAN.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pmwf_select_kernel(SolveArgs a, int pitch, int* ref_out) {
+    const int u = blockIdx.y;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int C = a.num_channels, F = a.num_bins;
+    const int NP = npairs(C);
+    int ref = 0;
+    double best = -1e300;
+    for (int c = 0; c < C; ++c) {
+        const double ps = a.snr_acc[((size_t)u * C + c) * 2 + 0];
+        const double pn = a.snr_acc[((size_t)u * C + c) * 2 + 1];
+        const double r = ps / fmax(kEpsF32, pn);
+        if (r > best) {
+            best = r;
+            ref = c;
+        }
+    }
+    if (f == 0 && ref_out) ref_out[u] = ref;
+    if (f >= F) return;
+    const size_t prob = (size_t)u * F + f;
+    const float2* wm = reinterpret_cast<const float2*>(a.wmat) + (prob * C + ref) * C;
+    double2 w[kMaxChannels];
+    for (int i = 0; i < C; ++i) w[i] = make_double2(wm[i].x, wm[i].y);
+    if (a.flags & SETK_FLAG_BAN) {
+        const float* base = a.covar + (size_t)u * a.planes * pitch + f;
+        double nom = 0.0, den = 0.0;
+        for (int i = 0; i < C; ++i) {
+            double2 ui = make_double2(0.0, 0.0);
+            for (int m = 0; m < C; ++m) {
+                const int lo = i < m ? i : m, hi = i < m ? m : i;
+                const int e = pair_index(lo, hi, C);
+                const double re = base[(size_t)(2 * NP + e) * pitch];
+                double im = (i == m) ? 0.0 : base[(size_t)(3 * NP + e) * pitch];
+                if (i > m) im = -im;  // Rn[i][m] = conj(Rn[m][i])
+                ui.x += re * w[m].x - im * w[m].y;
+                ui.y += re * w[m].y + im * w[m].x;
+            }
+            nom += ui.x * ui.x + ui.y * ui.y;
+            den += w[i].x * ui.x + w[i].y * ui.y;
+        }
+        const double filt = sqrt(nom) / fmax(den, kEpsF32);
+        for (int i = 0; i < C; ++i) {
+            w[i].x *= filt;
+            w[i].y *= filt;
+        }
+    }
+    for (int i = 0; i < C; ++i) {
+        float2* dst = reinterpret_cast<float2*>(a.weight) + ((size_t)u * C + i) * pitch + f;
+        *dst = make_float2((float)w[i].x, (float)w[i].y);
+    }
+}
+
+hipError_t launch_pmwf_select(const SolveArgs& a, int* ref_out, hipStream_t s) {
+    const int pitch = (a.num_bins == kBins) ? kBinsPad : ((a.num_bins + 7) / 8) * 8;
+    dim3 grid((a.num_bins + 255) / 256, a.n_utts);
+    hipLaunchKernelGGL(pmwf_select_kernel, grid, dim3(256), 0, s, a, pitch, ref_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// layout helpers for the modular API
+// ---------------------------------------------------------------------------
+// covar[F][C][C] complex64 -> packed planes [2*NP][pitch] starting at plane0
+__global__ void pack_covar_kernel(const float2* fcc, int F, int C, int pitch, float* planes,
+                                  int plane0) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= pitch) return;
+    const int NP = npairs(C);
+    for (int i = 0; i < C; ++i)
+        for (int j = i; j < C; ++j) {
+            const int e = pair_index(i, j, C);
+            float2 v = make_float2(0.f, 0.f);
+            if (f < F) v = fcc[((size_t)f * C + i) * C + j];
+            planes[(size_t)(plane0 + e) * pitch + f] = v.x;
+            planes[(size_t)(plane0 + NP + e) * pitch + f] = v.y;
+        }
+}
+
+hipError_t launch_pack_covar(const float* fcc, int F, int C, float* planes, int plane0,
+                             hipStream_t s) {
+    const int pitch = (F == kBins) ? kBinsPad : ((F + 7) / 8) * 8;
+    hipLaunchKernelGGL(pack_covar_kernel, dim3((pitch + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(fcc), F, C, pitch, planes, plane0);
+    return hipGetLastError();
+}
+
+// weight planes [C][pitch] float2 -> w[F][C] complex64
+__global__ void unpack_weight_kernel(const float2* wp, int F, int C, int pitch, float2* w_fc) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    for (int c = 0; c < C; ++c) w_fc[(size_t)f * C + c] = wp[(size_t)c * pitch + f];
+}
+
+hipError_t launch_unpack_weight(const float* wplanes, int F, int C, float* w_fc, hipStream_t s) {
+    const int pitch = (F == kBins) ? kBinsPad : ((F + 7) / 8) * 8;
+    hipLaunchKernelGGL(unpack_weight_kernel, dim3((F + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(wplanes), F, C, pitch,
+                       reinterpret_cast<float2*>(w_fc));
+    return hipGetLastError();
+}
+
+}  // namespace setk

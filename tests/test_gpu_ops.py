@@ -1,0 +1,185 @@
+"""
+GPU parity of every C-ABI operator against the CPU oracle (same seeded inputs).
+Tolerances: STFT <= 1e-4 relative RMS, waveform <= 1e-3 (BASELINE north_star);
+eigenvector-carrying outputs are compared under the declared gauge.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rms, rel_rms
+from oracle import np_oracle as o
+from oracle import make_golden as mg
+
+pytestmark = pytest.mark.gpu
+
+STFT_KW = dict(frame_len=512, frame_hop=256, window="hann", center=True)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from setk_amd import _ffi
+    c = _ffi.Context(0)
+    c.stft_plan(512, 256, 512, True)
+    yield c
+    c.close()
+
+
+def tmajor(obs):
+    """N x F x T (reference layout) -> [C][T][F] contiguous."""
+    return np.ascontiguousarray(np.transpose(obs, (0, 2, 1)))
+
+
+def gpu_stft(ctx, samps):
+    samps = np.ascontiguousarray(samps, dtype=np.float32)
+    C, N = samps.shape
+    T = ctx.num_frames(N)
+    out = np.empty((C, T, 257), dtype=np.complex64)
+    ctx.stft(samps, out)
+    return out
+
+
+@pytest.mark.parametrize("C,N", [(1, 4000), (4, 8192), (5, 6001), (8, 16000), (11, 5000)])
+def test_stft_parity(ctx, C, N):
+    ctx.stft_plan(512, 256, 512, True)
+    x = o.synth_utterance(7, C, N)
+    ref = o.multichannel_stft(x, transpose=False, **STFT_KW)
+    if ref.ndim == 2:
+        ref = ref[None]
+    got = gpu_stft(ctx, x)
+    assert got.shape == (C, ref.shape[2], 257)
+    assert rel_rms(got, tmajor(ref)) < 1e-4
+    assert np.max(np.abs(got - tmajor(ref))) < 1e-4 * np.max(np.abs(ref))
+
+
+def test_stft_goldens(ctx):
+    g = load_golden("ref_stft.npz")
+    for name, N, fl, hop, center, rp2, window in mg.STFT_CASES:
+        n_fft = o.nextpow2(fl) if rp2 else fl
+        if n_fft != 512:
+            continue
+        win = o.make_window(window, fl).astype(np.float32)
+        ctx.stft_plan(fl, hop, n_fft, center, win)
+        x = g[f"{name}.x"]
+        got = gpu_stft(ctx, x[None])[0]
+        ref = g[f"{name}.S"].T
+        assert got.shape == ref.shape, name
+        assert rel_rms(got, ref) < 1e-4, name
+        # inverse on the reference spectrogram
+        S = np.ascontiguousarray(ref[None])
+        L = ctx.istft_num_samples(S.shape[1])
+        y = np.empty((1, L), dtype=np.float32)
+        ctx.istft(S, 1, S.shape[1], None, None, y)
+        assert y.shape[1] == g[f"{name}.y"].shape[0], name
+        # center=False leaves the first samples divided by window^2 ~ 1e-9
+        # (ill-conditioned in float32 on both sides): looser absolute bound
+        tol = 1e-5 if center else 1e-4
+        assert rms(y[0], g[f"{name}.y"]) < tol, name
+        yn = np.empty((1, L), dtype=np.float32)
+        ctx.istft(S, 1, S.shape[1], None, np.array([0.5], np.float32), yn)
+        assert rms(yn[0], g[f"{name}.y_norm"]) < tol, name
+    ctx.stft_plan(512, 256, 512, True)
+
+
+def test_istft_length_and_batch(ctx):
+    ctx.stft_plan(512, 256, 512, True)
+    x = o.synth_utterance(3, 3, 9000)
+    S = o.multichannel_stft(x, transpose=False, **STFT_KW)
+    St = tmajor(S)
+    for nsamps in (None, 9000, 4000, 12000):
+        L = ctx.istft_num_samples(St.shape[1], nsamps)
+        y = np.empty((3, L), dtype=np.float32)
+        ctx.istft(St, 3, St.shape[1], nsamps, None, y)
+        for c in range(3):
+            ref = o.inverse_stft(S[c], transpose=False, nsamps=nsamps, **STFT_KW)
+            assert ref.shape[0] == L
+            assert rms(y[c], ref) < 1e-5
+
+
+def test_roundtrip_property_full_size(ctx):
+    """istft(stft(x)) == x at BASELINE size (30 s), size independent property."""
+    ctx.stft_plan(512, 256, 512, True)
+    x = o.synth_utterance(0, 2, 480000)
+    S = gpu_stft(ctx, x)
+    L = ctx.istft_num_samples(S.shape[1])
+    y = np.empty((2, L), dtype=np.float32)
+    ctx.istft(S, 2, S.shape[1], None, None, y)
+    assert L == 480000
+    assert rms(y, x[:, :L]) / rms(x) < 1e-5
+
+
+@pytest.mark.parametrize("case", mg.BF_CASES, ids=[c[0] for c in mg.BF_CASES])
+def test_covar_pevd_weights(ctx, case):
+    from setk_amd import _ffi
+    name = case[0]
+    mix, mask = mg.bf_inputs(case)
+    obs = o.multichannel_stft(mix, transpose=False, **STFT_KW)
+    C, F, T = obs.shape
+    spec = tmajor(obs)
+    Rs_ref = np.ascontiguousarray(o.compute_covar(obs, mask).astype(np.complex64))
+    Rn_ref = np.ascontiguousarray(o.compute_covar(obs, 1 - mask).astype(np.complex64))
+    Rs = np.empty((F, C, C), np.complex64)
+    ctx.covar(spec, np.ascontiguousarray(mask), C, T, F, Rs)
+    assert rel_rms(Rs, Rs_ref) < 1e-5
+    # Hermitian property (reference test-beamformer.cc:34-48)
+    assert np.max(np.abs(Rs - np.conj(np.transpose(Rs, (0, 2, 1))))) == 0
+    # principal eigenvector, plain and generalised (gauge fixed on both sides)
+    st = np.zeros(F, np.int32)
+    pv = np.empty((F, C), np.complex64)
+    ctx.pevd(Rs_ref, None, F, C, 0, pv, st)
+    assert not st.any()
+    assert rel_rms(pv, o.fix_gauge_evd(o.solve_pevd(Rs_ref))) < 1e-4
+    ctx.pevd(Rs_ref, Rn_ref, F, C, 0, pv, st)
+    assert not st.any()
+    ref = o.fix_gauge_gev(o.solve_pevd(Rs_ref, Rn_ref), Rn_ref.astype(np.complex128))
+    assert rel_rms(pv, ref) < 1e-4
+    Ry_ref = np.ascontiguousarray(o.compute_covar(obs, np.ones_like(mask)).astype(np.complex64))
+    kinds = [
+        ("mvdr", _ffi.BF_MVDR, {}, lambda: o.mvdr_weight(Rs_ref, Rn_ref, gauge=True)),
+        ("gevd", _ffi.BF_GEVD, {}, lambda: o.gevd_weight(Rs_ref, Rn_ref, gauge=True)),
+        ("pmwf0", _ffi.BF_PMWF, dict(pmwf_ref=-1),
+         lambda: o.pmwf_weight(Rs_ref, Rn_ref, beta=0)),
+        ("pmwf1_ref1", _ffi.BF_PMWF, dict(pmwf_beta=1.0, pmwf_ref=1),
+         lambda: o.pmwf_weight(Rs_ref, Rn_ref, beta=1, ref_channel=1)),
+        ("pmwf0_eig", _ffi.BF_PMWF, dict(pmwf_ref=-1, rank1=_ffi.RANK1_EIG),
+         lambda: o.pmwf_weight(Rs_ref, Rn_ref, rank1_appro="eig")),
+        ("pmwf0_gev", _ffi.BF_PMWF, dict(pmwf_ref=-1, rank1=_ffi.RANK1_GEV),
+         lambda: o.pmwf_weight(Rs_ref, Rn_ref, rank1_appro="gev")),
+        ("mpdr", _ffi.BF_MPDR, {}, lambda: o.mpdr_weight(Rs_ref, Ry_ref, gauge=True)),
+        ("mpdr_whiten", _ffi.BF_MPDR_WHITEN, {},
+         lambda: o.mpdr_weight(Rs_ref, Ry_ref, Rn=Rn_ref, gauge=True)),
+    ]
+    for kname, kind, kw, ref_fn in kinds:
+        for ban in (False, True):
+            if ban and kind == _ffi.BF_MPDR:
+                continue
+            opts = _ffi.BfOpts(kind=kind, flags=_ffi.FLAG_BAN if ban else 0,
+                               pmwf_beta=kw.get("pmwf_beta", 0.0),
+                               pmwf_ref=kw.get("pmwf_ref", -1),
+                               rank1=kw.get("rank1", 0))
+            w = np.empty((F, C), np.complex64)
+            ctx.weights(opts, Rs_ref, Rn_ref, Ry_ref, F, C, w, st)
+            assert not st.any(), (name, kname)
+            wref = ref_fn()
+            if ban:
+                wref = o.do_ban(wref, Rn_ref)
+            assert rel_rms(w, wref) < 2e-4, (name, kname, ban, rel_rms(w, wref))
+    # beamform
+    wref = o.mvdr_weight(Rs_ref, Rn_ref, gauge=True).astype(np.complex64)
+    out = np.empty((T, F), np.complex64)
+    ctx.beamform(wref, spec, C, T, F, out)
+    assert rel_rms(out, o.beamform(wref, obs).T) < 1e-5
+
+
+def test_singular_noise_covariance_is_reported(ctx):
+    from setk_amd import _ffi
+    F, C = 9, 4
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((F, C, C)) + 1j * rng.standard_normal((F, C, C))
+    Rs = (A @ np.conj(np.transpose(A, (0, 2, 1)))).astype(np.complex64)
+    Rn = Rs.copy()
+    Rn[3] = 0  # all-zero noise mask in bin 3 -> LinAlgError in the reference
+    st = np.zeros(F, np.int32)
+    w = np.empty((F, C), np.complex64)
+    ctx.weights(_ffi.BfOpts(kind=_ffi.BF_MVDR), Rs, Rn, None, F, C, w, st)
+    assert st[3] == _ffi.NUM_SINGULAR
+    assert not st[[0, 1, 2, 4, 5, 6, 7, 8]].any()
