@@ -180,7 +180,8 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts,
 
 /* Stage timings (ms, hipEvent on `stream`) of the most recent
  * setk_enhance_batch when profiling was enabled with setk_set_profiling(h,1):
- * out[0..3] = stft+covar, solve, beamform+istft, renorm.  */
+ * out[0] = the fused STFT+covariance kernel alone, out[1] = partial reduction +
+ * weight solve, out[2] = beamform+iSTFT kernel, out[3] = renorm kernel.  */
 int setk_set_profiling(setk_handle_t h, int enable);
 int setk_last_stage_ms(setk_handle_t h, float out[4]);
 

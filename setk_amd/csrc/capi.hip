@@ -47,9 +47,9 @@ struct setk_context {
     size_t d_desc_cap = 0;
     // profiling
     bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;   // free events
+    std::vector<hipEvent_t> ev_used;   // 5 per profiled call, in call order
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    float stage_ms[4] = {0, 0, 0, 0};
-    bool stage_valid = false;
     // tunables
     int p1_items = 1024;
     int p2_items = 1024;
@@ -224,8 +224,8 @@ int setk_destroy(setk_handle_t h) {
     if (h->d_tw256) (void)hipFree(h->d_tw256);
     if (h->d_tw512) (void)hipFree(h->d_tw512);
     if (h->d_desc) (void)hipFree(h->d_desc);
-    for (auto& e : h->ev)
-        if (e) (void)hipEventDestroy(e);
+    for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
+    for (auto& e : h->ev_used) (void)hipEventDestroy(e);
     delete h;
     return SETK_OK;
 }
@@ -235,21 +235,28 @@ const char* setk_last_error(setk_handle_t h) { return h ? h->err.c_str() : "null
 int setk_set_profiling(setk_handle_t h, int enable) {
     if (!h) return SETK_ERR_INVALID;
     h->profiling = enable != 0;
-    if (h->profiling)
-        for (auto& e : h->ev)
-            if (!e) HIP_TRY(h, hipEventCreate(&e));
     return SETK_OK;
 }
 
+// mean stage times (ms) over the profiled setk_enhance_batch calls since the
+// last query; the recorded events are recycled.
 int setk_last_stage_ms(setk_handle_t h, float out[4]) {
     if (!h || !out) return SETK_ERR_INVALID;
-    if (!h->stage_valid) return fail(h, SETK_ERR_INVALID, "no profiled run available");
-    for (int i = 0; i < 4; ++i) {
-        float ms = 0.f;
-        HIP_TRY(h, hipEventSynchronize(h->ev[i + 1]));
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-        out[i] = ms;
+    const size_t calls = h->ev_used.size() / 5;
+    if (calls == 0) return fail(h, SETK_ERR_INVALID, "no profiled run available");
+    double acc[4] = {0, 0, 0, 0};
+    for (size_t c = 0; c < calls; ++c) {
+        hipEvent_t* e = &h->ev_used[c * 5];
+        HIP_TRY(h, hipEventSynchronize(e[4]));
+        for (int i = 0; i < 4; ++i) {
+            float ms = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, e[i], e[i + 1]));
+            acc[i] += ms;
+        }
     }
+    for (int i = 0; i < 4; ++i) out[i] = (float)(acc[i] / (double)calls);
+    for (auto& e : h->ev_used) h->ev_pool.push_back(e);
+    h->ev_used.clear();
     return SETK_OK;
 }
 
@@ -734,10 +741,22 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
     HIP_TRY(h, hipMemsetAsync(d_small, 0, (size_t)n_utts * 3 * 4, s));
 
     const bool prof = h->profiling;
-    h->stage_valid = false;
-    if (prof) HIP_TRY(h, hipEventRecord(h->ev[0], s));
+    if (prof) {
+        for (int i = 0; i < 5; ++i) {
+            hipEvent_t e;
+            if (!h->ev_pool.empty()) {
+                e = h->ev_pool.back();
+                h->ev_pool.pop_back();
+            } else {
+                HIP_TRY(h, hipEventCreate(&e));
+            }
+            h->ev[i] = e;
+            h->ev_used.push_back(e);
+        }
+        HIP_TRY(h, hipEventRecord(h->ev[0], s));
+    }
 
-    // ---- stage 1: STFT + covariance partials, finalize ----
+    // ---- stage 1: STFT + covariance partials (timed alone), then finalize ----
     Pass1Args p1;
     memset(&p1, 0, sizeof(p1));
     p1.utts = d_uds;
@@ -750,6 +769,7 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
     p1.g = g;
     p1.flags = opts->flags;
     HIP_TRY(h, launch_pass1(C, false, p1, (int)items1.size(), s));
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[1], s));
     FinalizeArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.utts = d_uds;
@@ -758,7 +778,6 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
     fa.num_channels = C;
     fa.with_ry = mpdr ? 1 : 0;
     HIP_TRY(h, launch_finalize(fa, n_utts, s));
-    if (prof) HIP_TRY(h, hipEventRecord(h->ev[1], s));
 
     // ---- stage 2: weights ----
     SolveArgs sa;
@@ -810,10 +829,7 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
     sc.outmax_bits = d_omax;
     sc.pcm16 = pcm16 ? 1 : 0;
     HIP_TRY(h, launch_scale(sc, n_utts, max_len, s));
-    if (prof) {
-        HIP_TRY(h, hipEventRecord(h->ev[4], s));
-        h->stage_valid = true;
-    }
+    if (prof) HIP_TRY(h, hipEventRecord(h->ev[4], s));
     if (status) {
         HIP_TRY(h, hipMemcpyAsync(status, d_status, (size_t)n_utts * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
