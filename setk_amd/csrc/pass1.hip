@@ -2,18 +2,26 @@
 //
 // Replaces (funcwj/setk): SpectrogramReader._load (libs/data_handler.py:492-503)
 // -> forward_stft (libs/utils.py:96-138) -> compute_covar x2
-// (libs/beamformer.py:87-103, 279-281).  X is never written to HBM: a
-// workgroup walks a contiguous frame range of one utterance in tiles of
-// TB = 32/C frames, transforms all C channels of the tile into LDS, and every
-// thread (= one frequency bin) folds the tile's outer products x x^H, weighted
-// by the speech and noise masks, into register accumulators.  The per-range
-// sums leave the chip once, as a partial slab, reduced by covar_finalize.
+// (libs/beamformer.py:87-103, 279-281).  X is never written to HBM.
 //
-// Roofline: HBM bound by construction (4*C*N + 4*T*F bytes per utterance), but
-// at C = 8 the VALU work (FFT ~173 MF + outer products ~208 MF per 30 s
-// utterance) is of the same order as the HBM time -- see DESIGN.md.
+// A 512-thread workgroup walks a contiguous frame range of one utterance in
+// tiles of TB = 32/C frames:
+//   produce  each of the 32 quad-rows (16 lanes) transforms one (frame,
+//            channel) pair on its own -- global load + window, radix-16,
+//            LDS transpose, radix-16, Hermitian split -- with no workgroup
+//            barrier inside (a quad-row lives in one wavefront);
+//   consume  thread (f, h) = (tid & 255, tid >> 8) folds the tile's outer
+//            products x x^H of bin f, weighted by the speech and noise masks,
+//            into register accumulators; the Hermitian pairs are split between
+//            the two halves h so that a thread carries <= 72 accumulators and
+//            two workgroups (4 waves/SIMD) fit a CU.
+// The per-range sums leave the chip once, as a partial slab reduced by
+// covar_finalize.  Roofline: HBM by construction (4*C*N + 4*T*F bytes per
+// utterance); at C = 8 the VALU work is of the same order -- see DESIGN.md.
 #include "common.h"
 #include "fft512.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace setk {
 
@@ -60,48 +68,104 @@ SETK_DEV void load_frame(cf (&v)[16], const float* __restrict__ x, int n_samp, i
     }
 }
 
-SETK_DEV float block_max_256(float v, float* red) {
+// One quad-row: full forward real transform of the frame in v; on return the
+// slot holds X[0..255] and *nyq = X[256].  No workgroup barrier: the 16 lanes
+// share a wavefront and LDS operations of a wavefront complete in order.
+SETK_DEV void quadrow_rfft(cf (&v)[16], cf* slot, float* nyq, const cf* tw, const cf* tw5,
+                           int la) {
+    fft256_stage_a<-1>(v, slot, tw, la);
+    __builtin_amdgcn_wave_barrier();
+    fft256_stage_b<-1>(v, slot, la);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) red[w] = v;
-    __syncthreads();
-    v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    return v;
+    for (int kb = 0; kb < 16; ++kb) slot[la + 16 * kb] = v[dft16_pos(kb)];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int k = la + 16 * m;
+        const cf Zk = slot[k];
+        const cf Zm = slot[(256 - k) & 255];
+        cf Xk, Xm;
+        rfft_split(Zk, Zm, tw5[k], Xk, Xm);
+        if (k == 0) {
+            const cf Z128 = slot[128];
+            slot[0] = make_float2(Xk.x, 0.f);
+            *nyq = Xm.x;
+            slot[128] = make_float2(Z128.x, -Z128.y);
+        } else {
+            slot[k] = Xk;
+            slot[256 - k] = Xm;
+        }
+    }
 }
 
+// outer products of the pairs [LO, HI) of the (i <= j) enumeration
+template <int C, int LO, int HI>
+SETK_DEV void accumulate_pairs(const cf (&x)[C], float ws, float wn, cf* acc_s, cf* acc_n) {
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+#pragma unroll
+        for (int j = i; j < C; ++j) {
+            if (e >= LO && e < HI) {
+                const cf p = cmulc(x[i], x[j]);
+                acc_s[e - LO].x = fmaf(ws, p.x, acc_s[e - LO].x);
+                acc_n[e - LO].x = fmaf(wn, p.x, acc_n[e - LO].x);
+                if (i != j) {
+                    acc_s[e - LO].y = fmaf(ws, p.y, acc_s[e - LO].y);
+                    acc_n[e - LO].y = fmaf(wn, p.y, acc_n[e - LO].y);
+                }
+            }
+            ++e;
+        }
+}
+
+template <int C, int LO, int HI>
+SETK_DEV void store_pairs(float* P, int f, const cf* acc_s, const cf* acc_n) {
+    constexpr int NP = npairs(C);
+    constexpr int FP = kBinsPad;
+#pragma unroll
+    for (int e = LO; e < HI; ++e) {
+        P[(0 * NP + e) * FP + f] = acc_s[e - LO].x;
+        P[(1 * NP + e) * FP + f] = acc_s[e - LO].y;
+        P[(2 * NP + e) * FP + f] = acc_n[e - LO].x;
+        P[(3 * NP + e) * FP + f] = acc_n[e - LO].y;
+    }
+}
+
+constexpr int kP1Threads = 512;
+
 template <int C, bool DUMP>
-__global__ __launch_bounds__(256) void stft_covar_kernel(Pass1Args a) {
+__global__ __launch_bounds__(kP1Threads, 2) void stft_covar_kernel(Pass1Args a) {
     constexpr int TB = 32 / C;  // frames per tile
     constexpr int NF = TB * C;  // transforms per tile (<= 32)
     constexpr int NP = npairs(C);
+    constexpr int NPH = (NP + 1) / 2;  // pairs of half 0; half 1 takes the rest
     constexpr int F = kBins, FP = kBinsPad;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cf* xt = reinterpret_cast<cf*>(smem);           // [NF][256]
-    cf* tw = xt + NF * 256;                         // [16][16]
-    float* win = reinterpret_cast<float*>(tw + 256);  // [512]
-    float* xn = win + kNfft;                        // [NF] nyquist bins (real)
-    float* red = xn + 32;                           // [4]
+    cf* xt = reinterpret_cast<cf*>(smem);             // [NF][256]
+    cf* tw = xt + NF * 256;                           // [16][16]
+    cf* tw5 = tw + 256;                               // [128]
+    float* win = reinterpret_cast<float*>(tw5 + 128);  // [512]
+    float* xn = win + kNfft;                          // [32] nyquist bins (real)
+    float* red = xn + 32;                             // [8]
 
     const int tid = threadIdx.x;
     const int la = tid & 15, grp = tid >> 4;
+    const int f = tid & 255, h = tid >> 8;
     const WorkItem wi = a.items[blockIdx.x];
     const UttDesc ud = a.utts[wi.utt];
     const int n_samp = ud.num_samples;
     const int T = ud.num_frames;
 
-    tw[tid] = a.tw256[tid];
+    if (tid < 256) tw[tid] = a.tw256[tid];
+    if (tid < 128) tw5[tid] = a.tw512[tid];
     win[tid] = a.window[tid];
-    win[tid + 256] = a.window[tid + 256];
-    const cf wsplit = a.tw512[tid & 127];
 
-    // covariance accumulators of bin f = tid
-    cf acc_s[NP], acc_n[NP];
+    cf acc_s[NPH], acc_n[NPH];
     float sum_s = 0.f, sum_n = 0.f;
 #pragma unroll
-    for (int e = 0; e < NP; ++e) {
+    for (int e = 0; e < NPH; ++e) {
         acc_s[e] = make_float2(0.f, 0.f);
         acc_n[e] = make_float2(0.f, 0.f);
     }
@@ -128,9 +192,10 @@ __global__ __launch_bounds__(256) void stft_covar_kernel(Pass1Args a) {
 
     const bool clamp = (a.flags & 0x2) != 0;
     const bool has_mn = ud.mask_n != nullptr;
+    const int my_tt = grp / C, my_c = grp - my_tt * C;  // this quad-row's transform
 
     for (int tb = wi.t0; tb < wi.t1; tb += TB) {
-        // ---- mask prefetch (bin tid, nyquist column for the ny threads) ----
+        // ---- mask prefetch (bin f, nyquist column for the ny threads) ----
         float ms[TB], mn[TB], nyw[TB];
         if (!DUMP) {
 #pragma unroll
@@ -139,9 +204,9 @@ __global__ __launch_bounds__(256) void stft_covar_kernel(Pass1Args a) {
                 const bool valid = t < wi.t1;
                 float s = 0.f, n = 0.f, w = 0.f;
                 if (valid) {
-                    s = ud.mask_s[(size_t)t * F + tid];
+                    s = ud.mask_s[(size_t)t * F + f];
                     if (clamp) s = fminf(s, 1.f);
-                    n = has_mn ? ud.mask_n[(size_t)t * F + tid] : 1.f - s;
+                    n = has_mn ? ud.mask_n[(size_t)t * F + f] : 1.f - s;
                     if (ny_active) {
                         float s256 = ud.mask_s[(size_t)t * F + 256];
                         if (clamp) s256 = fminf(s256, 1.f);
@@ -157,84 +222,42 @@ __global__ __launch_bounds__(256) void stft_covar_kernel(Pass1Args a) {
         }
         __syncthreads();  // tables ready / previous tile fully consumed
 
-        // ---- stage A: radix-16 over the strided points, transpose to LDS ----
-        for (int i = grp; i < NF; i += 16) {
-            const int tt = i / C, c = i - tt * C;
-            const int t = tb + tt;
+        // ---- produce: one transform per quad-row ----
+        if (grp < NF) {
+            const int t = tb + my_tt;
             cf v[16];
-            load_frame(v, ud.audio + (size_t)c * n_samp, n_samp, t * a.g.hop - a.g.pad, la, win,
+            load_frame(v, ud.audio + (size_t)my_c * n_samp, n_samp, t * a.g.hop - a.g.pad, la, win,
                        t < wi.t1, mx);
-            fft256_stage_a<-1>(v, xt + i * 256, tw, la);
-        }
-        __syncthreads();
-        // ---- stage B: second radix-16, natural-order Z into the slot ----
-        for (int i = grp; i < NF; i += 16) {
-            cf v[16];
-            cf* slot = xt + i * 256;
-            fft256_stage_b<-1>(v, slot, la);
-#pragma unroll
-            for (int kb = 0; kb < 16; ++kb) slot[la + 16 * kb] = v[dft16_pos(kb)];
-        }
-        __syncthreads();
-        // ---- Hermitian split in place: Z -> X[0..255], nyquist aside ----
-        for (int i = tid >> 7; i < NF; i += 2) {
-            const int k = tid & 127;
-            cf* slot = xt + i * 256;
-            const cf Zk = slot[k];
-            const cf Zm = slot[(256 - k) & 255];
-            cf Xk, Xm;
-            rfft_split(Zk, Zm, wsplit, Xk, Xm);
-            if (k == 0) {
-                const cf Z128 = slot[128];
-                slot[0] = make_float2(Xk.x, 0.f);
-                xn[i] = Xm.x;
-                slot[128] = make_float2(Z128.x, -Z128.y);
-            } else {
-                slot[k] = Xk;
-                slot[256 - k] = Xm;
-            }
+            quadrow_rfft(v, xt + grp * 256, xn + grp, tw, tw5, la);
         }
         __syncthreads();
 
         if (DUMP) {
             // spec[c][t][f], f fastest
-#pragma unroll
-            for (int tt = 0; tt < TB; ++tt) {
+            for (int i = h; i < NF; i += 2) {
+                const int tt = i / C, c = i - tt * C;
                 const int t = tb + tt;
                 if (t < wi.t1) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        float2* dst = reinterpret_cast<float2*>(a.spec_dump) +
-                                      ((size_t)c * T + t) * F;
-                        dst[tid] = xt[(tt * C + c) * 256 + tid];
-                        if (tid == 0) dst[256] = make_float2(xn[tt * C + c], 0.f);
-                    }
+                    float2* dst = reinterpret_cast<float2*>(a.spec_dump) + ((size_t)c * T + t) * F;
+                    dst[f] = xt[i * 256 + f];
+                    if (f == 0) dst[256] = make_float2(xn[i], 0.f);
                 }
             }
         } else {
-            // ---- masked outer products, bin f = tid ----
+            // ---- consume: masked outer products of bin f, pair half h ----
 #pragma unroll
             for (int tt = 0; tt < TB; ++tt) {
                 cf x[C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) x[c] = xt[(tt * C + c) * 256 + tid];
+                for (int c = 0; c < C; ++c) x[c] = xt[(tt * C + c) * 256 + f];
                 const float ws = ms[tt], wn = mn[tt];
-                sum_s += ws;
-                sum_n += wn;
-                int e = 0;
-#pragma unroll
-                for (int i = 0; i < C; ++i)
-#pragma unroll
-                    for (int j = i; j < C; ++j) {
-                        const cf p = cmulc(x[i], x[j]);
-                        acc_s[e].x = fmaf(ws, p.x, acc_s[e].x);
-                        acc_n[e].x = fmaf(wn, p.x, acc_n[e].x);
-                        if (i != j) {
-                            acc_s[e].y = fmaf(ws, p.y, acc_s[e].y);
-                            acc_n[e].y = fmaf(wn, p.y, acc_n[e].y);
-                        }
-                        ++e;
-                    }
+                if (h == 0) {
+                    sum_s += ws;
+                    sum_n += wn;
+                    accumulate_pairs<C, 0, NPH>(x, ws, wn, acc_s, acc_n);
+                } else {
+                    accumulate_pairs<C, NPH, NP>(x, ws, wn, acc_s, acc_n);
+                }
                 if (ny_active) {
                     const float prod = (ny_item < 2 * NP)
                                            ? xn[tt * C + ny_i] * xn[tt * C + ny_j]
@@ -245,29 +268,36 @@ __global__ __launch_bounds__(256) void stft_covar_kernel(Pass1Args a) {
         }
     }
 
-    // ---- max |audio| (the renorm target, WaveReader.maxabs) ----
     if (!DUMP) {
+        // ---- max |audio| (the renorm target, WaveReader.maxabs) ----
         if (wi.last) {
             // samples after the last frame's span are never loaded above
             const int covered = (T - 1) * a.g.hop - a.g.pad + kNfft;
             for (int c = 0; c < C; ++c)
-                for (int i = covered + tid; i < n_samp; i += 256)
+                for (int i = covered + tid; i < n_samp; i += kP1Threads)
                     mx = fmaxf(mx, fabsf(ud.audio[(size_t)c * n_samp + i]));
         }
-        const float bm = block_max_256(mx, red);
-        if (tid == 0) atomicMax(a.norm_bits + wi.utt, __float_as_uint(bm));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            float bm = red[0];
+#pragma unroll
+            for (int w = 1; w < kP1Threads / 64; ++w) bm = fmaxf(bm, red[w]);
+            atomicMax(a.norm_bits + wi.utt, __float_as_uint(bm));
+        }
 
         // ---- partial slab: planes [s.re | s.im | n.re | n.im | sum_s sum_n] ----
         float* P = a.partials + (size_t)wi.part * nplanes_partial(C) * FP;
-#pragma unroll
-        for (int e = 0; e < NP; ++e) {
-            P[(0 * NP + e) * FP + tid] = acc_s[e].x;
-            P[(1 * NP + e) * FP + tid] = acc_s[e].y;
-            P[(2 * NP + e) * FP + tid] = acc_n[e].x;
-            P[(3 * NP + e) * FP + tid] = acc_n[e].y;
+        if (h == 0) {
+            store_pairs<C, 0, NPH>(P, f, acc_s, acc_n);
+            P[(4 * NP + 0) * FP + f] = sum_s;
+            P[(4 * NP + 1) * FP + f] = sum_n;
+        } else {
+            store_pairs<C, NPH, NP>(P, f, acc_s, acc_n);
         }
-        P[(4 * NP + 0) * FP + tid] = sum_s;
-        P[(4 * NP + 1) * FP + tid] = sum_n;
         if (ny_active) {
             if (ny_item < NP) {
                 P[(0 * NP + ny_item) * FP + 256] = ny_acc;
@@ -285,13 +315,20 @@ __global__ __launch_bounds__(256) void stft_covar_kernel(Pass1Args a) {
 template <int C, bool DUMP>
 static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s) {
     constexpr int TB = 32 / C, NF = TB * C;
-    const size_t lds = (size_t)NF * 256 * sizeof(cf) + 256 * sizeof(cf) + kNfft * sizeof(float) +
-                       32 * sizeof(float) + 4 * sizeof(float);
+    const size_t lds = (size_t)NF * 256 * sizeof(cf) + 256 * sizeof(cf) + 128 * sizeof(cf) +
+                       kNfft * sizeof(float) + 32 * sizeof(float) + 8 * sizeof(float);
     auto k = stft_covar_kernel<C, DUMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(n_items), dim3(256), lds, s, a);
+    if (getenv("SETK_DEBUG")) {
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k),
+                                                           kP1Threads, lds);
+        fprintf(stderr, "[setk] pass1<%d,%d> lds=%zu items=%d blocks/CU=%d\n", C, (int)DUMP, lds,
+                n_items, nb);
+    }
+    hipLaunchKernelGGL(k, dim3(n_items), dim3(kP1Threads), lds, s, a);
     return hipGetLastError();
 }
 

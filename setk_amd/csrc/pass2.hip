@@ -15,6 +15,8 @@
 // windowed frames are overlap-added out of LDS with coalesced stores.
 #include "common.h"
 #include "fft512.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace setk {
 
@@ -62,13 +64,42 @@ size_t pass2_lds_bytes(int C, int keep) {
     return (size_t)(kSuperTile + keep) * 2048 + wt + 4 * 2048 + 64;
 }
 
-// ISTFT_ONLY: Y comes from a[].spec_in (spec[b][t][f]) instead of being
-// beamformed from audio.
+// raw (un-windowed) frame points of one quad-row lane: v[j] = (x[s+2n], x[s+2n+1])
+SETK_DEV void load_raw(cf (&v)[16], const float* __restrict__ x, int n_samp, int s, int la,
+                       bool valid) {
+    if (!valid) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = make_float2(0.f, 0.f);
+        return;
+    }
+    const bool interior = (s >= 0) && (s + kNfft <= n_samp) &&
+                          ((reinterpret_cast<uintptr_t>(x + s) & 7) == 0);
+    if (interior) {
+        const float2* p = reinterpret_cast<const float2*>(x + s);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = p[la + 16 * j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int n = la + 16 * j;
+            v[j] = make_float2(x[reflect_index2(s + 2 * n, n_samp)],
+                               x[reflect_index2(s + 2 * n + 1, n_samp)]);
+        }
+    }
+}
+
+// ISTFT_ONLY: Y comes from the per-item spectrogram (ud.audio reinterpreted as
+// spec[t][f]) instead of being beamformed from audio.
+//
+// Quad-row g of the workgroup owns frame ts + g of the super-tile: it transforms
+// the C channels of that frame one after the other, folds conj(w_c) X_c into
+// its lanes' accumulators (lane la owns bins k = la + 16 m and 256 - k), merges,
+// inverse-transforms and leaves the windowed frame in its LDS slot.  Nothing in
+// that chain needs a workgroup barrier; only the overlap-add does.
 template <int C, bool ISTFT_ONLY>
-__global__ __launch_bounds__(256) void beamform_istft_kernel(Pass2Args a) {
+__global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
     constexpr int F = kBins;
     constexpr int ST = kSuperTile;
-    constexpr int R = ST / 2;  // pair items per thread (16 frames x 128 / 256)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int keep = a.g.keep;
@@ -85,10 +116,11 @@ __global__ __launch_bounds__(256) void beamform_istft_kernel(Pass2Args a) {
     float* winsq = reinterpret_cast<float*>(p);
     p += 2048;
     float* red = reinterpret_cast<float*>(p);
+    cf* tw5 = reinterpret_cast<cf*>(synwin);  // synthesis window == analysis window:
+                                              // the synwin region holds the split twiddles
 
     const int tid = threadIdx.x;
     const int la = tid & 15, grp = tid >> 4;
-    const int k = tid & 127;
     const WorkItem wi = a.items[blockIdx.x];
     const UttDesc ud = a.utts[wi.utt];
     const int n_samp = ud.num_samples;
@@ -98,9 +130,9 @@ __global__ __launch_bounds__(256) void beamform_istft_kernel(Pass2Args a) {
     const bool clamp = (a.flags & 0x2) != 0;
 
     tw[tid] = a.tw256[tid];
+    if (tid < 128) tw5[tid] = a.tw512[tid];
     for (int i = tid; i < kNfft; i += 256) {
         win[i] = a.window[i];
-        synwin[i] = a.synwin[i];
         winsq[i] = a.winsq[i];
     }
     if (!ISTFT_ONLY) {
@@ -110,92 +142,89 @@ __global__ __launch_bounds__(256) void beamform_istft_kernel(Pass2Args a) {
             wtab[i] = wsrc[c * kBinsPad + f];
         }
     }
-    const cf wsplit = a.tw512[k];
     float omax = 0.f;
 
     // frames needed to complete the first output position of this range
     const int t_first = max(wi.t0 - keep, 0);
-    // zero the carried-over slots so that positions before t_first*hop are inert
     for (int i = tid; i < keep * 256; i += 256) slots[i] = make_float2(0.f, 0.f);
+    const float2* w2 = reinterpret_cast<const float2*>(win);
 
     for (int ts = t_first; ts < wi.t1; ts += ST) {
-        cf* cur = slots + keep * 256;  // 16 slots of this super-tile
-        cf Yk[R], Ym[R];
+        cf* slot = slots + (keep + grp) * 256;  // this quad-row's frame slot
+        const int t = ts + grp;
+        const bool tvalid = t < T;
+        cf Yk[8], Ym[8];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            Yk[r] = make_float2(0.f, 0.f);
-            Ym[r] = make_float2(0.f, 0.f);
+        for (int m = 0; m < 8; ++m) {
+            Yk[m] = make_float2(0.f, 0.f);
+            Ym[m] = make_float2(0.f, 0.f);
         }
-        __syncthreads();
+        __syncthreads();  // tables ready / slots free (carry copied)
         if (ISTFT_ONLY) {
-            const cf* spec = reinterpret_cast<const cf*>(ud.audio);  // per-item spectrogram
+            if (tvalid) {
+                const cf* row = reinterpret_cast<const cf*>(ud.audio) + (size_t)t * F;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int g = (tid >> 7) + 2 * r;
-                const int t = ts + g;
-                if (t < T) {
-                    const cf* row = spec + (size_t)t * F;
+                for (int m = 0; m < 8; ++m) {
+                    const int k = la + 16 * m;
                     if (k == 0) {
-                        Yk[r] = make_float2(row[0].x, row[256].x);
-                        Ym[r] = row[128];
+                        Yk[m] = make_float2(row[0].x, row[256].x);
+                        Ym[m] = row[128];
                     } else {
-                        Yk[r] = row[k];
-                        Ym[r] = row[256 - k];
+                        Yk[m] = row[k];
+                        Ym[m] = row[256 - k];
                     }
                 }
             }
         } else {
+            cf nxt[16];
+            load_raw(nxt, ud.audio, n_samp, t * hop - a.g.pad, la, tvalid);
+#pragma unroll 1
             for (int c = 0; c < C; ++c) {
-                {
-                    const int t = ts + grp;
-                    cf v[16];
-                    load_frame2(v, ud.audio + (size_t)c * n_samp, n_samp, t * hop - a.g.pad, la,
-                                win, t < T);
-                    fft256_stage_a<-1>(v, cur + grp * 256, tw, la);
-                }
-                __syncthreads();
-                {
-                    cf v[16];
-                    cf* slot = cur + grp * 256;
-                    fft256_stage_b<-1>(v, slot, la);
+                cf v[16];
 #pragma unroll
-                    for (int kb = 0; kb < 16; ++kb) slot[la + 16 * kb] = v[dft16_pos(kb)];
+                for (int j = 0; j < 16; ++j) {
+                    const float2 w = w2[la + 16 * j];
+                    v[j] = make_float2(nxt[j].x * w.x, nxt[j].y * w.y);
                 }
-                __syncthreads();
+                if (c + 1 < C)
+                    load_raw(nxt, ud.audio + (size_t)(c + 1) * n_samp, n_samp, t * hop - a.g.pad,
+                             la, tvalid);
+                fft256_stage_a<-1>(v, slot, tw, la);
+                __builtin_amdgcn_wave_barrier();
+                fft256_stage_b<-1>(v, slot, la);
+#pragma unroll
+                for (int kb = 0; kb < 16; ++kb) slot[la + 16 * kb] = v[dft16_pos(kb)];
+                __builtin_amdgcn_wave_barrier();
                 const cf* wc = wtab + c * F;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int g = (tid >> 7) + 2 * r;
-                    const cf* slot = cur + g * 256;
+                for (int m = 0; m < 8; ++m) {
+                    const int k = la + 16 * m;
                     const cf Zk = slot[k];
                     const cf Zm = slot[(256 - k) & 255];
                     cf Xk, Xm;
-                    rfft_split(Zk, Zm, wsplit, Xk, Xm);
+                    rfft_split(Zk, Zm, tw5[k], Xk, Xm);
                     if (k == 0) {
                         // X[0], X[256] are real and only Re Y[0], Re Y[256]
                         // reach the inverse (numpy irfft drops their imag)
-                        Yk[r].x = fmaf(wc[0].x, Xk.x, Yk[r].x);
-                        Yk[r].y = fmaf(wc[256].x, Xm.x, Yk[r].y);
+                        Yk[m].x = fmaf(wc[0].x, Xk.x, Yk[m].x);
+                        Yk[m].y = fmaf(wc[256].x, Xm.x, Yk[m].y);
                         const cf Z128 = slot[128];
                         const cf X128 = make_float2(Z128.x, -Z128.y);
-                        const cf t128 = cmulc(X128, wc[128]);
-                        Ym[r] = cadd(Ym[r], t128);
+                        Ym[m] = cadd(Ym[m], cmulc(X128, wc[128]));
                     } else {
-                        Yk[r] = cadd(Yk[r], cmulc(Xk, wc[k]));
-                        Ym[r] = cadd(Ym[r], cmulc(Xm, wc[256 - k]));
+                        Yk[m] = cadd(Yk[m], cmulc(Xk, wc[k]));
+                        Ym[m] = cadd(Ym[m], cmulc(Xm, wc[256 - k]));
                     }
                 }
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
             }
         }
         // ---- optional post-mask, merge into the packed inverse input ----
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int g = (tid >> 7) + 2 * r;
-            const int t = ts + g;
-            cf* slot = cur + g * 256;
-            cf yk = Yk[r], ym = Ym[r];
-            if (post_mask && t < T) {
+        for (int m = 0; m < 8; ++m) {
+            const int k = la + 16 * m;
+            cf yk = Yk[m], ym = Ym[m];
+            if (post_mask && tvalid) {
                 const float* mrow = ud.mask_s + (size_t)t * F;
                 if (k == 0) {
                     float m0 = mrow[0], m256 = mrow[256], m128 = mrow[128];
@@ -215,33 +244,26 @@ __global__ __launch_bounds__(256) void beamform_istft_kernel(Pass2Args a) {
                 slot[128] = make_float2(ym.x, -ym.y);
             } else {
                 cf Zk, Zm;
-                irfft_merge(yk, ym, wsplit, Zk, Zm);
+                irfft_merge(yk, ym, tw5[k], Zk, Zm);
                 slot[k] = Zk;
                 slot[256 - k] = Zm;
             }
         }
-        __syncthreads();
-        // ---- inverse transform of frame ts + grp ----
+        __builtin_amdgcn_wave_barrier();
+        // ---- inverse transform, windowed frame left in the slot ----
         {
             cf v[16];
-            cf* slot = cur + grp * 256;
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = slot[la + 16 * j];
             fft256_stage_a<+1>(v, slot, tw, la);
-        }
-        __syncthreads();
-        {
-            cf v[16];
-            cf* slot = cur + grp * 256;
+            __builtin_amdgcn_wave_barrier();
             fft256_stage_b<+1>(v, slot, la);
-            const bool valid = (ts + grp) < T;
-            const float sc = valid ? (1.f / 256.f) : 0.f;
-            const float2* sw = reinterpret_cast<const float2*>(synwin);
+            const float sc = tvalid ? (1.f / 256.f) : 0.f;
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) {
                 const int n = la + 16 * kb;
                 const cf z = v[dft16_pos(kb)];
-                const float2 w = sw[n];
+                const float2 w = w2[n];
                 slot[n] = make_float2(z.x * sc * w.x, z.y * sc * w.y);
             }
         }
@@ -258,9 +280,9 @@ __global__ __launch_bounds__(256) void beamform_istft_kernel(Pass2Args a) {
                 int t_lo = max((n - kNfft) / hop + 1, 0);
                 if (n < kNfft) t_lo = 0;
                 float v = 0.f, wss = 0.f;
-                for (int t = t_lo; t <= t_hi; ++t) {
-                    const int off = n - t * hop;
-                    const int sl = t - ts + keep;  // slot of frame t
+                for (int tt = t_lo; tt <= t_hi; ++tt) {
+                    const int off = n - tt * hop;
+                    const int sl = tt - ts + keep;  // slot of frame tt
                     v += frames[sl * kNfft + off];
                     wss += winsq[off];
                 }
@@ -274,19 +296,12 @@ __global__ __launch_bounds__(256) void beamform_istft_kernel(Pass2Args a) {
         }
         __syncthreads();
         // ---- carry the last `keep` frames over to the next super-tile ----
+        // (source slots [16, 16+keep) and destination slots [0, keep) are disjoint)
         {
             float4* dst = reinterpret_cast<float4*>(slots);
             const float4* src = reinterpret_cast<const float4*>(slots + ST * 256);
-            float4 tmp[4];
             const int n4 = keep * 128;  // float4 per slot = 128
-            // keep <= 7 -> at most 896 float4, <= 4 per thread
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (tid + 256 * q < n4) tmp[q] = src[tid + 256 * q];
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (tid + 256 * q < n4) dst[tid + 256 * q] = tmp[q];
+            for (int i = tid; i < n4; i += 256) dst[i] = src[i];
         }
     }
     // ---- max |out| for the renorm ----
@@ -308,6 +323,11 @@ static hipError_t launch_pass2_t(const Pass2Args& a, int n_items, hipStream_t s)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    if (getenv("SETK_DEBUG")) {
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), 256, lds);
+        fprintf(stderr, "[setk] pass2<%d,%d> lds=%zu items=%d blocks/CU=%d\n", C, (int)IO, lds, n_items, nb);
+    }
     hipLaunchKernelGGL(k, dim3(n_items), dim3(256), lds, s, a);
     return hipGetLastError();
 }
