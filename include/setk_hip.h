@@ -151,6 +151,17 @@ int setk_weights(setk_handle_t h, const setk_bf_opts* opts, const float* Rs,
                  int num_channels, float* weight, int* status, int* ref_out,
                  void* stream);
 
+/* do_ban (libs/beamformer.py:14-28) on an arbitrary weight:
+ * out[f] = w[f] * sqrt(|w^H Rn Rn w|) / max(Re w^H Rn w, eps_f32). */
+int setk_ban(setk_handle_t h, const float* weight, const float* Rn, int num_bins,
+             int num_channels, float* out, void* stream);
+
+/* rank1_constraint (libs/beamformer.py:66-84): p = principal eigenvector of Rs
+ * (Rn NULL) or Rn v for the pencil (Rs, Rn);
+ * out[f] = tr(Rs) / max(tr(p p^H), eps_f32) * p p^H,  [F][C][C] complex64. */
+int setk_rank1(setk_handle_t h, const float* Rs, const float* Rn, int num_bins,
+               int num_channels, float* out, int* status, void* stream);
+
 /* Beamformer.beamform (libs/beamformer.py:220-234):
  * out[t][f] = sum_c conj(w[f][c]) spec[c][t][f]. */
 int setk_beamform(setk_handle_t h, const float* weight, const float* spec,

@@ -46,7 +46,7 @@ def exported_symbols():
         "setk_abi_version", "setk_create", "setk_destroy", "setk_last_error",
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
-        "setk_beamform", "setk_enhance_batch", "setk_set_profiling",
+        "setk_ban", "setk_rank1", "setk_beamform", "setk_enhance_batch", "setk_set_profiling",
         "setk_last_stage_ms"
     ]
 
@@ -83,6 +83,8 @@ def load_library():
     lib.setk_pevd.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, fp, c_void_p]
     lib.setk_weights.argtypes = [H, POINTER(BfOpts), fp, fp, fp, c_int, c_int,
                                  fp, fp, POINTER(c_int), c_void_p]
+    lib.setk_ban.argtypes = [H, fp, fp, c_int, c_int, fp, c_void_p]
+    lib.setk_rank1.argtypes = [H, fp, fp, c_int, c_int, fp, fp, c_void_p]
     lib.setk_beamform.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, c_void_p]
     lib.setk_enhance_batch.argtypes = [
         H, POINTER(BfOpts), c_int, c_int, POINTER(c_void_p), POINTER(c_int),
@@ -223,6 +225,16 @@ class Context:
                                    ctypes.byref(ref),
                                    current_stream_ptr() if stream is None else stream))
         return ref.value
+
+    def ban(self, weight, Rn, F, C, out, stream=None):
+        self.check(
+            self._lib.setk_ban(self._h, _ptr(weight), _ptr(Rn), F, C, _ptr(out),
+                               current_stream_ptr() if stream is None else stream))
+
+    def rank1(self, Rs, Rn, F, C, out, status, stream=None):
+        self.check(
+            self._lib.setk_rank1(self._h, _ptr(Rs), _ptr(Rn), F, C, _ptr(out), _ptr(status),
+                                 current_stream_ptr() if stream is None else stream))
 
     def beamform(self, weight, spec, C, T, F, out, stream=None):
         self.check(

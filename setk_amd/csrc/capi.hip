@@ -596,6 +596,62 @@ int setk_weights(setk_handle_t h, const setk_bf_opts* opts, const float* Rs, con
                        ref_out, static_cast<hipStream_t>(stream));
 }
 
+int setk_ban(setk_handle_t h, const float* weight, const float* Rn, int num_bins,
+             int num_channels, float* out, void* stream) {
+    if (!h || !weight || !Rn || !out || num_bins <= 0 || num_channels <= 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h);
+    const int F = num_bins, C = num_channels;
+    const float *d_w, *d_Rn;
+    int rc = stage_in(h, weight, (size_t)F * C * 2, s, &d_w);
+    if (rc) return rc;
+    rc = stage_in(h, Rn, (size_t)F * C * C * 2, s, &d_Rn);
+    if (rc) return rc;
+    OutBuf ob;
+    rc = stage_out(h, out, (size_t)F * C * sizeof(float2), &ob);
+    if (rc) return rc;
+    HIP_TRY(h, launch_ban(d_w, d_Rn, F, C, static_cast<float*>(ob.dev), s));
+    rc = copy_back(h, ob, s);
+    if (rc) return rc;
+    if (ob.host) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
+int setk_rank1(setk_handle_t h, const float* Rs, const float* Rn, int num_bins,
+               int num_channels, float* out, int* status, void* stream) {
+    if (!h || !Rs || !out || num_bins <= 0) return fail(h, SETK_ERR_INVALID, "bad args");
+    if (num_channels < 1 || num_channels > kMaxChannels)
+        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int F = num_bins, C = num_channels;
+    // principal vectors first (device resident), then the rebuild kernel
+    float* d_pv = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&d_pv), (size_t)F * C * sizeof(float2)));
+    setk_bf_opts o;
+    memset(&o, 0, sizeof(o));
+    o.flags = SETK_FLAG_NO_GAUGE;
+    int rc = run_weights(h, o, kKindPevd, Rs, Rn, nullptr, F, C, d_pv, status, nullptr, s);
+    if (rc == SETK_OK) {
+        arena_reset(h);
+        const float *d_Rs, *d_Rn = nullptr;
+        rc = stage_in(h, Rs, (size_t)F * C * C * 2, s, &d_Rs);
+        if (rc == SETK_OK && Rn) rc = stage_in(h, Rn, (size_t)F * C * C * 2, s, &d_Rn);
+        OutBuf ob;
+        if (rc == SETK_OK) rc = stage_out(h, out, (size_t)F * C * C * sizeof(float2), &ob);
+        if (rc == SETK_OK) {
+            hipError_t e = launch_rank1(d_pv, d_Rs, d_Rn, F, C, static_cast<float*>(ob.dev), s);
+            if (e != hipSuccess) rc = fail(h, SETK_ERR_HIP, hipGetErrorString(e));
+        }
+        if (rc == SETK_OK) rc = copy_back(h, ob, s);
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(d_pv);
+    return rc;
+}
+
 int setk_beamform(setk_handle_t h, const float* weight, const float* spec, int num_channels,
                   int num_frames, int num_bins, float* out, void* stream) {
     if (!h || !weight || !spec || !out || num_channels <= 0 || num_frames <= 0 || num_bins <= 0)

@@ -126,6 +126,9 @@ hipError_t launch_covar_spec_finalize(int C, const float* partials, int nparts, 
 hipError_t launch_pack_covar(const float* fcc, int F, int C, float* planes, int plane0,
                              hipStream_t s);
 hipError_t launch_unpack_weight(const float* wplanes, int F, int C, float* w_fc, hipStream_t s);
+hipError_t launch_ban(const float* w, const float* Rn, int F, int C, float* out, hipStream_t s);
+hipError_t launch_rank1(const float* pv, const float* Rs, const float* Rn, int F, int C,
+                        float* out, hipStream_t s);
 hipError_t launch_beamform_spec(const float* w_fc, const float* spec, int C, int T, int F,
                                 float* out, hipStream_t s);
 

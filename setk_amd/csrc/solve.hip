@@ -600,4 +600,96 @@ hipError_t launch_unpack_weight(const float* wplanes, int F, int C, float* w_fc,
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// stand-alone do_ban (libs/beamformer.py:14-28) and the rank-1 rebuild of
+// rank1_constraint (libs/beamformer.py:75-84) on [F][C][C] / [F][C] arrays;
+// one thread per bin, fp64.
+// ---------------------------------------------------------------------------
+__global__ void ban_kernel(const float2* __restrict__ w, const float2* __restrict__ Rn, int F,
+                           int C, float2* __restrict__ out) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    // nominator = w^H Rn Rn w = sum_i (w^H Rn)_i (Rn w)_i ; denominator = Re w^H Rn w
+    double nom_re = 0.0, nom_im = 0.0, den = 0.0;
+    for (int i = 0; i < C; ++i) {
+        double ux = 0.0, uy = 0.0;  // (Rn w)_i
+        double vx = 0.0, vy = 0.0;  // (w^H Rn)_i = sum_m conj(w_m) Rn[m][i]
+        for (int m = 0; m < C; ++m) {
+            const float2 r = Rn[((size_t)f * C + i) * C + m];
+            const float2 rt = Rn[((size_t)f * C + m) * C + i];
+            const float2 x = w[(size_t)f * C + m];
+            ux += (double)r.x * x.x - (double)r.y * x.y;
+            uy += (double)r.x * x.y + (double)r.y * x.x;
+            vx += (double)x.x * rt.x + (double)x.y * rt.y;
+            vy += (double)x.x * rt.y - (double)x.y * rt.x;
+        }
+        const float2 wi = w[(size_t)f * C + i];
+        nom_re += vx * ux - vy * uy;
+        nom_im += vx * uy + vy * ux;
+        den += (double)wi.x * ux + (double)wi.y * uy;
+    }
+    const double filt = sqrt(sqrt(nom_re * nom_re + nom_im * nom_im)) / fmax(den, kEpsF32);
+    for (int i = 0; i < C; ++i) {
+        const float2 x = w[(size_t)f * C + i];
+        out[(size_t)f * C + i] = make_float2((float)(x.x * filt), (float)(x.y * filt));
+    }
+}
+
+hipError_t launch_ban(const float* w, const float* Rn, int F, int C, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(ban_kernel, dim3((F + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(w), reinterpret_cast<const float2*>(Rn), F,
+                       C, reinterpret_cast<float2*>(out));
+    return hipGetLastError();
+}
+
+// pv: principal (generalised) eigenvectors [F][C]; if Rn != null pv <- Rn pv.
+// out = tr(Rs) / max(tr(p p^H), eps) * p p^H
+__global__ void rank1_kernel(const float2* __restrict__ pv, const float2* __restrict__ Rs,
+                             const float2* __restrict__ Rn, int F, int C,
+                             float2* __restrict__ out) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    double px[kMaxChannels], py[kMaxChannels];
+    for (int i = 0; i < C; ++i) {
+        if (Rn) {
+            double ux = 0.0, uy = 0.0;
+            for (int m = 0; m < C; ++m) {
+                const float2 r = Rn[((size_t)f * C + i) * C + m];
+                const float2 x = pv[(size_t)f * C + m];
+                ux += (double)r.x * x.x - (double)r.y * x.y;
+                uy += (double)r.x * x.y + (double)r.y * x.x;
+            }
+            px[i] = ux;
+            py[i] = uy;
+        } else {
+            px[i] = pv[(size_t)f * C + i].x;
+            py[i] = pv[(size_t)f * C + i].y;
+        }
+    }
+    double trx = 0.0, try_ = 0.0, pn = 0.0;
+    for (int i = 0; i < C; ++i) {
+        trx += Rs[((size_t)f * C + i) * C + i].x;
+        try_ += Rs[((size_t)f * C + i) * C + i].y;
+        pn += px[i] * px[i] + py[i] * py[i];
+    }
+    const double d = fmax(pn, kEpsF32);
+    const double sx = trx / d, sy = try_ / d;
+    for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) {
+            // p_i conj(p_j)
+            const double rx = px[i] * px[j] + py[i] * py[j];
+            const double ry = py[i] * px[j] - px[i] * py[j];
+            out[((size_t)f * C + i) * C + j] =
+                make_float2((float)(sx * rx - sy * ry), (float)(sx * ry + sy * rx));
+        }
+}
+
+hipError_t launch_rank1(const float* pv, const float* Rs, const float* Rn, int F, int C,
+                        float* out, hipStream_t s) {
+    hipLaunchKernelGGL(rank1_kernel, dim3((F + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(pv), reinterpret_cast<const float2*>(Rs),
+                       reinterpret_cast<const float2*>(Rn), F, C, reinterpret_cast<float2*>(out));
+    return hipGetLastError();
+}
+
 }  // namespace setk

@@ -1,0 +1,77 @@
+"""
+Utterance sharding over the GPUs of one node.
+
+The reference parallelises this path with ``split_scp.pl`` + ``run.pl JOB=1:nj``
+(scripts/run_adapt_beamformer.sh:69-92): contiguous scp shards, one process
+each, no communication.  Here: one process per GPU (torchrun), utterances are
+independent units dealt to ranks by duration (longest first, round robin) and
+RCCL (torch.distributed backend "nccl") carries only the start/finish barrier
+and the three counters of the final "Processed N utterances" line.  There is no
+data-path collective because the path has no exchange step.
+"""
+import os
+
+
+class Shard:
+    """rank/world view of the job; degenerates to a single process."""
+
+    def __init__(self, backend=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self._dist = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if not dist.is_initialized():
+                kw = {}
+                if backend == "nccl":
+                    torch.cuda.set_device(self.local_rank)
+                    kw["device_id"] = torch.device("cuda", self.local_rank)
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+            self._dist = dist
+            self.backend = backend
+
+    @property
+    def device(self):
+        return self.local_rank
+
+    def assign(self, keys, weights=None):
+        """Keys owned by this rank.  With weights (e.g. durations) the keys are
+        dealt longest-first round robin, which balances the sum of weights;
+        without, plain round robin in table order."""
+        return assign_keys(keys, self.rank, self.world, weights)
+
+    def barrier(self):
+        if self._dist is not None:
+            self._dist.barrier()
+
+    def sum_counts(self, values):
+        """Element-wise sum of a short list of python numbers over all ranks."""
+        if self._dist is None:
+            return list(values)
+        import torch
+        dev = torch.device("cuda", self.local_rank) if self.backend == "nccl" else "cpu"
+        t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return t.cpu().tolist()
+
+    def close(self):
+        if self._dist is not None and self._dist.is_initialized():
+            self._dist.destroy_process_group()
+            self._dist = None
+
+
+def assign_keys(keys, rank, world, weights=None):
+    keys = list(keys)
+    if world <= 1:
+        return keys
+    if weights is None:
+        return keys[rank::world]
+    order = sorted(range(len(keys)), key=lambda i: (-float(weights[i]), i))
+    mine = sorted(order[rank::world])  # keep table order inside a rank
+    return [keys[i] for i in mine]

@@ -1,0 +1,156 @@
+"""
+Batched front end of the fused hot path (setk_enhance_batch): takes decoded
+utterances (numpy), keeps them resident in HBM through torch tensors, runs the
+four kernel stages for the whole batch and hands back PCM16 / float32 waves.
+
+This is the compute body of apply_adaptive_beamformer.py:130-178 for many
+utterances at once -- per-utterance work is microseconds on an MI355X, so the
+engineering unit is the batch, not the utterance.
+"""
+import numpy as np
+
+from . import _ffi
+from .libs.utils import nextpow2, stft_window, cmat_abs
+
+BEAMFORMER_KINDS = {
+    # name -> (kind, pmwf_beta)
+    "mvdr": (_ffi.BF_MVDR, 0.0),
+    "mpdr": (_ffi.BF_MPDR, 0.0),
+    "mpdr-whiten": (_ffi.BF_MPDR_WHITEN, 0.0),
+    "gevd": (_ffi.BF_GEVD, 0.0),
+    "pmwf-0": (_ffi.BF_PMWF, 0.0),
+    "pmwf-1": (_ffi.BF_PMWF, 1.0),
+}
+RANK1 = {"": _ffi.RANK1_NONE, "none": _ffi.RANK1_NONE, "eig": _ffi.RANK1_EIG,
+         "gev": _ffi.RANK1_GEV}
+
+
+def compute_vad_masks(spectrogram, proportion):
+    """Energy based VAD mask of apply_adaptive_beamformer.py:50-71: keep
+    proportion*100 % of the energy.  spectrogram F x T -> (T x F bool, index).
+    The cumulative sum replaces the reference's python while-loop."""
+    energy = cmat_abs(spectrogram)
+    vec = np.sort(energy.flatten())
+    filter_energy = np.sum(vec) * (1 - proportion)
+    csum = np.cumsum(vec)
+    index = int(np.searchsorted(csum, filter_energy, side="right"))
+    threshold = vec[min(index, vec.shape[0] - 1)] if vec.shape[0] else 0
+    return (energy < threshold).transpose(), index
+
+
+class BatchEnhancer(object):
+    def __init__(self, beamformer="mvdr", frame_len=512, frame_hop=256, center=True,
+                 round_power_of_two=True, window="hann", ban=False, pmwf_ref=-1, rank1_appro="",
+                 post_mask=False, vad_proportion=1, pcm16=False, device=None, ctx=None,
+                 max_batch_samples=1 << 28):
+        if beamformer not in BEAMFORMER_KINDS:
+            raise ValueError(f"unknown beamformer {beamformer}")
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _ffi.SetkError("BatchEnhancer needs an MI355X (no CPU fallback)")
+        self.ctx = ctx or _ffi.default_context(device)
+        self.dev = torch.device("cuda", self.ctx.device)
+        n_fft = nextpow2(frame_len) if round_power_of_two else frame_len
+        self.stft = dict(frame_len=frame_len, frame_hop=frame_hop, n_fft=n_fft, center=center,
+                         window=stft_window(window, frame_len))
+        self.num_bins = n_fft // 2 + 1
+        kind, beta = BEAMFORMER_KINDS[beamformer]
+        flags = 0
+        if ban:
+            flags |= _ffi.FLAG_BAN
+        if post_mask:
+            flags |= _ffi.FLAG_POST_MASK
+        if pcm16:
+            flags |= _ffi.FLAG_OUT_PCM16
+        self.base_flags = flags
+        self.opts_kw = dict(kind=kind, pmwf_beta=beta, pmwf_ref=int(pmwf_ref),
+                            rank1=RANK1[rank1_appro])
+        self.pcm16 = pcm16
+        self.vad_proportion = vad_proportion
+        self.max_batch_samples = max_batch_samples
+
+    def _plan(self):
+        s = self.stft
+        self.ctx.stft_plan(s["frame_len"], s["frame_hop"], s["n_fft"], s["center"], s["window"])
+
+    def condition_mask(self, mask, num_frames):
+        """apply_adaptive_beamformer.py:146-151: masks arrive T x F or F x T."""
+        F = self.num_bins
+        mask = np.asarray(mask)
+        if mask.ndim != 2:
+            raise ValueError(f"mask must be 2D, got {mask.shape}")
+        if mask.shape[0] == F and mask.shape[1] != F:
+            mask = np.transpose(mask)
+        if mask.shape[1] != F:
+            raise ValueError("Input mask matrix should be shape as " +
+                             f"[num_frames x num_bins], now is {mask.shape}")
+        if mask.shape[0] != num_frames:
+            raise ValueError("Shape of input obs do not match with mask matrix, " +
+                             f"{num_frames} frames vs {mask.shape}")
+        return mask
+
+    def enhance(self, utts):
+        """utts: list of (samps C x N float32, speech mask, interferer mask|None).
+        Returns list of (wave ndarray | None, status) in input order; status != 0
+        is the reference's LinAlgError case (the utterance is to be skipped)."""
+        self._plan()
+        results = [None] * len(utts)
+        groups = {}
+        for i, (samps, _, itf) in enumerate(utts):
+            samps = np.asarray(samps)
+            if samps.ndim == 1:
+                samps = samps[None]
+            groups.setdefault((samps.shape[0], itf is not None), []).append(i)
+        for (C, has_itf), idx in groups.items():
+            batch, nsamp = [], 0
+            for i in idx:
+                n = np.asarray(utts[i][0]).size
+                if batch and nsamp + n > self.max_batch_samples:
+                    self._run(utts, batch, C, has_itf, results)
+                    batch, nsamp = [], 0
+                batch.append(i)
+                nsamp += n
+            if batch:
+                self._run(utts, batch, C, has_itf, results)
+        return results
+
+    def _run(self, utts, batch, C, has_itf, results):
+        torch, ctx, dev = self.torch, self.ctx, self.dev
+        audio, masks, itfs, waves, ns = [], [], [], [], []
+        flags = self.base_flags | (0 if has_itf else _ffi.FLAG_CLAMP_MASK)
+        for i in batch:
+            samps, mask, itf = utts[i]
+            samps = np.ascontiguousarray(samps, dtype=np.float32)
+            if samps.ndim == 1:
+                samps = samps[None]
+            N = samps.shape[1]
+            T = ctx.num_frames(N)
+            mask = self.condition_mask(mask, T)
+            if has_itf:
+                itf = self.condition_mask(itf, T)
+            a = torch.from_numpy(samps).to(dev)
+            if 0.5 < self.vad_proportion < 1:
+                spec0 = torch.empty((1, T, self.num_bins), dtype=torch.complex64, device=dev)
+                ctx.stft(a[:1], spec0)
+                vad, _ = compute_vad_masks(spec0[0].cpu().numpy().T, self.vad_proportion)
+                if not has_itf:
+                    mask = np.minimum(mask, 1)
+                mask = np.where(vad, 1.0e-4, mask)
+                if has_itf:
+                    itf = np.where(vad, 1.0e-4, itf)
+            audio.append(a)
+            masks.append(torch.from_numpy(np.ascontiguousarray(mask, dtype=np.float32)).to(dev))
+            if has_itf:
+                itfs.append(torch.from_numpy(np.ascontiguousarray(itf, dtype=np.float32)).to(dev))
+            L = ctx.istft_num_samples(T)
+            waves.append(torch.empty(L, dtype=torch.int16 if self.pcm16 else torch.float32,
+                                     device=dev))
+            ns.append(N)
+        opts = _ffi.BfOpts(flags=flags, **self.opts_kw)
+        status = ctx.enhance_batch(opts, C, [t.data_ptr() for t in audio], ns,
+                                   [t.data_ptr() for t in masks],
+                                   [t.data_ptr() for t in itfs] if has_itf else None,
+                                   [t.data_ptr() for t in waves], want_status=True)
+        for j, i in enumerate(batch):
+            results[i] = (waves[j].cpu().numpy() if status[j] == 0 else None, status[j])

@@ -1,0 +1,286 @@
+"""
+Mirror of the mask-based (supervised) part of scripts/sptk/libs/beamformer.py.
+Same functions, classes, argument meaning, array layouts and error behaviour:
+
+    obs      N x F x T complex   (N: microphones, F: bins, T: frames)
+    tf_mask  T x F real
+    covar    F x N x N complex
+    weight   F x N complex
+    output   F x T complex
+
+All arithmetic runs in libsetk_hip.so (setk_covar / setk_pevd / setk_weights /
+setk_ban / setk_rank1 / setk_beamform); numerical failures reported by the
+device (noise covariance not positive definite, ...) are raised as
+numpy.linalg.LinAlgError exactly where the reference's LAPACK calls would.
+
+Eigenvector gauge: the reference inherits a LAPACK dependent per-bin sign from
+eigh / eigh(A, B).  Here every principal eigenvector has component 0 real and
+non-negative (for the pencil the rule applies to L^H v with Rn = L L^H), see
+DESIGN.md "Gauge".  Geometry based (DS/SD) beamformers are out of scope.
+"""
+import numpy as np
+
+from .. import _ffi
+from .utils import EPSILON
+
+__all__ = [
+    "compute_covar", "solve_pevd", "do_ban", "rank1_constraint", "Beamformer",
+    "SupervisedBeamformer", "MvdrBeamformer", "MpdrBeamformer", "PmwfBeamformer",
+    "GevdBeamformer", "OnlineSupervisedBeamformer", "OnlineMvdrBeamformer",
+    "OnlineGevdBeamformer"
+]
+
+_STATUS_TEXT = {
+    _ffi.NUM_SINGULAR: "Singular matrix",
+    _ffi.NUM_NOCONV: "Eigenvalues did not converge",
+    _ffi.NUM_NONFINITE: "Array must not contain infs or NaNs",
+}
+
+
+def _ctx():
+    return _ffi.default_context()
+
+
+def _c64(x):
+    return np.ascontiguousarray(x, dtype=np.complex64)
+
+
+def _f32(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def _time_major(obs):
+    """N x F x T (reference layout) -> [N][T][F] contiguous complex64."""
+    return np.ascontiguousarray(np.transpose(obs, (0, 2, 1)), dtype=np.complex64)
+
+
+def _raise_on_status(status):
+    bad = status[status != 0]
+    if bad.size:
+        code = int(bad.max())
+        raise np.linalg.LinAlgError(
+            f"{_STATUS_TEXT.get(code, 'numerical failure')} "
+            f"(frequency bins {np.flatnonzero(status)[:8].tolist()} ...)")
+
+
+def do_ban(weight, Rn):
+    """Blind Analytical Normalization (reference beamformer.py:14-28).
+    weight F x N, Rn F x N x N -> F x N."""
+    F, N = weight.shape
+    out = np.empty((F, N), dtype=np.complex64)
+    _ctx().ban(_c64(weight), _c64(Rn), F, N, out)
+    return out.astype(np.result_type(weight.dtype, np.complex64))
+
+
+def solve_pevd(Rs, Rn=None):
+    """Principal eigenvector of the covariance matrix (pair), F x N
+    (reference beamformer.py:31-63; complex128 for the generalised problem)."""
+    F, N, _ = Rs.shape
+    out = np.empty((F, N), dtype=np.complex64)
+    status = np.zeros(F, dtype=np.int32)
+    _ctx().pevd(_c64(Rs), None if Rn is None else _c64(Rn), F, N, 0, out, status)
+    _raise_on_status(status)
+    return out if Rn is None else out.astype(np.complex128)
+
+
+def rank1_constraint(Rs, Rn=None):
+    """(Generalised) rank-1 approximation of Rs, F x N x N
+    (reference beamformer.py:66-84)."""
+    F, N, _ = Rs.shape
+    out = np.empty((F, N, N), dtype=np.complex64)
+    status = np.zeros(F, dtype=np.int32)
+    _ctx().rank1(_c64(Rs), None if Rn is None else _c64(Rn), F, N, out, status)
+    _raise_on_status(status)
+    return out if Rn is None else out.astype(np.complex128)
+
+
+def compute_covar(obs, tf_mask):
+    """covar[f] = sum_t m[t, f] x x^H / max(sum_t m[t, f], 1e-6)
+    (reference beamformer.py:87-103).  obs N x F x T, tf_mask T x F."""
+    N, F, T = obs.shape
+    out = np.empty((F, N, N), dtype=np.complex64)
+    _ctx().covar(_time_major(obs), _f32(tf_mask), N, T, F, out)
+    wide = obs.dtype == np.complex128 or np.asarray(tf_mask).dtype == np.float64
+    return out.astype(np.complex128) if wide else out
+
+
+class Beamformer(object):
+    def __init__(self):
+        pass
+
+    def beamform(self, weight, obs):
+        """out[f, t] = sum_n conj(weight[f, n]) obs[n, f, t]
+        (reference beamformer.py:220-234)."""
+        if weight.shape[0] != obs.shape[1] or weight.shape[1] != obs.shape[0]:
+            raise ValueError("Input obs do not match with weight, " +
+                             f"{weight.shape} vs {obs.shape}")
+        N, F, T = obs.shape
+        out = np.empty((T, F), dtype=np.complex64)
+        _ctx().beamform(_c64(weight), _time_major(obs), N, T, F, out)
+        enh = out.T  # F x T view
+        wide = weight.dtype == np.complex128 or obs.dtype == np.complex128
+        return enh.astype(np.complex128) if wide else enh
+
+
+class SupervisedBeamformer(Beamformer):
+    """Base class of the TF-mask based beamformers (reference :237-283)."""
+    _kind = None
+    _wide = False  # reference dtype of the weights (complex128 for GEV)
+
+    def __init__(self, num_bins):
+        super(SupervisedBeamformer, self).__init__()
+        self.num_bins = num_bins
+
+    def compute_covar_mat(self, target_mask, obs):
+        if target_mask.shape[1] != self.num_bins or target_mask.ndim != 2:
+            raise ValueError("Input mask matrix should be shape as " +
+                             f"[num_frames x num_bins], now is {target_mask.shape}")
+        if obs.shape[1] != target_mask.shape[1] or obs.shape[2] != target_mask.shape[0]:
+            raise ValueError("Shape of input obs do not match with " +
+                             f"mask matrix, {obs.shape} vs {target_mask.shape}")
+        return compute_covar(obs, target_mask)
+
+    def _opts(self, ban=False):
+        return _ffi.BfOpts(kind=self._kind, flags=_ffi.FLAG_BAN if ban else 0, pmwf_beta=0.0,
+                           pmwf_ref=-1, rank1=0)
+
+    def _device_weight(self, Rs, Rn, Ry=None, ban=False):
+        F, N, _ = Rs.shape
+        out = np.empty((F, N), dtype=np.complex64)
+        status = np.zeros(F, dtype=np.int32)
+        _ctx().weights(self._opts(ban), _c64(Rs), None if Rn is None else _c64(Rn),
+                       None if Ry is None else _c64(Ry), F, N, out, status)
+        _raise_on_status(status)
+        return out.astype(np.complex128) if self._wide else out
+
+    def weight(self, Rs, Rn):
+        raise NotImplementedError
+
+    def run(self, mask_s, obs, mask_n=None, ban=False):
+        """mask_s T x F, obs N x F x T -> enhanced F x T (reference :270-283)."""
+        Rn = self.compute_covar_mat(1 - mask_s if mask_n is None else mask_n, obs)
+        Rs = self.compute_covar_mat(mask_s, obs)
+        weight = self._device_weight(Rs, Rn, ban=ban) if self._kind is not None else (
+            do_ban(self.weight(Rs, Rn), Rn) if ban else self.weight(Rs, Rn))
+        return self.beamform(weight, obs)
+
+
+class MvdrBeamformer(SupervisedBeamformer):
+    """h = Rn^-1 d / (d^H Rn^-1 d), d = P(Rs)  (reference :515-539)."""
+    _kind = _ffi.BF_MVDR
+
+    def weight(self, Rs, Rn):
+        return self._device_weight(Rs, Rn)
+
+
+class GevdBeamformer(SupervisedBeamformer):
+    """h = P(Rs, Rn), the max-SNR beamformer (reference :662-682)."""
+    _kind = _ffi.BF_GEVD
+    _wide = True
+
+    def weight(self, Rs, Rn):
+        return self._device_weight(Rs, Rn)
+
+
+class PmwfBeamformer(SupervisedBeamformer):
+    """Parameterized multichannel Wiener filter (reference :593-659):
+    W = Rn^-1 Rs / (beta + tr(Rn^-1 Rs)), column ref_channel (or the channel of
+    maximum estimated SNR when ref_channel < 0)."""
+    _kind = _ffi.BF_PMWF
+
+    def __init__(self, num_bins, beta=0, ref_channel=-1, rank1_appro=""):
+        super(PmwfBeamformer, self).__init__(num_bins)
+        self.ref_channel = ref_channel
+        self.rank1_appro = rank1_appro
+        self.beta = beta
+
+    def _opts(self, ban=False):
+        rank1 = {"eig": _ffi.RANK1_EIG, "gev": _ffi.RANK1_GEV}.get(self.rank1_appro,
+                                                                   _ffi.RANK1_NONE)
+        return _ffi.BfOpts(kind=self._kind, flags=_ffi.FLAG_BAN if ban else 0,
+                           pmwf_beta=float(self.beta), pmwf_ref=int(self.ref_channel),
+                           rank1=rank1)
+
+    def weight(self, Rs, Rn):
+        _, N, _ = Rs.shape
+        if self.ref_channel >= N:
+            raise RuntimeError("Reference channel ID exceeds total " +
+                               f"channels: {self.ref_channel} vs {N}")
+        self._wide = self.rank1_appro == "gev"
+        return self._device_weight(Rs, Rn)
+
+    def run(self, mask_s, obs, mask_n=None, ban=False):
+        if self.ref_channel >= obs.shape[0]:
+            raise RuntimeError("Reference channel ID exceeds total " +
+                               f"channels: {self.ref_channel} vs {obs.shape[0]}")
+        self._wide = self.rank1_appro == "gev"
+        return super(PmwfBeamformer, self).run(mask_s, obs, mask_n=mask_n, ban=ban)
+
+
+class MpdrBeamformer(SupervisedBeamformer):
+    """h = Ry^-1 d / (d^H Ry^-1 d) (reference :542-590); d = P(Rs) or, with
+    whiten, Rn P(Rs, Rn)."""
+
+    def __init__(self, num_bins, whiten=False):
+        super(MpdrBeamformer, self).__init__(num_bins)
+        self.whiten = whiten
+        self._kind = _ffi.BF_MPDR_WHITEN if whiten else _ffi.BF_MPDR
+        self._wide = bool(whiten)
+
+    def weight(self, Rs, Ry, Rn=None):
+        kind = _ffi.BF_MPDR if Rn is None else _ffi.BF_MPDR_WHITEN
+        saved = self._kind, self._wide
+        self._kind, self._wide = kind, Rn is not None
+        try:
+            return self._device_weight(Rs, Rn, Ry=Ry)
+        finally:
+            self._kind, self._wide = saved
+
+    def run(self, mask_s, obs, mask_n=None, ban=False):
+        Rs = self.compute_covar_mat(mask_s, obs)
+        Ry = self.compute_covar_mat(np.ones_like(mask_s), obs)
+        Rn = None
+        if self.whiten:
+            Rn = self.compute_covar_mat(1 - mask_s if mask_n is None else mask_n, obs)
+        elif ban:
+            # the reference reaches `do_ban(weight, Rn)` with Rn undefined here
+            # (beamformer.py:590, NameError); raise a diagnosable error instead
+            raise ValueError("BAN needs a noise covariance: use MpdrBeamformer(whiten=True)")
+        weight = self.weight(Rs, Ry, Rn=Rn)
+        return self.beamform(do_ban(weight, Rn) if ban else weight, obs)
+
+
+class OnlineSupervisedBeamformer(SupervisedBeamformer):
+    """Block-online variant with recursive covariance smoothing (reference
+    :286-320).  NB: the reference CLI calls run(..., normalize=) and fails with
+    a TypeError (apply_adaptive_beamformer.py:42-45); the keyword here is ban=."""
+
+    def __init__(self, num_bins, num_channels, alpha=0.8):
+        super(OnlineSupervisedBeamformer, self).__init__(num_bins)
+        self.covar_mat_shape = (num_bins, num_channels, num_channels)
+        self.reset_stats(alpha=alpha)
+
+    def reset_stats(self, alpha=0.8):
+        self.Rs = np.zeros(self.covar_mat_shape, dtype=np.complex128)
+        self.Rn = np.zeros(self.covar_mat_shape, dtype=np.complex128)
+        self.alpha = alpha
+        self.reset = True
+
+    def run(self, mask_s, obs, mask_n=None, ban=False):
+        Rn = self.compute_covar_mat(1 - mask_s if mask_n is None else mask_n, obs)
+        Rs = self.compute_covar_mat(mask_s, obs)
+        phi = 1 if self.reset else (1 - self.alpha)
+        self.Rs = self.Rs * self.alpha + phi * Rs
+        self.Rn = self.Rn * self.alpha + phi * Rn
+        self.reset = False
+        weight = self._device_weight(self.Rs, self.Rn)
+        return self.beamform(do_ban(weight, Rn) if ban else weight, obs)
+
+
+class OnlineMvdrBeamformer(OnlineSupervisedBeamformer):
+    _kind = _ffi.BF_MVDR
+
+
+class OnlineGevdBeamformer(OnlineSupervisedBeamformer):
+    _kind = _ffi.BF_GEVD
+    _wide = True

@@ -1,0 +1,239 @@
+"""
+GPU tests of the drop-in surface: the python mirror of libs.utils /
+libs.beamformer and the apply_adaptive_beamformer CLI, against the vectors the
+unmodified reference produced (tests/golden) and against the oracle.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, rms, rel_rms
+from oracle import np_oracle as o
+from oracle import make_golden as mg
+
+pytestmark = pytest.mark.gpu
+
+STFT_KW = dict(frame_len=512, frame_hop=256, window="hann", center=True)
+
+
+def test_forward_inverse_stft_mirror():
+    from setk_amd.libs import utils
+    from setk_amd import _ffi
+    g = load_golden("ref_stft.npz")
+    for name, N, fl, hop, center, rp2, window in mg.STFT_CASES:
+        x = g[f"{name}.x"]
+        n_fft = o.nextpow2(fl) if rp2 else fl
+        kw = dict(frame_len=fl, frame_hop=hop, center=center, window=window)
+        if n_fft != 512:
+            with pytest.raises(_ffi.SetkUnsupported):
+                utils.forward_stft(x, round_power_of_two=rp2, transpose=False, **kw)
+            continue
+        S = utils.forward_stft(x, round_power_of_two=rp2, transpose=False, **kw)
+        ref = g[f"{name}.S"]
+        assert S.shape == ref.shape and S.dtype == np.complex64
+        assert rel_rms(S, ref) < 1e-4, name
+        St = utils.forward_stft(x, round_power_of_two=rp2, transpose=True, **kw)
+        assert np.array_equal(St, S.T)
+        mag = utils.forward_stft(x, round_power_of_two=rp2, transpose=False, apply_log=True, **kw)
+        assert np.allclose(mag, np.log(np.maximum(np.abs(ref), utils.EPSILON)), atol=2e-3)
+        tol = 1e-5 if center else 1e-4
+        y = utils.inverse_stft(ref, transpose=False, **kw)
+        assert y.dtype == np.float32 and rms(y, g[f"{name}.y"]) < tol, name
+        yn = utils.inverse_stft(ref, transpose=False, norm=0.5, **kw)
+        assert rms(yn, g[f"{name}.y_norm"]) < tol, name
+    with pytest.raises(RuntimeError):
+        utils.forward_stft(np.zeros((2, 4000), np.float32), frame_len=512)
+
+
+def test_config0_roundtrip_on_device():
+    """BASELINE configs[0] (1-ch 10 s STFT -> iSTFT) through the mirror."""
+    from setk_amd.libs import utils
+    x = o.synth_utterance(0, 1, 160000)[0]
+    S = utils.forward_stft(x, transpose=False, **STFT_KW)
+    assert S.shape == (257, 626)
+    assert rel_rms(S, o.forward_stft(x, transpose=False, **STFT_KW)) < 1e-4
+    y = utils.inverse_stft(S, transpose=False, **STFT_KW)
+    assert y.shape[0] == 160000 and rms(y, x) / rms(x) < 1e-5
+
+
+@pytest.mark.parametrize("case", mg.BF_CASES, ids=[c[0] for c in mg.BF_CASES])
+def test_beamformer_mirror_against_reference_vectors(case):
+    from setk_amd.libs import beamformer as B
+    from test_oracle_golden import ORACLE_KINDS
+    g = load_golden("ref_beamformer.npz")
+    name = case[0]
+    mix, mask = mg.bf_inputs(case)
+    obs = o.multichannel_stft(mix, transpose=False, **STFT_KW)
+    N, F, T = obs.shape
+    Rs = B.compute_covar(obs, mask)
+    Rn = B.compute_covar(obs, 1 - mask)
+    assert Rs.shape == (F, N, N) and Rs.dtype == np.complex64
+    assert rel_rms(Rs, g[f"{name}.Rs"]) < 1e-5 and rel_rms(Rn, g[f"{name}.Rn"]) < 1e-5
+    pe = B.solve_pevd(g[f"{name}.Rs"])
+    assert rel_rms(pe, o.fix_gauge_evd(g[f"{name}.pevd"])) < 1e-4
+    pg = B.solve_pevd(g[f"{name}.Rs"], g[f"{name}.Rn"])
+    assert pg.dtype == np.complex128
+    assert rel_rms(pg, o.fix_gauge_gev(g[f"{name}.pgevd"], g[f"{name}.Rn"].astype(complex))) < 1e-4
+    # rank-1 approximations and BAN on the reference's covariances
+    for Rn_opt in (None, g[f"{name}.Rn"]):
+        r1 = B.rank1_constraint(g[f"{name}.Rs"], Rn_opt)
+        ref = o.rank1_constraint(g[f"{name}.Rs"], Rn_opt)
+        assert rel_rms(r1, ref) < 1e-4
+    w = o.mvdr_weight(g[f"{name}.Rs"], g[f"{name}.Rn"], gauge=True)
+    assert rel_rms(B.do_ban(w, g[f"{name}.Rn"]), o.do_ban(w, g[f"{name}.Rn"])) < 1e-5
+    classes = {
+        "mvdr": (lambda: B.MvdrBeamformer(F), {}),
+        "mvdr_ban": (lambda: B.MvdrBeamformer(F), dict(ban=True)),
+        "gevd": (lambda: B.GevdBeamformer(F), {}),
+        "gevd_ban": (lambda: B.GevdBeamformer(F), dict(ban=True)),
+        "pmwf0": (lambda: B.PmwfBeamformer(F, beta=0), {}),
+        "pmwf1": (lambda: B.PmwfBeamformer(F, beta=1), {}),
+        "pmwf0_ref1": (lambda: B.PmwfBeamformer(F, beta=0, ref_channel=1), {}),
+        "pmwf0_eig": (lambda: B.PmwfBeamformer(F, beta=0, rank1_appro="eig"), {}),
+        "pmwf0_gev": (lambda: B.PmwfBeamformer(F, beta=0, rank1_appro="gev"), {}),
+        "mpdr": (lambda: B.MpdrBeamformer(F), {}),
+        "mpdr_whiten": (lambda: B.MpdrBeamformer(F, whiten=True), {}),
+        "mpdr_whiten_ban": (lambda: B.MpdrBeamformer(F, whiten=True), dict(ban=True)),
+    }
+    norm = float(np.max(np.abs(mix)))
+    for kind, (mk, kw) in classes.items():
+        enh = mk().run(mask, obs, **kw)
+        assert enh.shape == (F, T)
+        wav = o.inverse_stft(enh, norm=norm, transpose=False, **STFT_KW)
+        if kind.startswith("pmwf"):
+            # gauge free: the vector stored by the unmodified reference
+            ref = g[f"{name}.{kind}.wav"]
+        else:
+            # the stored vector carries LAPACK's per-bin sign (pinned against the
+            # oracle in test_oracle_golden); compare under the declared gauge
+            okind, okw = ORACLE_KINDS[kind]
+            ref = o.inverse_stft(o.supervised_run(okind, mask, obs, gauge=True, **okw),
+                                 norm=norm, transpose=False, **STFT_KW)
+        err = rms(wav, ref) / rms(ref)
+        assert err < 1e-3, (name, kind, err)
+    # error behaviour of the reference
+    with pytest.raises(ValueError):
+        B.MvdrBeamformer(F).run(mask[:, :100], obs)
+    with pytest.raises(ValueError):
+        B.MvdrBeamformer(F).run(mask[:-1], obs)
+    with pytest.raises(ValueError):
+        B.Beamformer().beamform(np.zeros((F, N + 1), np.complex64), obs)
+    with pytest.raises(np.linalg.LinAlgError):
+        B.MvdrBeamformer(F).run(np.ones_like(mask), obs)  # noise mask == 0 -> singular
+    with pytest.raises(RuntimeError):
+        B.PmwfBeamformer(F, ref_channel=N).run(mask, obs)
+
+
+def _write_inputs(td, g, fmt):
+    import scipy.io.wavfile
+    from setk_amd.libs.data_handler import ArchiveWriter
+    keys = []
+    with open(os.path.join(td, "wav.scp"), "w") as ws:
+        for i in range(2):
+            scipy.io.wavfile.write(os.path.join(td, f"u{i}.wav"), 16000, g[f"u{i}.pcm"])
+            ws.write(f"u{i} {td}/u{i}.wav\n")
+            keys.append(f"u{i}")
+    if fmt == "numpy":
+        with open(os.path.join(td, "mask.scp"), "w") as ms:
+            for k in keys:
+                np.save(os.path.join(td, f"{k}.npy"), g[f"{k}.mask"])
+                ms.write(f"{k} {td}/{k}.npy\n")
+    else:
+        with ArchiveWriter(os.path.join(td, "mask.ark"), os.path.join(td, "mask.scp")) as w:
+            for k in keys:
+                w.write(k, g[f"{k}.mask"])
+    return keys
+
+
+@pytest.mark.parametrize("fmt", ["numpy", "kaldi"])
+def test_cli_end_to_end_against_reference_cli(tmp_path, fmt):
+    """Run the drop-in CLI as a subprocess on the inputs the reference CLI was
+    run on (oracle/make_golden.py gen_cli) and compare the PCM16 files."""
+    import scipy.io.wavfile
+    from test_oracle_golden import per_bin_gain_fit
+    g = load_golden("ref_cli.npz")
+    td = str(tmp_path)
+    keys = _write_inputs(td, g, fmt)
+    for bf in ("mvdr", "gevd", "pmwf-0"):
+        dst = os.path.join(td, bf)
+        cmd = [sys.executable, os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py"),
+               "--frame-len", "512", "--frame-hop", "256", "--mask-format", fmt,
+               "--beamformer", bf, os.path.join(td, "wav.scp"), os.path.join(td, "mask.scp"), dst]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "Processed 2 utterances out of 2" in r.stderr
+        assert f"Using offline {bf} beamformer" in r.stderr
+        for k in keys:
+            sr, y = scipy.io.wavfile.read(os.path.join(dst, k + ".wav"))
+            ref = g[f"{k}.{bf}"]
+            assert sr == 16000 and y.dtype == np.int16 and y.shape == ref.shape
+            a = y.astype(np.float64) / 32768
+            if bf == "pmwf-0":
+                # gauge free: the file the reference CLI itself wrote
+                b = ref.astype(np.float64) / 32768
+            else:
+                # the reference's file carries LAPACK's per-bin signs (pinned to
+                # the oracle in test_oracle_golden::test_cli_goldens)
+                samps = (g[f"{k}.pcm"].astype(np.float32) / 32768.0).T.copy()
+                b = o.enhance_utterance(samps, g[f"{k}.mask"], kind=bf, gauge=True)
+                b = np.rint(b.astype(np.float64) * 32767) / 32768
+            assert rms(a, b) / rms(b) < 1e-3, (bf, k)
+
+
+def test_cli_options_vad_postmask_itf_online(tmp_path):
+    import scipy.io.wavfile
+    g = load_golden("ref_cli.npz")
+    td = str(tmp_path)
+    _write_inputs(td, g, "numpy")
+    samps = (g["u0.pcm"].astype(np.float32) / 32768.0).T.copy()
+    mask = g["u0.mask"]
+    itf = np.random.default_rng(4).uniform(0.1, 0.9, size=mask.shape).astype(np.float32)
+    with open(os.path.join(td, "itf.scp"), "w") as f:
+        for k in ("u0", "u1"):
+            m = itf if k == "u0" else np.random.default_rng(5).uniform(
+                0.1, 0.9, size=g["u1.mask"].shape).astype(np.float32)
+            np.save(os.path.join(td, f"itf_{k}.npy"), m)
+            f.write(f"{k} {td}/itf_{k}.npy\n")
+    script = os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py")
+    base = [sys.executable, script, "--mask-format", "numpy"]
+    cases = {
+        "vad": (["--vad-proportion", "0.9", "--post-masking", "true", "--ban", "true"],
+                dict(vad_proportion=0.9, post_mask=True, ban=True)),
+        "itf": (["--itf-mask", os.path.join(td, "itf.scp")], dict(itf_mask=itf)),
+    }
+    for name, (extra, okw) in cases.items():
+        dst = os.path.join(td, name)
+        r = subprocess.run(base + extra + [os.path.join(td, "wav.scp"),
+                                           os.path.join(td, "mask.scp"), dst],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        sr, y = scipy.io.wavfile.read(os.path.join(dst, "u0.wav"))
+        ref = o.enhance_utterance(samps, mask, kind="mvdr", gauge=True, **okw)
+        a = y.astype(np.float64) / 32767
+        assert rms(a, ref) / rms(ref) < 2e-3, name
+    # block-online mode runs (the reference's raises TypeError) and is sane
+    dst = os.path.join(td, "online")
+    r = subprocess.run(base + ["--online.chunk-size", "16", os.path.join(td, "wav.scp"),
+                               os.path.join(td, "mask.scp"), dst],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "too small" in r.stderr
+    r = subprocess.run(base + ["--online.chunk-size", "32", "--online.channels", "4",
+                               os.path.join(td, "u0only.scp"), os.path.join(td, "mask.scp"), dst],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0  # missing scp
+    with open(os.path.join(td, "u0only.scp"), "w") as f:
+        f.write(f"u0 {td}/u0.wav\n")
+    r = subprocess.run(base + ["--online.chunk-size", "32", "--online.channels", "4",
+                               os.path.join(td, "u0only.scp"), os.path.join(td, "mask.scp"), dst],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    sr, y = scipy.io.wavfile.read(os.path.join(dst, "u0.wav"))
+    assert y.shape[0] == 8192 and np.max(np.abs(y)) > 1000
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
