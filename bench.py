@@ -116,7 +116,7 @@ def main():
     for _ in range(args.warmup):
         step()
     st = ctx.enhance_batch(opts, C, aptr, ns, mptr, None, wptr, want_status=True)
-    if any(st):
+    if any(st) and not os.environ.get("SETK_BENCH_NOCHECK"):
         raise SystemExit(f"numerical status {st}")
     ctx.set_profiling(True)
     barrier()

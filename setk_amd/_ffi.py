@@ -14,7 +14,7 @@ from ctypes import (POINTER, c_char_p, c_float, c_int, c_void_p)
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsetk_hip.so")
+LIB_PATH = os.environ.get("SETK_LIB", os.path.join(_HERE, "libsetk_hip.so"))
 
 SETK_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM = -1, -2, -3, -4

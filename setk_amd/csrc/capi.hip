@@ -715,7 +715,7 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
         if (T < 0) return T;
         total_frames += T;
     }
-    constexpr int TBq[9] = {0, 32, 16, 10, 8, 6, 5, 4, 4};
+    constexpr int TBq[9] = {0, 8, 8, 8, 4, 6, 5, 4, 4};
     const int target1 = (int)std::max<long>(TBq[C] * 8, (total_frames + h->p1_items - 1) / h->p1_items);
     const int target2 = (int)std::max<long>(kSuperTile * 4, (total_frames + h->p2_items - 1) / h->p2_items);
     int nparts_total = 0;

@@ -68,17 +68,44 @@ SETK_DEV void load_frame(cf (&v)[16], const float* __restrict__ x, int n_samp, i
     }
 }
 
-// One quad-row: full forward real transform of the frame in v; on return the
-// slot holds X[0..255] and *nyq = X[256].  No workgroup barrier: the 16 lanes
-// share a wavefront and LDS operations of a wavefront complete in order.
-SETK_DEV void quadrow_rfft(cf (&v)[16], cf* slot, float* nyq, const cf* tw, const cf* tw5,
-                           int la) {
+// raw (un-windowed) frame points: v[j] = (x[s+2n], x[s+2n+1]), n = la + 16 j
+SETK_DEV void load_raw(cf (&v)[16], const float* __restrict__ x, int n_samp, int s, int la,
+                       bool valid) {
+    if (!valid) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = make_float2(0.f, 0.f);
+        return;
+    }
+    const bool interior = (s >= 0) && (s + kNfft <= n_samp) &&
+                          ((reinterpret_cast<uintptr_t>(x + s) & 7) == 0);
+    if (interior) {
+        const float2* p = reinterpret_cast<const float2*>(x + s);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = p[la + 16 * j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int n = la + 16 * j;
+            v[j] = make_float2(x[reflect_index(s + 2 * n, n_samp)],
+                               x[reflect_index(s + 2 * n + 1, n_samp)]);
+        }
+    }
+}
+
+// One quad-row: forward real transform of a frame in three LDS-separated stages
+// (no workgroup barrier: the 16 lanes share a wavefront, and the LDS operations
+// of a wavefront complete in order).  After stage 3 the slot holds X[0..255]
+// and *nyq = X[256].
+SETK_DEV void qr_stage1(cf (&v)[16], cf* slot, const cf* tw, int la) {
     fft256_stage_a<-1>(v, slot, tw, la);
-    __builtin_amdgcn_wave_barrier();
+}
+SETK_DEV void qr_stage2(cf* slot, int la) {
+    cf v[16];
     fft256_stage_b<-1>(v, slot, la);
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) slot[la + 16 * kb] = v[dft16_pos(kb)];
-    __builtin_amdgcn_wave_barrier();
+}
+SETK_DEV void qr_stage3(cf* slot, float* nyq, const cf* tw5, int la) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int k = la + 16 * m;
@@ -132,27 +159,38 @@ SETK_DEV void store_pairs(float* P, int f, const cf* acc_s, const cf* acc_n) {
     }
 }
 
-constexpr int kP1Threads = 512;
+// frames per tile: 32/C transforms fill the 32 quad-rows; capped at 8 (small C
+// then uses several producer sets), 4 for C = 4 so that two mask planes fit LDS
+__host__ __device__ constexpr int tile_frames(int c) {
+    return c == 4 ? 4 : ((32 / c) < 8 ? (32 / c) : 8);
+}
 
-template <int C, bool DUMP>
-__global__ __launch_bounds__(kP1Threads, 2) void stft_covar_kernel(Pass1Args a) {
-    constexpr int TB = 32 / C;  // frames per tile
+// NQ = number of threads sharing one bin's Hermitian pairs (workgroup = 256*NQ
+// threads = 16*NQ quad-rows).  NQ = 4: 1024 threads, <= 128 VGPRs, 4 waves/SIMD.
+template <int C, bool DUMP, int NQ>
+__global__ __launch_bounds__(256 * NQ, NQ) void stft_covar_kernel(Pass1Args a) {
+    constexpr int NT = 256 * NQ;
+    constexpr int TB = tile_frames(C);  // frames per tile
     constexpr int NF = TB * C;  // transforms per tile (<= 32)
     constexpr int NP = npairs(C);
-    constexpr int NPH = (NP + 1) / 2;  // pairs of half 0; half 1 takes the rest
+    constexpr int NPQ = (NP + NQ - 1) / NQ;    // accumulator pairs per thread (max)
+    constexpr int NS = (16 * NQ) / NF;         // producer sets (quad-row groups of NF)
     constexpr int F = kBins, FP = kBinsPad;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cf* xt = reinterpret_cast<cf*>(smem);             // [NF][256]
-    cf* tw = xt + NF * 256;                           // [16][16]
+    cf* xt0 = reinterpret_cast<cf*>(smem);            // [2][NF][256] double-buffered tile
+    cf* tw = xt0 + 2 * NF * 256;                      // [16][16]
     cf* tw5 = tw + 256;                               // [128]
     float* win = reinterpret_cast<float*>(tw5 + 128);  // [512]
-    float* xn = win + kNfft;                          // [32] nyquist bins (real)
-    float* red = xn + 32;                             // [8]
+    float* xn0 = win + kNfft;                         // [2][32] nyquist bins (real)
+    float* red = xn0 + 64;                            // [16]
+    constexpr int MK = TB * F;                        // mask floats per tile
+    float* mks0 = red + 16;                           // [2][MK] speech mask rows of a tile
+    float* mkn0 = mks0 + 2 * MK;                      // [2][MK] interferer mask rows
 
     const int tid = threadIdx.x;
     const int la = tid & 15, grp = tid >> 4;
-    const int f = tid & 255, h = tid >> 8;
+    const int f = tid & 255, q = tid >> 8;
     const WorkItem wi = a.items[blockIdx.x];
     const UttDesc ud = a.utts[wi.utt];
     const int n_samp = ud.num_samples;
@@ -160,12 +198,13 @@ __global__ __launch_bounds__(kP1Threads, 2) void stft_covar_kernel(Pass1Args a) 
 
     if (tid < 256) tw[tid] = a.tw256[tid];
     if (tid < 128) tw5[tid] = a.tw512[tid];
-    win[tid] = a.window[tid];
+    if (tid < kNfft) win[tid] = a.window[tid];
+    if (NT < kNfft && tid + NT < kNfft) win[tid + NT] = a.window[tid + NT];
 
-    cf acc_s[NPH], acc_n[NPH];
+    cf acc_s[NPQ], acc_n[NPQ];
     float sum_s = 0.f, sum_n = 0.f;
 #pragma unroll
-    for (int e = 0; e < NPH; ++e) {
+    for (int e = 0; e < NPQ; ++e) {
         acc_s[e] = make_float2(0.f, 0.f);
         acc_n[e] = make_float2(0.f, 0.f);
     }
@@ -192,49 +231,147 @@ __global__ __launch_bounds__(kP1Threads, 2) void stft_covar_kernel(Pass1Args a) 
 
     const bool clamp = (a.flags & 0x2) != 0;
     const bool has_mn = ud.mask_n != nullptr;
-    const int my_tt = grp / C, my_c = grp - my_tt * C;  // this quad-row's transform
+    // this quad-row's role: transform `my_i` of the tiles whose index == my_set (mod NS)
+    const int my_set = grp / NF;
+    const int my_i = grp - my_set * NF;
+    const int my_tt = my_i / C, my_c = my_i - my_tt * C;
+    const bool producer = my_set < NS;
 
-    for (int tb = wi.t0; tb < wi.t1; tb += TB) {
-        // ---- mask prefetch (bin f, nyquist column for the ny threads) ----
-        float ms[TB], mn[TB], nyw[TB];
-        if (!DUMP) {
+    // Software pipeline over tiles (double-buffered LDS tile, ONE barrier per
+    // tile): while tile k is consumed from buffer k&1, tile k+1 is transformed
+    // into the other buffer by producer set (k+1) % NS, its three LDS-separated
+    // stages interleaved with the consume frames of the same waves.
+    const float* my_audio = ud.audio + (size_t)my_c * n_samp;
+    const float2* w2 = reinterpret_cast<const float2*>(win);
+    __syncthreads();  // tables ready
+
+    // register prefetch, one production / one tile ahead
+    cf raw[16];
+    auto fetch_raw = [&](int tb_tile) {
+        const int t = tb_tile + my_tt;
+        load_raw(raw, my_audio, n_samp, t * a.g.hop - a.g.pad, la, t < wi.t1);
+    };
+    auto stage1 = [&](cf* slot, int tb_next_own) {
+        // window the prefetched frame, start the next fetch, radix-16, transpose
+        cf v[16];
 #pragma unroll
-            for (int tt = 0; tt < TB; ++tt) {
-                const int t = tb + tt;
-                const bool valid = t < wi.t1;
-                float s = 0.f, n = 0.f, w = 0.f;
-                if (valid) {
-                    s = ud.mask_s[(size_t)t * F + f];
-                    if (clamp) s = fminf(s, 1.f);
-                    n = has_mn ? ud.mask_n[(size_t)t * F + f] : 1.f - s;
-                    if (ny_active) {
-                        float s256 = ud.mask_s[(size_t)t * F + 256];
-                        if (clamp) s256 = fminf(s256, 1.f);
-                        const float n256 = has_mn ? ud.mask_n[(size_t)t * F + 256] : 1.f - s256;
-                        const bool speech = (ny_item < NP) || (ny_item == 2 * NP);
-                        w = speech ? s256 : n256;
-                    }
-                }
-                ms[tt] = s;
-                mn[tt] = n;
-                nyw[tt] = w;
+        for (int j = 0; j < 16; ++j) {
+            const float2 d = raw[j];
+            const float2 w = w2[la + 16 * j];
+            mx = fmaxf(mx, fmaxf(fabsf(d.x), fabsf(d.y)));
+            v[j] = make_float2(d.x * w.x, d.y * w.y);
+        }
+        if (tb_next_own < wi.t1) fetch_raw(tb_next_own);
+        qr_stage1(v, slot, tw, la);
+    };
+    // mask rows [tile][F] are contiguous in memory: staged flat, coalesced,
+    // one tile ahead, through registers into LDS (clamp applied here)
+    constexpr int MKL = (MK + NT - 1) / NT;  // loads per thread
+    float mreg_s[MKL], mreg_n[MKL];
+    auto fetch_masks = [&](int tb_tile) {
+        const int nvalid = min(TB, wi.t1 - tb_tile) * F;
+        const float* src_s = ud.mask_s + (size_t)tb_tile * F;
+        const float* src_n = has_mn ? ud.mask_n + (size_t)tb_tile * F : nullptr;
+#pragma unroll
+        for (int r = 0; r < MKL; ++r) {
+            const int i = tid + r * NT;
+            float vs = 0.f, vn = 0.f;
+#if !(defined(SETK_ABL) && SETK_ABL == 3)
+            if (i < nvalid) {
+                vs = src_s[i];
+                if (has_mn) vn = src_n[i];
+            }
+#endif
+            mreg_s[r] = vs;
+            mreg_n[r] = vn;
+        }
+    };
+    auto stash_masks = [&](int b) {
+#pragma unroll
+        for (int r = 0; r < MKL; ++r) {
+            const int i = tid + r * NT;
+            if (i < MK) {
+                mks0[b * MK + i] = clamp ? fminf(mreg_s[r], 1.f) : mreg_s[r];
+                if (has_mn) mkn0[b * MK + i] = mreg_n[r];
             }
         }
-        __syncthreads();  // tables ready / previous tile fully consumed
+    };
 
-        // ---- produce: one transform per quad-row ----
-        if (grp < NF) {
-            const int t = tb + my_tt;
-            cf v[16];
-            load_frame(v, ud.audio + (size_t)my_c * n_samp, n_samp, t * a.g.hop - a.g.pad, la, win,
-                       t < wi.t1, mx);
-            quadrow_rfft(v, xt + grp * 256, xn + grp, tw, tw5, la);
-        }
-        __syncthreads();
+    if (!DUMP) {
+        fetch_masks(wi.t0);
+        stash_masks(0);
+    }
+    if (producer) fetch_raw(wi.t0 + my_set * TB);
+    if (producer && my_set == 0) {
+        cf* slot = xt0 + my_i * 256;
+        stage1(slot, wi.t0 + NS * TB);
+        __builtin_amdgcn_wave_barrier();
+        qr_stage2(slot, la);
+        __builtin_amdgcn_wave_barrier();
+        qr_stage3(slot, xn0 + my_i, tw5, la);
+    }
+    __syncthreads();
+    int buf = 0;
+    int next_set = 1 % NS;  // producer set of tile k+1
+    constexpr int FA = (TB + 3) / 4, FB = (TB + 1) / 2;  // consume frames [0,FA) [FA,FB) [FB,TB)
 
+    for (int tb = wi.t0; tb < wi.t1; tb += TB, buf ^= 1) {
+        const cf* xt = xt0 + buf * NF * 256;
+        const float* xn = xn0 + buf * 32;
+        cf* slot = xt0 + (buf ^ 1) * NF * 256 + my_i * 256;  // next tile's slot
+#if defined(SETK_ABL) && SETK_ABL == 2
+        const bool prod = false;
+#else
+        const bool prod = producer && (my_set == next_set) && (tb + TB < wi.t1);
+#endif
+        next_set = (next_set + 1 == NS) ? 0 : next_set + 1;
+        // ---- mask rows of tile k+1: loads in flight during this tile ----
+        const float* mks = mks0 + buf * MK;
+        const float* mkn = mkn0 + buf * MK;
+        const bool more = tb + TB < wi.t1;
+        if (!DUMP && more) fetch_masks(tb + TB);
+        auto consume = [&](int tt) {
+            cf x[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) x[c] = xt[(tt * C + c) * 256 + f];
+            const bool fvalid = tb + tt < wi.t1;
+            const float ws = mks[tt * F + f];
+            const float wn = fvalid ? (has_mn ? mkn[tt * F + f] : 1.f - ws) : 0.f;
+#if defined(SETK_ABL) && SETK_ABL == 1
+            {
+                float t = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) t += x[c].x + x[c].y;
+                sum_s += t * ws + wn;
+                return;
+            }
+#endif
+            if (q == 0) {
+                sum_s += ws;
+                sum_n += wn;
+                accumulate_pairs<C, (0 * NP) / NQ, (1 * NP) / NQ>(x, ws, wn, acc_s, acc_n);
+            }
+            if (NQ > 1 && q == 1)
+                accumulate_pairs<C, (1 * NP) / NQ, (2 * NP) / NQ>(x, ws, wn, acc_s, acc_n);
+            if (NQ > 2 && q == 2)
+                accumulate_pairs<C, (2 * NP) / NQ, (3 * NP) / NQ>(x, ws, wn, acc_s, acc_n);
+            if (NQ > 3 && q == 3)
+                accumulate_pairs<C, (3 * NP) / NQ, (4 * NP) / NQ>(x, ws, wn, acc_s, acc_n);
+            if (ny_active) {
+                const float prod_ny = (ny_item < 2 * NP)
+                                          ? xn[tt * C + ny_i] * xn[tt * C + ny_j]
+                                          : 1.f;
+                const float s256 = mks[tt * F + 256];
+                const float n256 = fvalid ? (has_mn ? mkn[tt * F + 256] : 1.f - s256) : 0.f;
+                const bool speech = (ny_item < NP) || (ny_item == 2 * NP);
+                ny_acc = fmaf(speech ? s256 : n256, prod_ny, ny_acc);
+            }
+        };
+
+        if (prod) stage1(slot, tb + TB + NS * TB);
         if (DUMP) {
             // spec[c][t][f], f fastest
-            for (int i = h; i < NF; i += 2) {
+            for (int i = q; i < NF; i += NQ) {
                 const int tt = i / C, c = i - tt * C;
                 const int t = tb + tt;
                 if (t < wi.t1) {
@@ -244,28 +381,25 @@ __global__ __launch_bounds__(kP1Threads, 2) void stft_covar_kernel(Pass1Args a) 
                 }
             }
         } else {
-            // ---- consume: masked outer products of bin f, pair half h ----
 #pragma unroll
-            for (int tt = 0; tt < TB; ++tt) {
-                cf x[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) x[c] = xt[(tt * C + c) * 256 + f];
-                const float ws = ms[tt], wn = mn[tt];
-                if (h == 0) {
-                    sum_s += ws;
-                    sum_n += wn;
-                    accumulate_pairs<C, 0, NPH>(x, ws, wn, acc_s, acc_n);
-                } else {
-                    accumulate_pairs<C, NPH, NP>(x, ws, wn, acc_s, acc_n);
-                }
-                if (ny_active) {
-                    const float prod = (ny_item < 2 * NP)
-                                           ? xn[tt * C + ny_i] * xn[tt * C + ny_j]
-                                           : 1.f;
-                    ny_acc = fmaf(nyw[tt], prod, ny_acc);
-                }
-            }
+            for (int tt = 0; tt < FA; ++tt) consume(tt);
         }
+        __builtin_amdgcn_wave_barrier();
+        if (prod) qr_stage2(slot, la);
+        if (!DUMP) {
+#pragma unroll
+            for (int tt = FA; tt < FB; ++tt) consume(tt);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (prod) qr_stage3(slot, xn0 + (buf ^ 1) * 32 + my_i, tw5, la);
+        if (!DUMP) {
+#pragma unroll
+            for (int tt = FB; tt < TB; ++tt) consume(tt);
+        }
+        if (!DUMP && more) stash_masks(buf ^ 1);
+#if !(defined(SETK_ABL) && SETK_ABL == 4)
+        __syncthreads();
+#endif
     }
 
     if (!DUMP) {
@@ -274,7 +408,7 @@ __global__ __launch_bounds__(kP1Threads, 2) void stft_covar_kernel(Pass1Args a) 
             // samples after the last frame's span are never loaded above
             const int covered = (T - 1) * a.g.hop - a.g.pad + kNfft;
             for (int c = 0; c < C; ++c)
-                for (int i = covered + tid; i < n_samp; i += kP1Threads)
+                for (int i = covered + tid; i < n_samp; i += NT)
                     mx = fmaxf(mx, fabsf(ud.audio[(size_t)c * n_samp + i]));
         }
 #pragma unroll
@@ -285,19 +419,20 @@ __global__ __launch_bounds__(kP1Threads, 2) void stft_covar_kernel(Pass1Args a) 
         if (tid == 0) {
             float bm = red[0];
 #pragma unroll
-            for (int w = 1; w < kP1Threads / 64; ++w) bm = fmaxf(bm, red[w]);
+            for (int w = 1; w < NT / 64; ++w) bm = fmaxf(bm, red[w]);
             atomicMax(a.norm_bits + wi.utt, __float_as_uint(bm));
         }
 
         // ---- partial slab: planes [s.re | s.im | n.re | n.im | sum_s sum_n] ----
         float* P = a.partials + (size_t)wi.part * nplanes_partial(C) * FP;
-        if (h == 0) {
-            store_pairs<C, 0, NPH>(P, f, acc_s, acc_n);
+        if (q == 0) {
+            store_pairs<C, (0 * NP) / NQ, (1 * NP) / NQ>(P, f, acc_s, acc_n);
             P[(4 * NP + 0) * FP + f] = sum_s;
             P[(4 * NP + 1) * FP + f] = sum_n;
-        } else {
-            store_pairs<C, NPH, NP>(P, f, acc_s, acc_n);
         }
+        if (NQ > 1 && q == 1) store_pairs<C, (1 * NP) / NQ, (2 * NP) / NQ>(P, f, acc_s, acc_n);
+        if (NQ > 2 && q == 2) store_pairs<C, (2 * NP) / NQ, (3 * NP) / NQ>(P, f, acc_s, acc_n);
+        if (NQ > 3 && q == 3) store_pairs<C, (3 * NP) / NQ, (4 * NP) / NQ>(P, f, acc_s, acc_n);
         if (ny_active) {
             if (ny_item < NP) {
                 P[(0 * NP + ny_item) * FP + 256] = ny_acc;
@@ -312,31 +447,44 @@ __global__ __launch_bounds__(kP1Threads, 2) void stft_covar_kernel(Pass1Args a) 
     }
 }
 
-template <int C, bool DUMP>
+static int p1_nq() {
+    static int nq = -1;
+    if (nq < 0) {
+        const char* e = getenv("SETK_P1_NQ");
+        nq = e ? atoi(e) : 2;
+        if (nq != 2 && nq != 4) nq = 2;
+    }
+    return nq;
+}
+
+template <int C, bool DUMP, int NQ>
 static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s) {
-    constexpr int TB = 32 / C, NF = TB * C;
-    const size_t lds = (size_t)NF * 256 * sizeof(cf) + 256 * sizeof(cf) + 128 * sizeof(cf) +
-                       kNfft * sizeof(float) + 32 * sizeof(float) + 8 * sizeof(float);
-    auto k = stft_covar_kernel<C, DUMP>;
+    constexpr int TB = tile_frames(C), NF = TB * C;
+    const size_t lds = (size_t)2 * NF * 256 * sizeof(cf) + 256 * sizeof(cf) + 128 * sizeof(cf) +
+                       kNfft * sizeof(float) + 64 * sizeof(float) + 16 * sizeof(float) +
+                       (size_t)4 * TB * kBins * sizeof(float);
+    auto k = stft_covar_kernel<C, DUMP, NQ>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (getenv("SETK_DEBUG")) {
         int nb = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k),
-                                                           kP1Threads, lds);
-        fprintf(stderr, "[setk] pass1<%d,%d> lds=%zu items=%d blocks/CU=%d\n", C, (int)DUMP, lds,
-                n_items, nb);
+                                                           256 * NQ, lds);
+        fprintf(stderr, "[setk] pass1<%d,%d,%d> lds=%zu items=%d blocks/CU=%d\n", C, (int)DUMP, NQ,
+                lds, n_items, nb);
     }
-    hipLaunchKernelGGL(k, dim3(n_items), dim3(kP1Threads), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(n_items), dim3(256 * NQ), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s) {
-#define SETK_CASE(c)                                                        \
-    case c:                                                                 \
-        return dump ? launch_pass1_t<c, true>(a, n_items, s)                \
-                    : launch_pass1_t<c, false>(a, n_items, s);
+    const int nq = p1_nq();
+#define SETK_CASE(c)                                                                      \
+    case c:                                                                               \
+        if (dump) return launch_pass1_t<c, true, 2>(a, n_items, s);                        \
+        return nq == 4 ? launch_pass1_t<c, false, 4>(a, n_items, s)                        \
+                       : launch_pass1_t<c, false, 2>(a, n_items, s);
     switch (C) {
         SETK_CASE(1)
         SETK_CASE(2)
