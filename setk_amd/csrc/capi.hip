@@ -35,7 +35,8 @@ struct setk_context {
     // STFT plan
     bool planned = false;
     int frame_len = 0, hop = 0, n_fft = 0, center = 0;
-    float* d_window = nullptr;  // [n_fft] padded analysis/synthesis window
+    float* d_window = nullptr;  // [n_fft] padded analysis/synthesis window, scaled by 0.5
+                                // (the rfft split / irfft merge omit their 1/2)
     float* d_winsq = nullptr;   // [n_fft]
     float2* d_tw256 = nullptr;  // [256]
     float2* d_tw512 = nullptr;  // [129]
@@ -271,7 +272,7 @@ int setk_stft_plan(setk_handle_t h, int frame_len, int frame_hop, int n_fft, int
     const int lpad = (n_fft - frame_len) / 2;
     for (int i = 0; i < frame_len; ++i) {
         double v = window ? (double)window[i] : 0.5 - 0.5 * std::cos(2.0 * kPi * i / frame_len);
-        w[lpad + i] = (float)v;
+        w[lpad + i] = 0.5f * (float)v;
         w2[lpad + i] = (float)(v * v);
     }
     std::vector<float2> t256(256), t512(129);

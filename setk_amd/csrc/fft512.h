@@ -108,20 +108,25 @@ SETK_DEV void fft256_stage_b(cf (&v)[16], const cf* slot, int la) {
 
 // Hermitian split of the packed transform: from Zk = Z[k], Zm = Z[256-k]
 // (Z[256] == Z[0]) produce X[k] and X[256-k] of the 512-point real DFT.
-// w = exp(-2 pi i k / 512).
+// w = exp(-2 pi i k / 512).  The 1/2 of E = (Zk + conj Zm)/2, O = (Zk - conj Zm)/2i
+// is NOT applied here: the analysis window table is pre-scaled by 0.5 (exact in
+// binary floating point), which saves four multiplies per bin pair.  The
+// self-paired bin 128, X[128] = conj(Z[128]), must therefore be doubled by the
+// caller.
 SETK_DEV void rfft_split(cf Zk, cf Zm, cf w, cf& Xk, cf& Xm) {
-    cf A = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));   // E[k]
-    cf O = make_float2(0.5f * (Zk.y + Zm.y), -0.5f * (Zk.x - Zm.x));  // O[k]
+    cf A = make_float2(Zk.x + Zm.x, Zk.y - Zm.y);  // 2 E[k]
+    cf O = make_float2(Zk.y + Zm.y, Zm.x - Zk.x);  // 2 O[k]
     cf B = cmul(w, O);
     Xk = cadd(A, B);
     Xm = make_float2(A.x - B.x, -(A.y - B.y));
 }
 
-// Inverse of rfft_split: from Y[k], Y[256-k] build Z[k], Z[256-k] of the
-// packed inverse transform.  w = exp(-2 pi i k / 512) (conjugated inside).
+// Inverse of rfft_split: from Y[k], Y[256-k] build 2 Z[k], 2 Z[256-k] of the
+// packed inverse transform (the 1/2 is folded into the half-scaled synthesis
+// window).  w = exp(-2 pi i k / 512) (conjugated inside).
 SETK_DEV void irfft_merge(cf Yk, cf Ym, cf w, cf& Zk, cf& Zm) {
-    cf E = make_float2(0.5f * (Yk.x + Ym.x), 0.5f * (Yk.y - Ym.y));
-    cf D = make_float2(0.5f * (Yk.x - Ym.x), 0.5f * (Yk.y + Ym.y));
+    cf E = make_float2(Yk.x + Ym.x, Yk.y - Ym.y);
+    cf D = make_float2(Yk.x - Ym.x, Yk.y + Ym.y);
     cf O = cmulc(D, w);  // D * conj(w)
     Zk = make_float2(E.x - O.y, E.y + O.x);   // E + i O
     Zm = make_float2(E.x + O.y, -E.y + O.x);  // conj(E) + i conj(O)

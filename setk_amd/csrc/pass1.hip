@@ -99,25 +99,45 @@ SETK_DEV void load_raw(cf (&v)[16], const float* __restrict__ x, int n_samp, int
 SETK_DEV void qr_stage1(cf (&v)[16], cf* slot, const cf* tw, int la) {
     fft256_stage_a<-1>(v, slot, tw, la);
 }
-SETK_DEV void qr_stage2(cf* slot, int la) {
+// lane la <- value of lane (16 - la) & 15 of the same quad-row (a DPP row):
+// row_mirror (la -> 15 - la) followed by row_ror:1
+SETK_DEV float qr_partner(float x) {
+    int v = __builtin_bit_cast(int, x);
+    v = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);  // row_mirror
+    v = __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, true);  // row_ror:1
+    return __builtin_bit_cast(float, v);
+}
+// Stage 2+3: second radix-16 and the Hermitian split done in registers: lane la
+// owns Z[la + 16 kb]; the mirror bin 256 - k of k = la + 16 m lives in lane
+// (16 - la) & 15, register 15 - m (lane 0: its own register 16 - m), fetched with
+// two DPP moves instead of an LDS round trip.  Writes X[k], X[256-k], m < 8.
+SETK_DEV void qr_stage23(cf* slot, float* nyq, const cf* tw5, int la) {
     cf v[16];
     fft256_stage_b<-1>(v, slot, la);
-#pragma unroll
-    for (int kb = 0; kb < 16; ++kb) slot[la + 16 * kb] = v[dft16_pos(kb)];
-}
-SETK_DEV void qr_stage3(cf* slot, float* nyq, const cf* tw5, int la) {
+    const bool lane0 = (la == 0);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int k = la + 16 * m;
-        const cf Zk = slot[k];
-        const cf Zm = slot[(256 - k) & 255];
+        const cf Zk = v[dft16_pos(m)];
+        const cf src = v[dft16_pos(15 - m)];
+        cf Zm = make_float2(qr_partner(src.x), qr_partner(src.y));
+        const cf own = v[dft16_pos((16 - m) & 15)];
+        Zm.x = lane0 ? own.x : Zm.x;
+        Zm.y = lane0 ? own.y : Zm.y;
         cf Xk, Xm;
         rfft_split(Zk, Zm, tw5[k], Xk, Xm);
-        if (k == 0) {
-            const cf Z128 = slot[128];
-            slot[0] = make_float2(Xk.x, 0.f);
-            *nyq = Xm.x;
-            slot[128] = make_float2(Z128.x, -Z128.y);
+        if (m == 0) {
+            // lane 0: k = 0 pairs with itself (Z[256] == Z[0]): X[0], X[256]; and
+            // the self-paired bin 128 = conj(Z[128])
+            const cf Z128 = v[dft16_pos(8)];
+            if (lane0) {
+                slot[0] = make_float2(Xk.x, 0.f);
+                *nyq = Xm.x;
+                slot[128] = make_float2(2.f * Z128.x, -2.f * Z128.y);
+            } else {
+                slot[k] = Xk;
+                slot[256 - k] = Xm;
+            }
         } else {
             slot[k] = Xk;
             slot[256 - k] = Xm;
@@ -306,14 +326,12 @@ __global__ __launch_bounds__(256 * NQ, NQ) void stft_covar_kernel(Pass1Args a) {
         cf* slot = xt0 + my_i * 256;
         stage1(slot, wi.t0 + NS * TB);
         __builtin_amdgcn_wave_barrier();
-        qr_stage2(slot, la);
-        __builtin_amdgcn_wave_barrier();
-        qr_stage3(slot, xn0 + my_i, tw5, la);
+        qr_stage23(slot, xn0 + my_i, tw5, la);
     }
     __syncthreads();
     int buf = 0;
     int next_set = 1 % NS;  // producer set of tile k+1
-    constexpr int FA = (TB + 3) / 4, FB = (TB + 1) / 2;  // consume frames [0,FA) [FA,FB) [FB,TB)
+    constexpr int FB = (TB + 1) / 2;  // consume frames [0,FB) | [FB,TB) around stage 2+3
 
     for (int tb = wi.t0; tb < wi.t1; tb += TB, buf ^= 1) {
         const cf* xt = xt0 + buf * NF * 256;
@@ -382,16 +400,10 @@ __global__ __launch_bounds__(256 * NQ, NQ) void stft_covar_kernel(Pass1Args a) {
             }
         } else {
 #pragma unroll
-            for (int tt = 0; tt < FA; ++tt) consume(tt);
+            for (int tt = 0; tt < FB; ++tt) consume(tt);
         }
         __builtin_amdgcn_wave_barrier();
-        if (prod) qr_stage2(slot, la);
-        if (!DUMP) {
-#pragma unroll
-            for (int tt = FA; tt < FB; ++tt) consume(tt);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (prod) qr_stage3(slot, xn0 + (buf ^ 1) * 32 + my_i, tw5, la);
+        if (prod) qr_stage23(slot, xn0 + (buf ^ 1) * 32 + my_i, tw5, la);
         if (!DUMP) {
 #pragma unroll
             for (int tt = FB; tt < TB; ++tt) consume(tt);

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                         Yk[m].x = fmaf(wc[0].x, Xk.x, Yk[m].x);
                         Yk[m].y = fmaf(wc[256].x, Xm.x, Yk[m].y);
                         const cf Z128 = slot[128];
-                        const cf X128 = make_float2(Z128.x, -Z128.y);
+                        const cf X128 = make_float2(2.f * Z128.x, -2.f * Z128.y);
                         Ym[m] = cadd(Ym[m], cmulc(X128, wc[128]));
                     } else {
                         Yk[m] = cadd(Yk[m], cmulc(Xk, wc[k]));
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                 }
             }
             if (k == 0) {
-                slot[0] = make_float2(0.5f * (yk.x + yk.y), 0.5f * (yk.x - yk.y));
-                slot[128] = make_float2(ym.x, -ym.y);
+                slot[0] = make_float2(yk.x + yk.y, yk.x - yk.y);
+                slot[128] = make_float2(2.f * ym.x, -2.f * ym.y);
             } else {
                 cf Zk, Zm;
                 irfft_merge(yk, ym, tw5[k], Zk, Zm);

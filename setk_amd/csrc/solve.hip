@@ -61,7 +61,7 @@ SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
     cd v[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) v[i] = make_double2((i == j) ? 1.0 : 0.0, 0.0);
-    const double tol2 = 1e-24;  // |g_p^H g_q| <= 1e-12 |g_p||g_q|
+    const double tol2 = 1e-20;  // |g_p^H g_q| <= 1e-10 |g_p||g_q| (outputs are float32)
     bool done = false;
     for (int sweep = 0; sweep < 40 && !done; ++sweep) {
         bool rot = false;
