@@ -191,6 +191,31 @@ void split_frames(int T, int target, int quant, std::vector<std::pair<int, int>>
     for (int t = 0; t < T; t += fw) out->push_back({t, std::min(T, t + fw)});
 }
 
+// Frames per work item such that the work list fills whole "waves" of resident
+// workgroups: among the splits of the longest utterance into 1..32 ranges pick
+// the one minimising  ceil(items / slots) * frames_per_item  (makespan in
+// frames); utterances shorter than the target become single items.
+int choose_target(const std::vector<int>& frames, int slots, int quant, int min_frames) {
+    int tmax = 1;
+    for (int t : frames) tmax = std::max(tmax, t);
+    long best_cost = -1;
+    int best = tmax;
+    for (int parts = 1; parts <= 32; ++parts) {
+        int target = (tmax + parts - 1) / parts;
+        target = ((target + quant - 1) / quant) * quant;
+        if (target < min_frames && parts > 1) break;
+        long items = 0;
+        for (int t : frames) items += (t + target - 1) / target;
+        const long waves = (items + slots - 1) / slots;
+        const long cost = waves * (long)target + 8 * waves;  // + per-wave fixed cost
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = target;
+        }
+    }
+    return best;
+}
+
 }  // namespace
 
 extern "C" {
@@ -209,6 +234,13 @@ int setk_create(setk_handle_t* out, int device_ordinal) {
     if (hipSetDevice(device_ordinal) != hipSuccess) return SETK_ERR_HIP;
     setk_context* h = new setk_context();
     h->device = device_ordinal;
+    // resident workgroup slots: pass 1 runs 1 workgroup per CU, pass 2 two; the
+    // work lists are cut to fill whole waves of those slots (choose_target)
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) {
+        h->p1_items = prop.multiProcessorCount;
+        h->p2_items = 2 * prop.multiProcessorCount;
+    }
     if (const char* e = getenv("SETK_P1_ITEMS")) h->p1_items = std::max(1, atoi(e));
     if (const char* e = getenv("SETK_P2_ITEMS")) h->p2_items = std::max(1, atoi(e));
     *out = h;
@@ -717,8 +749,10 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
         total_frames += T;
     }
     constexpr int TBq[9] = {0, 8, 8, 8, 4, 6, 5, 4, 4};
-    const int target1 = (int)std::max<long>(TBq[C] * 8, (total_frames + h->p1_items - 1) / h->p1_items);
-    const int target2 = (int)std::max<long>(kSuperTile * 4, (total_frames + h->p2_items - 1) / h->p2_items);
+    std::vector<int> all_frames(n_utts);
+    for (int u = 0; u < n_utts; ++u) all_frames[u] = setk_stft_num_frames(h, num_samples[u]);
+    const int target1 = choose_target(all_frames, h->p1_items, TBq[C], TBq[C] * 8);
+    const int target2 = choose_target(all_frames, h->p2_items, kSuperTile, kSuperTile * 4);
     int nparts_total = 0;
     for (int u = 0; u < n_utts; ++u) {
         UttDesc& ud = uds[u];

@@ -88,6 +88,15 @@ SETK_DEV void load_raw(cf (&v)[16], const float* __restrict__ x, int n_samp, int
     }
 }
 
+// lane la <- value of lane (16 - la) & 15 of the same quad-row (a DPP row):
+// row_mirror (la -> 15 - la) then row_ror:1
+SETK_DEV float qr_partner2(float x) {
+    int v = __builtin_bit_cast(int, x);
+    v = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
+    v = __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, true);
+    return __builtin_bit_cast(float, v);
+}
+
 // ISTFT_ONLY: Y comes from the per-item spectrogram (ud.audio reinterpreted as
 // spec[t][f]) instead of being beamformed from audio.
 //
@@ -121,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
 
     const int tid = threadIdx.x;
     const int la = tid & 15, grp = tid >> 4;
+    const bool lane0 = (la == 0);
     const WorkItem wi = a.items[blockIdx.x];
     const UttDesc ud = a.utts[wi.utt];
     const int n_samp = ud.num_samples;
@@ -191,70 +201,86 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                              la, tvalid);
                 fft256_stage_a<-1>(v, slot, tw, la);
                 __builtin_amdgcn_wave_barrier();
-                fft256_stage_b<-1>(v, slot, la);
-#pragma unroll
-                for (int kb = 0; kb < 16; ++kb) slot[la + 16 * kb] = v[dft16_pos(kb)];
-                __builtin_amdgcn_wave_barrier();
+                fft256_stage_b<-1>(v, slot, la);  // v[pos(kb)] = Z[la + 16 kb]
                 const cf* wc = wtab + c * F;
+                // Hermitian split in registers: the mirror bin of k = la + 16 m is
+                // register 15 - m of lane (16 - la) & 15 (lane 0: own register 16 - m)
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const int k = la + 16 * m;
-                    const cf Zk = slot[k];
-                    const cf Zm = slot[(256 - k) & 255];
+                    const cf Zk = v[dft16_pos(m)];
+                    const cf src = v[dft16_pos(15 - m)];
+                    const cf own = v[dft16_pos((16 - m) & 15)];
+                    cf Zm = make_float2(qr_partner2(src.x), qr_partner2(src.y));
+                    Zm.x = lane0 ? own.x : Zm.x;
+                    Zm.y = lane0 ? own.y : Zm.y;
                     cf Xk, Xm;
                     rfft_split(Zk, Zm, tw5[k], Xk, Xm);
-                    if (k == 0) {
-                        // X[0], X[256] are real and only Re Y[0], Re Y[256]
-                        // reach the inverse (numpy irfft drops their imag)
-                        Yk[m].x = fmaf(wc[0].x, Xk.x, Yk[m].x);
-                        Yk[m].y = fmaf(wc[256].x, Xm.x, Yk[m].y);
-                        const cf Z128 = slot[128];
+                    const cf wk = wc[k], wm = wc[256 - k];
+                    const cf yk1 = cadd(Yk[m], cmulc(Xk, wk));
+                    const cf ym1 = cadd(Ym[m], cmulc(Xm, wm));
+                    if (m == 0) {
+                        // lane 0: X[0], X[256] are real and only Re Y[0], Re Y[256]
+                        // reach the inverse (numpy irfft drops their imag); the
+                        // self-paired bin 128 rides in Ym
+                        const cf Z128 = v[dft16_pos(8)];
                         const cf X128 = make_float2(2.f * Z128.x, -2.f * Z128.y);
-                        Ym[m] = cadd(Ym[m], cmulc(X128, wc[128]));
+                        const cf yk0 = make_float2(fmaf(wk.x, Xk.x, Yk[m].x), fmaf(wm.x, Xm.x, Yk[m].y));
+                        const cf ym0 = cadd(Ym[m], cmulc(X128, wc[128]));
+                        Yk[m] = lane0 ? yk0 : yk1;
+                        Ym[m] = lane0 ? ym0 : ym1;
                     } else {
-                        Yk[m] = cadd(Yk[m], cmulc(Xk, wc[k]));
-                        Ym[m] = cadd(Ym[m], cmulc(Xm, wc[256 - k]));
+                        Yk[m] = yk1;
+                        Ym[m] = ym1;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        // ---- optional post-mask, merge into the packed inverse input ----
+        // ---- optional post-mask, merge into the packed inverse input (registers) ----
+        cf Zlo[8], Zhi[8];  // 2 Z'[la + 16 m] and 2 Z'[256 - (la + 16 m)]
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int k = la + 16 * m;
             cf yk = Yk[m], ym = Ym[m];
             if (post_mask && tvalid) {
                 const float* mrow = ud.mask_s + (size_t)t * F;
-                if (k == 0) {
-                    float m0 = mrow[0], m256 = mrow[256], m128 = mrow[128];
-                    if (clamp) { m0 = fminf(m0, 1.f); m256 = fminf(m256, 1.f); m128 = fminf(m128, 1.f); }
-                    yk.x *= m0;
-                    yk.y *= m256;
-                    ym = cscale(ym, m128);
-                } else {
-                    float mk = mrow[k], mm = mrow[256 - k];
-                    if (clamp) { mk = fminf(mk, 1.f); mm = fminf(mm, 1.f); }
-                    yk = cscale(yk, mk);
-                    ym = cscale(ym, mm);
-                }
+                // lane 0, m == 0 carries (Re Y0, Re Y256) in yk and Y128 in ym
+                const int ia = k, ib = (k == 0) ? 256 : k;
+                float ma = mrow[ia], mb = mrow[ib];
+                float mc = mrow[(k == 0) ? 128 : 256 - k];
+                if (clamp) { ma = fminf(ma, 1.f); mb = fminf(mb, 1.f); mc = fminf(mc, 1.f); }
+                yk.x *= ma;
+                yk.y *= mb;
+                ym = cscale(ym, mc);
             }
-            if (k == 0) {
-                slot[0] = make_float2(yk.x + yk.y, yk.x - yk.y);
-                slot[128] = make_float2(2.f * ym.x, -2.f * ym.y);
+            cf zk, zm;
+            irfft_merge(yk, ym, tw5[k], zk, zm);
+            if (m == 0) {
+                const cf z0 = make_float2(yk.x + yk.y, yk.x - yk.y);
+                const cf z128 = make_float2(2.f * ym.x, -2.f * ym.y);
+                Zlo[m] = lane0 ? z0 : zk;
+                Zhi[m] = lane0 ? z128 : zm;  // lane 0: Zhi[0] holds 2 Z'[128]
             } else {
-                cf Zk, Zm;
-                irfft_merge(yk, ym, tw5[k], Zk, Zm);
-                slot[k] = Zk;
-                slot[256 - k] = Zm;
+                Zlo[m] = zk;
+                Zhi[m] = zm;
             }
         }
-        __builtin_amdgcn_wave_barrier();
         // ---- inverse transform, windowed frame left in the slot ----
         {
+            // v[j] = 2 Z'[la + 16 j]: j < 8 own; j >= 8 is the mirror value the
+            // partner lane computed (lane 0: its own Zhi[16 - j], Zhi[0] for j = 8)
             cf v[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = slot[la + 16 * j];
+            for (int j = 0; j < 8; ++j) v[j] = Zlo[j];
+#pragma unroll
+            for (int j = 8; j < 16; ++j) {
+                const cf src = Zhi[15 - j];
+                const cf own = Zhi[(16 - j) & 7];
+                cf pv = make_float2(qr_partner2(src.x), qr_partner2(src.y));
+                v[j].x = lane0 ? own.x : pv.x;
+                v[j].y = lane0 ? own.y : pv.y;
+            }
             fft256_stage_a<+1>(v, slot, tw, la);
             __builtin_amdgcn_wave_barrier();
             fft256_stage_b<+1>(v, slot, la);
