@@ -459,16 +459,6 @@ __global__ __launch_bounds__(256 * NQ, NQ) void stft_covar_kernel(Pass1Args a) {
     }
 }
 
-static int p1_nq() {
-    static int nq = -1;
-    if (nq < 0) {
-        const char* e = getenv("SETK_P1_NQ");
-        nq = e ? atoi(e) : 2;
-        if (nq != 2 && nq != 4) nq = 2;
-    }
-    return nq;
-}
-
 template <int C, bool DUMP, int NQ>
 static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s) {
     constexpr int TB = tile_frames(C), NF = TB * C;
@@ -491,12 +481,12 @@ static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s)
 }
 
 hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s) {
-    const int nq = p1_nq();
+    // NQ = 2 (512 threads, 2 waves/SIMD).  NQ = 4 (1024 threads, <= 128 VGPRs)
+    // was measured 3x slower on MI355X: spills plus 4x redundant tile reads.
 #define SETK_CASE(c)                                                                      \
     case c:                                                                               \
         if (dump) return launch_pass1_t<c, true, 2>(a, n_items, s);                        \
-        return nq == 4 ? launch_pass1_t<c, false, 4>(a, n_items, s)                        \
-                       : launch_pass1_t<c, false, 2>(a, n_items, s);
+        return launch_pass1_t<c, false, 2>(a, n_items, s);
     switch (C) {
         SETK_CASE(1)
         SETK_CASE(2)

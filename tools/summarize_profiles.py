@@ -98,7 +98,7 @@ def main():
         out.append("| " + " | ".join(row) + " |")
     open(os.path.join(dst, f"{tag}_pmc_summary.md"), "w").write("\n".join(out) + "\n")
     # traffic json for bench.py
-    k1 = [k for k in kernels if "stft_covar_kernel<8, false>" in k]
+    k1 = [k for k in kernels if "stft_covar_kernel<8, false" in k]
     if k1 and traffic[k1[0]][0] is not None and traffic[k1[0]][1] is not None:
         rd, wr = traffic[k1[0]]
         json.dump({
