@@ -168,6 +168,18 @@ int setk_beamform(setk_handle_t h, const float* weight, const float* spec,
                   int num_channels, int num_frames, int num_bins, float* out,
                   void* stream);
 
+/* ---- CGMM mask estimation (BASELINE configs[4]) ---------------
+ * CgmmTrainer(obs, 2, gamma=init).train(num_iters) of
+ * scripts/sptk/libs/cluster.py:396-465 as used by estimate_cgmm_masks.py:44-64:
+ * K = 2 complex-Gaussian mixture, alpha fixed at 1/2, deterministic start
+ * (Rs = x x^H / T, Rn = I) or an initial speech mask.
+ * spec[C][T][F] complex64, init_mask[T][F] or NULL.
+ * gamma_out (may be NULL) receives the posteriors [2][T][F]; mask_out[T][F]
+ * receives gamma[0] (the speech mask the CLI saves).  1 <= C <= 8. */
+int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int num_frames,
+                    int num_bins, int num_iters, const float* init_mask, float* gamma_out,
+                    float* mask_out, void* stream);
+
 /* ---- fused hot path ------------------------------------------------------
  * The compute body of apply_adaptive_beamformer.py:130-178 for a batch of
  * utterances that share the channel count, in four kernel stages:

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsetk_hip.so")
-SOURCES = ["pass1.hip", "pass2.hip", "solve.hip", "modular.hip", "capi.hip"]
+SOURCES = ["pass1.hip", "pass2.hip", "solve.hip", "modular.hip", "cgmm.hip", "capi.hip"]
 HEADERS = ["common.h", "fft512.h", os.path.join("..", "..", "include", "setk_hip.h")]
 ARCH = "gfx950"
 

@@ -708,6 +708,51 @@ int setk_beamform(setk_handle_t h, const float* weight, const float* spec, int n
     return SETK_OK;
 }
 
+int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int num_frames,
+                    int num_bins, int num_iters, const float* init_mask, float* gamma_out,
+                    float* mask_out, void* stream) {
+    if (!h || !spec || !mask_out || num_frames <= 0 || num_bins <= 0 || num_iters < 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    if (num_channels < 1 || num_channels > kMaxChannels)
+        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h);
+    const int C = num_channels, T = num_frames, F = num_bins;
+    const float *d_spec, *d_init = nullptr;
+    int rc = stage_in(h, spec, (size_t)C * T * F * 2, s, &d_spec);
+    if (rc) return rc;
+    if (init_mask) {
+        rc = stage_in(h, init_mask, (size_t)T * F, s, &d_init);
+        if (rc) return rc;
+    }
+    OutBuf om, og;
+    rc = stage_out(h, mask_out, (size_t)T * F * 4, &om);
+    if (rc) return rc;
+    float* d_gamma;
+    if (gamma_out) {
+        rc = stage_out(h, gamma_out, (size_t)2 * T * F * 4, &og);
+        if (rc) return rc;
+        d_gamma = static_cast<float*>(og.dev);
+    } else {
+        d_gamma = static_cast<float*>(arena_alloc(h, (size_t)2 * T * F * 4));
+    }
+    float* d_phi = static_cast<float*>(arena_alloc(h, (size_t)2 * T * F * 4));
+    const size_t sb = cgmm_scratch_bytes(C, T, F);
+    void* d_scr = arena_alloc(h, sb);
+    if (!d_gamma || !d_phi || !d_scr) return fail(h, SETK_ERR_NOMEM, "arena");
+    HIP_TRY(h, launch_cgmm(C, d_spec, T, F, num_iters, d_init, d_gamma, d_phi,
+                           static_cast<float*>(om.dev), d_scr, sb, s));
+    rc = copy_back(h, om, s);
+    if (rc) return rc;
+    if (gamma_out) {
+        rc = copy_back(h, og, s);
+        if (rc) return rc;
+    }
+    if (om.host || (gamma_out && og.host)) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
 int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, int num_channels,
                        const float* const* audio, const int* num_samples,
                        const float* const* mask_s, const float* const* mask_n,

@@ -1,0 +1,348 @@
+// cgmm.hip -- CGMM (K = 2) time-frequency mask estimation by EM on the device.
+//
+// Replaces (funcwj/setk): CgmmTrainer / Cgmm / CgDistribution / Covariance in
+// scripts/sptk/libs/cluster.py:94-287, 396-465 as driven by
+// scripts/sptk/estimate_cgmm_masks.py:19-71 (K = 2, deterministic init or an
+// initial mask, alpha fixed at 1/2).
+//
+// Per EM iteration (cluster.py:193-212, 261-287), M = channels:
+//   R_k(f)   = sum_t gamma_k M / phi_k  x x^H / max(sum_t gamma_k, eps)      cgmm_accum + finalize
+//   (w, V)   = eigh(R_k);  w <- max(w / max(max w, eps), eps)                 cgmm_eig (fp64 Jacobi)
+//   phi_k    = max(|x^H R_k^-1 x|, eps) / M,  R^-1 = V diag(1/w) V^H          cgmm_estep
+//   gamma_k  = softmax_k(-M log phi_k - sum log w) with alpha = 1/2           cgmm_estep
+// The quadratic form is evaluated in the eigenbasis, sum_j |v_j^H x|^2 / w_j
+// (all terms positive), so float32 does not suffer the cancellation the dense
+// x^H R^-1 x would (1/w reaches 8e6); the reference does it in float64.
+// Spectrogram layout [C][T][F]; one wavefront handles 32 bins x 2 classes
+// (lanes 0-31 class 0, lanes 32-63 class 1), classes meet through __shfl_xor.
+#include <cstring>
+#include "common.h"
+#include "fft512.h"
+#include "../../include/setk_hip.h"
+
+namespace setk {
+
+typedef double2 zd;
+#define ZD __device__ __forceinline__
+ZD zd zd_add(zd a, zd b) { return make_double2(a.x + b.x, a.y + b.y); }
+ZD zd zd_sub(zd a, zd b) { return make_double2(a.x - b.x, a.y - b.y); }
+ZD zd zd_mul(zd a, zd b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+ZD zd zd_cmul(zd a, zd b) { return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x); }
+ZD zd zd_scale(zd a, double s) { return make_double2(a.x * s, a.y * s); }
+ZD double zd_abs2(zd a) { return a.x * a.x + a.y * a.y; }
+ZD zd zd_shfl(zd v, int src) { return make_double2(__shfl(v.x, src, 8), __shfl(v.y, src, 8)); }
+
+constexpr float kEps32 = 1.1920928955078125e-07f;
+constexpr int kCgInitId = 0, kCgInitMask = 1, kCgEm = 2;
+
+struct CgmmArgs {
+    const cf* spec;          // [C][T][F]
+    float* gamma;            // [2][T][F]
+    float* phi;              // [2][T][F]
+    const float* init_mask;  // [T][F] or null
+    float* partials;         // [nchunks][2][2*NP+1][pitch]
+    double* R;               // [2][2*NP][pitch]   re | im planes per Hermitian pair
+    cf* V;                   // [2][F][C][C]       V[j][i] = component i of eigenvector j
+    float* invw;             // [2][F][C]
+    float* logdet;           // [2][F]
+    float* mask_out;         // [T][F] or null (last E-step)
+    int T, F, pitch, nchunks, tchunk, mode;
+};
+
+// ---- M-step: weighted outer products, 32 bins x 2 classes per wavefront ----
+template <int C>
+__global__ __launch_bounds__(64) void cgmm_accum_kernel(CgmmArgs a) {
+    constexpr int NP = npairs(C);
+    const int lane = threadIdx.x;
+    const int f = blockIdx.x * 32 + (lane & 31);
+    const int k = lane >> 5;
+    const int chunk = blockIdx.y;
+    const int t0 = chunk * a.tchunk, t1 = min(a.T, t0 + a.tchunk);
+    const int T = a.T, F = a.F;
+    cf acc[NP];
+#pragma unroll
+    for (int e = 0; e < NP; ++e) acc[e] = make_float2(0.f, 0.f);
+    float sumg = 0.f;
+    if (f < F && !(a.mode == kCgInitId && k == 1)) {
+        for (int t = t0; t < t1; ++t) {
+            float w, g;
+            if (a.mode == kCgEm) {
+                g = a.gamma[((size_t)k * T + t) * F + f];
+                w = g * (float)C / a.phi[((size_t)k * T + t) * F + f];
+            } else if (a.mode == kCgInitMask) {
+                const float m = a.init_mask[(size_t)t * F + f];
+                g = (k == 0) ? m : 1.f - m;
+                w = g;
+            } else {
+                g = 1.f;
+                w = 1.f;
+            }
+            sumg += g;
+            cf x[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) x[c] = a.spec[((size_t)c * T + t) * F + f];
+            int e = 0;
+#pragma unroll
+            for (int i = 0; i < C; ++i)
+#pragma unroll
+                for (int j = i; j < C; ++j) {
+                    const cf p = cmulc(x[i], x[j]);
+                    acc[e].x = fmaf(w, p.x, acc[e].x);
+                    if (i != j) acc[e].y = fmaf(w, p.y, acc[e].y);
+                    ++e;
+                }
+        }
+    }
+    if (f < F) {
+        float* P = a.partials + ((size_t)chunk * 2 + k) * (2 * NP + 1) * a.pitch;
+#pragma unroll
+        for (int e = 0; e < NP; ++e) {
+            P[(size_t)e * a.pitch + f] = acc[e].x;
+            P[(size_t)(NP + e) * a.pitch + f] = acc[e].y;
+        }
+        P[(size_t)(2 * NP) * a.pitch + f] = sumg;
+    }
+}
+
+// sum the frame chunks in fp64, normalise (cluster.py:203-205 / 419-440)
+__global__ void cgmm_finalize_kernel(CgmmArgs a, int C) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.y, k = blockIdx.z;
+    const int NP = npairs(C);
+    if (f >= a.F) return;
+    double* out = a.R + ((size_t)k * 2 * NP + e) * a.pitch;
+    if (a.mode == kCgInitId && k == 1) {
+        // identity: diagonal pairs are the ones with i == j in the real planes
+        int idx = 0, isdiag = 0;
+        for (int i = 0; i < C && !isdiag; ++i)
+            for (int j = i; j < C; ++j) {
+                if (idx == e && i == j) isdiag = 1;
+                ++idx;
+            }
+        out[f] = isdiag ? 1.0 : 0.0;
+        return;
+    }
+    const size_t slab = (size_t)(2 * NP + 1) * a.pitch;
+    double acc = 0.0, den = 0.0;
+    for (int c = 0; c < a.nchunks; ++c) {
+        const float* P = a.partials + ((size_t)c * 2 + k) * slab;
+        acc += (double)P[(size_t)e * a.pitch + f];
+        den += (double)P[(size_t)(2 * NP) * a.pitch + f];
+    }
+    if (a.mode == kCgInitId) den = (double)a.T;
+    out[f] = acc / fmax(den, (double)kEps32);
+}
+
+// ---- eigendecomposition of R_k(f): one-sided Jacobi, 8 lanes per problem ----
+ZD int cg_partner(int r, int j) {
+    if (j == 7) return r;
+    int k = (2 * r - j) % 7;
+    if (k < 0) k += 7;
+    return (k == j) ? 7 : k;
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void cgmm_eig_kernel(CgmmArgs a) {
+    constexpr int NP = npairs(C);
+    const int tid = threadIdx.x;
+    const int j = tid & 7;
+    const int F = a.F;
+    long prob = (long)blockIdx.x * 8 + (tid >> 3);
+    const long nprob = 2L * F;
+    const bool live = prob < nprob;
+    if (!live) prob = nprob - 1;
+    const int k = (int)(prob / F), f = (int)(prob % F);
+    // column j of the Hermitian matrix
+    zd g[C], v[C];
+    const double* base = a.R + (size_t)k * 2 * NP * a.pitch + f;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        g[i] = make_double2(0.0, 0.0);
+        v[i] = make_double2((i == j) ? 1.0 : 0.0, 0.0);
+        if (j < C) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const int e = pair_index(lo, hi, C);
+            const double re = base[(size_t)e * a.pitch];
+            const double im = (i == j) ? 0.0 : base[(size_t)(NP + e) * a.pitch];
+            g[i] = make_double2(re, (i <= j) ? im : -im);
+        }
+    }
+    bool done = false;
+    for (int sweep = 0; sweep < 40 && !done; ++sweep) {
+        bool rot = false;
+        for (int r = 0; r < 7; ++r) {
+            const int p = cg_partner(r, j);
+            zd gp[C], vp[C];
+            double m = 0.0, o = 0.0;
+            zd d = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                gp[i] = zd_shfl(g[i], p);
+                vp[i] = zd_shfl(v[i], p);
+                m += zd_abs2(g[i]);
+                o += zd_abs2(gp[i]);
+                d = zd_add(d, zd_cmul(g[i], gp[i]));
+            }
+            const double dd = zd_abs2(d);
+            if (dd > 1e-26 * m * o && dd > 0.0) {
+                const double absd = sqrt(dd);
+                const double sigma = (j < p) ? 1.0 : -1.0;
+                const double zeta = sigma * (o - m) / (2.0 * absd);
+                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t);
+                const double fsc = sigma * cs * t / absd;
+                const zd ph = make_double2(d.x * fsc, -d.y * fsc);
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    g[i] = zd_sub(zd_scale(g[i], cs), zd_mul(ph, gp[i]));
+                    v[i] = zd_sub(zd_scale(v[i], cs), zd_mul(ph, vp[i]));
+                }
+                rot = true;
+            }
+        }
+        done = !__any(rot);
+    }
+    double lam2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) lam2 += zd_abs2(g[i]);
+    double lam = sqrt(lam2);
+    double lmax = lam;
+#pragma unroll
+    for (int s = 1; s < 8; s <<= 1) lmax = fmax(lmax, __shfl_xor(lmax, s, 8));
+    // cluster.py:107-113
+    double w = lam / fmax(lmax, (double)kEps32);
+    w = fmax(w, (double)kEps32);
+    double lw = (j < C) ? log(w) : 0.0;
+#pragma unroll
+    for (int s = 1; s < 8; s <<= 1) lw += __shfl_xor(lw, s, 8);
+    if (live && j < C) {
+        cf* Vd = a.V + (((size_t)k * F + f) * C + j) * C;
+#pragma unroll
+        for (int i = 0; i < C; ++i) Vd[i] = make_float2((float)v[i].x, (float)v[i].y);
+        a.invw[((size_t)k * F + f) * C + j] = (float)(1.0 / w);
+        if (j == 0) a.logdet[(size_t)k * F + f] = (float)lw;
+    }
+}
+
+// ---- E-step: phi, posterior gamma (cluster.py:207-212, 214-235, 261-287) ----
+template <int C>
+__global__ __launch_bounds__(64) void cgmm_estep_kernel(CgmmArgs a) {
+    const int lane = threadIdx.x;
+    const int f = blockIdx.x * 32 + (lane & 31);
+    const int k = lane >> 5;
+    const int chunk = blockIdx.y;
+    const int t0 = chunk * a.tchunk, t1 = min(a.T, t0 + a.tchunk);
+    const int T = a.T, F = a.F;
+    const bool ok = f < F;
+    const int fc = ok ? f : F - 1;
+    cf Vr[C][C];
+    float iw[C];
+    const cf* Vd = a.V + ((size_t)k * F + fc) * C * C;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        iw[j] = a.invw[((size_t)k * F + fc) * C + j];
+#pragma unroll
+        for (int i = 0; i < C; ++i) Vr[j][i] = Vd[j * C + i];
+    }
+    const float ld = a.logdet[(size_t)k * F + fc];
+    for (int t = t0; t < t1; ++t) {
+        cf x[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[c] = a.spec[((size_t)c * T + t) * F + fc];
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            cf pr = make_float2(0.f, 0.f);  // v_j^H x
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                pr.x += Vr[j][i].x * x[i].x + Vr[j][i].y * x[i].y;
+                pr.y += Vr[j][i].x * x[i].y - Vr[j][i].y * x[i].x;
+            }
+            q = fmaf(iw[j], pr.x * pr.x + pr.y * pr.y, q);
+        }
+        const float ph = fmaxf(q, kEps32) / (float)C;
+        const float lp = -(float)C * logf(ph) - ld;
+        const float lo = __shfl_xor(lp, 32);
+        const float mx = fmaxf(lp, lo);
+        const float mine = 0.5f * expf(lp - mx), other = 0.5f * expf(lo - mx);
+        const float g = mine / fmaxf(mine + other, kEps32);
+        if (ok) {
+            a.phi[((size_t)k * T + t) * F + f] = ph;
+            a.gamma[((size_t)k * T + t) * F + f] = g;
+            if (a.mask_out && k == 0) a.mask_out[(size_t)t * F + f] = g;
+        }
+    }
+}
+
+template <int C>
+static hipError_t cgmm_run_t(CgmmArgs a, int num_iters, hipStream_t s) {
+    const int NP = npairs(C);
+    dim3 g_tf((a.F + 31) / 32, a.nchunks);
+    dim3 g_fin((a.F + 255) / 256, 2 * NP, 2);
+    const int eig_blocks = (2 * a.F + 7) / 8;
+    float* mask_out = a.mask_out;
+    a.mask_out = nullptr;
+    a.mode = a.init_mask ? kCgInitMask : kCgInitId;
+    for (int it = 0; it <= num_iters; ++it) {
+        hipLaunchKernelGGL(cgmm_accum_kernel<C>, g_tf, dim3(64), 0, s, a);
+        hipLaunchKernelGGL(cgmm_finalize_kernel, g_fin, dim3(256), 0, s, a, C);
+        hipLaunchKernelGGL(cgmm_eig_kernel<C>, dim3(eig_blocks), dim3(64), 0, s, a);
+        if (it == num_iters) a.mask_out = mask_out;
+        hipLaunchKernelGGL(cgmm_estep_kernel<C>, g_tf, dim3(64), 0, s, a);
+        a.mode = kCgEm;
+    }
+    return hipGetLastError();
+}
+
+// scratch floats needed besides gamma/phi (host computes the arena layout)
+hipError_t launch_cgmm(int C, const float* spec, int T, int F, int num_iters,
+                       const float* init_mask, float* gamma, float* phi, float* mask_out,
+                       void* scratch, size_t scratch_bytes, hipStream_t s) {
+    const int NP = npairs(C);
+    CgmmArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.spec = reinterpret_cast<const cf*>(spec);
+    a.gamma = gamma;
+    a.phi = phi;
+    a.init_mask = init_mask;
+    a.mask_out = mask_out;
+    a.T = T;
+    a.F = F;
+    a.pitch = ((F + 7) / 8) * 8;
+    a.tchunk = 64;
+    a.nchunks = (T + a.tchunk - 1) / a.tchunk;
+    char* p = static_cast<char*>(scratch);
+    auto take = [&](size_t bytes) {
+        char* r = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return r;
+    };
+    a.partials = reinterpret_cast<float*>(take((size_t)a.nchunks * 2 * (2 * NP + 1) * a.pitch * 4));
+    a.R = reinterpret_cast<double*>(take((size_t)2 * 2 * NP * a.pitch * 8));
+    a.V = reinterpret_cast<cf*>(take((size_t)2 * F * C * C * 8));
+    a.invw = reinterpret_cast<float*>(take((size_t)2 * F * C * 4));
+    a.logdet = reinterpret_cast<float*>(take((size_t)2 * F * 4));
+    if ((size_t)(p - static_cast<char*>(scratch)) > scratch_bytes) return hipErrorInvalidValue;
+    switch (C) {
+        case 1: return cgmm_run_t<1>(a, num_iters, s);
+        case 2: return cgmm_run_t<2>(a, num_iters, s);
+        case 3: return cgmm_run_t<3>(a, num_iters, s);
+        case 4: return cgmm_run_t<4>(a, num_iters, s);
+        case 5: return cgmm_run_t<5>(a, num_iters, s);
+        case 6: return cgmm_run_t<6>(a, num_iters, s);
+        case 7: return cgmm_run_t<7>(a, num_iters, s);
+        case 8: return cgmm_run_t<8>(a, num_iters, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+size_t cgmm_scratch_bytes(int C, int T, int F) {
+    const int NP = npairs(C);
+    const size_t pitch = ((F + 7) / 8) * 8;
+    const size_t nchunks = (T + 63) / 64;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return al(nchunks * 2 * (2 * NP + 1) * pitch * 4) + al((size_t)2 * 2 * NP * pitch * 8) +
+           al((size_t)2 * F * C * C * 8) + al((size_t)2 * F * C * 4) + al((size_t)2 * F * 4) + 1024;
+}
+
+}  // namespace setk

@@ -126,6 +126,10 @@ hipError_t launch_covar_spec_finalize(int C, const float* partials, int nparts, 
 hipError_t launch_pack_covar(const float* fcc, int F, int C, float* planes, int plane0,
                              hipStream_t s);
 hipError_t launch_unpack_weight(const float* wplanes, int F, int C, float* w_fc, hipStream_t s);
+hipError_t launch_cgmm(int C, const float* spec, int T, int F, int num_iters,
+                       const float* init_mask, float* gamma, float* phi, float* mask_out,
+                       void* scratch, size_t scratch_bytes, hipStream_t s);
+size_t cgmm_scratch_bytes(int C, int T, int F);
 hipError_t launch_ban(const float* w, const float* Rn, int F, int C, float* out, hipStream_t s);
 hipError_t launch_rank1(const float* pv, const float* Rs, const float* Rn, int F, int C,
                         float* out, hipStream_t s);

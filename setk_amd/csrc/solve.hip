@@ -131,10 +131,19 @@ SD void fix_gauge(cd (&v)[C]) {
 }
 
 // Cooperative Cholesky M = L L^H in LDS (column-major C x C, lane j = row j).
-// Returns 0 on success, 1 when a pivot is not positive.
+// The reference solves these systems with LAPACK's pivoted LU, which fails only
+// on an exactly zero pivot: a numerically semi-definite covariance (noise mask
+// non-zero in fewer than C frames) is factored with rounding noise as pivots
+// and the utterance is NOT skipped.  To keep that behaviour, pivots are floored
+// at eps_f32 * max diag(M) (the noise level of the float32-accumulated input);
+// only an all-zero / non-finite / negative-diagonal matrix reports 1.
 template <int C>
 SD int chol_lds(const cd* M, cd* L, double* piv, int j) {
-    int bad = 0;
+    double scale = (j < C) ? M[j * C + j].x : 0.0;
+#pragma unroll
+    for (int s = 1; s < 8; s <<= 1) scale = fmax(scale, __shfl_xor(scale, s, 8));
+    int bad = !(scale > 0.0);
+    const double floor_piv = kEpsF32 * scale;
 #pragma unroll
     for (int k = 0; k < C; ++k) {
         cd s = make_double2(0.0, 0.0);
@@ -144,8 +153,9 @@ SD int chol_lds(const cd* M, cd* L, double* piv, int j) {
         }
         if (j == k) *piv = s.x;
         __syncthreads();
-        const double d = *piv;
-        if (!(d > 0.0)) bad = 1;
+        double d = *piv;
+        if (!(d == d)) bad = 1;  // NaN
+        d = fmax(d, floor_piv);
         const double rd = (d > 0.0) ? 1.0 / sqrt(d) : 0.0;
         if (j >= k && j < C) L[k * C + j] = (j == k) ? make_double2(d * rd, 0.0) : zscale(s, rd);
         __syncthreads();

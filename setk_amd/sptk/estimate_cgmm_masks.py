@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""
+Speech / noise mask estimation with the CGMM model on the MI355X.
+
+Drop-in for funcwj/setk ``scripts/sptk/estimate_cgmm_masks.py`` (same
+positional arguments, options, defaults, outputs {dst_dir}/{key}.npy float32
+T x F, skip-if-exists behaviour :38).  --num-classes other than 2,
+--solve-permu and --update-alpha are outside the implemented path.
+"""
+import argparse
+from pathlib import Path
+
+import numpy as np
+
+from setk_amd import _ffi
+from setk_amd.dist import Shard
+from setk_amd.libs.cluster import CgmmTrainer
+from setk_amd.libs.data_handler import NumpyReader, NumpyWriter, ScriptReader, SpectrogramReader
+from setk_amd.libs.opts import StftParser, strtobool
+from setk_amd.libs.utils import get_logger
+
+logger = get_logger(__name__)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(
+        description="Speech & Noise mask estimation using CGMM model",
+        formatter_class=argparse.ArgumentDefaultsHelpFormatter, parents=[StftParser.parser])
+    parser.add_argument("wav_scp", type=str, help="Multi-channel wave scripts in kaldi format")
+    parser.add_argument("dst_dir", type=str, help="Location to dump estimated speech masks")
+    parser.add_argument("--num-iters", type=int, default=20,
+                        help="Number of iterations to train CGMM parameters")
+    parser.add_argument("--num-classes", type=int, default=2, help="Number of the cluster")
+    parser.add_argument("--seed", type=int, default=777, help="Random seed for initialization")
+    parser.add_argument("--init-mask", type=str, default="", dest="init_mask",
+                        help="Initial TF-mask for cgmm initialization")
+    parser.add_argument("--solve-permu", type=strtobool, default=False,
+                        help="If true, solving permutation problems")
+    parser.add_argument("--update-alpha", type=strtobool, default=False,
+                        help="If true, update alpha in M-step")
+    parser.add_argument("--mask-format", type=str, dest="fmt", default="numpy",
+                        choices=["kaldi", "numpy"], help="Mask storage format")
+    return parser
+
+
+def run(args):
+    if args.num_classes != 2 or args.solve_permu or args.update_alpha:
+        raise _ffi.SetkUnsupported("only --num-classes 2 without --solve-permu/--update-alpha")
+    stft_kwargs = dict(frame_len=args.frame_len, frame_hop=args.frame_hop,
+                       round_power_of_two=args.round_power_of_two, window=args.window,
+                       center=args.center, transpose=False)
+    shard = Shard()
+    reader = SpectrogramReader(args.wav_scp, **stft_kwargs)
+    MaskReader = {"numpy": NumpyReader, "kaldi": ScriptReader}
+    init_reader = MaskReader[args.fmt](args.init_mask) if args.init_mask else None
+    num_done = 0
+    with NumpyWriter(args.dst_dir) as writer:
+        dst_dir = Path(args.dst_dir)
+        for key in shard.assign(reader.index_keys):
+            if (dst_dir / f"{key}.npy").exists():
+                logger.info(f"Training utterance {key} ... Skip")
+                continue
+            stft = reader[key]
+            if stft.ndim == 2:
+                stft = stft[None]
+            init_mask = None
+            if init_reader and key in init_reader:
+                init_mask = np.transpose(init_reader[key])  # T x F -> F x T
+                logger.info("Using external TF-mask to initialize cgmm")
+            trainer = CgmmTrainer(stft, args.num_classes, gamma=init_mask)
+            masks = np.transpose(trainer.train(args.num_iters), (0, 2, 1))  # K x T x F
+            num_done += 1
+            writer.write(key, masks[0].astype(np.float32))
+            logger.info(f"Training utterance {key} ... Done")
+    shard.barrier()
+    if shard.world > 1:
+        num_done = int(round(shard.sum_counts([num_done])[0]))
+    if shard.rank == 0:
+        logger.info(f"Train {num_done:d} utterances over {len(reader):d}")
+    shard.close()
+
+
+def main(argv=None):
+    run(build_parser().parse_args(argv))
+
+
+if __name__ == "__main__":
+    main()
