@@ -40,6 +40,7 @@ struct setk_context {
     float* d_winsq = nullptr;   // [n_fft]
     float2* d_tw256 = nullptr;  // [256]
     float2* d_tw512 = nullptr;  // [129]
+    float2* d_twn = nullptr;    // [n_fft / 2] exp(-2 pi i k / n_fft), generic kernels
     // device arena (bump allocated per call, blocks reused across calls)
     std::vector<Block> blocks;
     // descriptor cache of the fused path
@@ -256,6 +257,7 @@ int setk_destroy(setk_handle_t h) {
     if (h->d_winsq) (void)hipFree(h->d_winsq);
     if (h->d_tw256) (void)hipFree(h->d_tw256);
     if (h->d_tw512) (void)hipFree(h->d_tw512);
+    if (h->d_twn) (void)hipFree(h->d_twn);
     if (h->d_desc) (void)hipFree(h->d_desc);
     for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
     for (auto& e : h->ev_used) (void)hipEventDestroy(e);
@@ -329,6 +331,17 @@ int setk_stft_plan(setk_handle_t h, int frame_len, int frame_hop, int n_fft, int
     HIP_TRY(h, hipMemcpy(h->d_winsq, w2.data(), n_fft * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_tw256, t256.data(), 256 * sizeof(float2), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_tw512, t512.data(), 129 * sizeof(float2), hipMemcpyHostToDevice));
+    {
+        std::vector<float2> tn(n_fft / 2);
+        for (int k = 0; k < n_fft / 2; ++k) {
+            const double ang = -2.0 * kPi * (double)k / (double)n_fft;
+            tn[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+        if (h->d_twn) (void)hipFree(h->d_twn);
+        h->d_twn = nullptr;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_twn), tn.size() * sizeof(float2)));
+        HIP_TRY(h, hipMemcpy(h->d_twn, tn.data(), tn.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
     h->frame_len = frame_len;
     h->hop = frame_hop;
     h->n_fft = n_fft;
@@ -355,9 +368,78 @@ int setk_istft_num_samples(setk_handle_t h, int num_frames, int nsamps) {
     return h->center ? h->hop * (num_frames - 1) : h->n_fft + h->hop * (num_frames - 1);
 }
 
+// n_fft != 512: generic LDS radix-2 kernels (modular.hip)
+static int stft_generic(setk_handle_t h, const float* audio, int C, int N, float* spec,
+                        hipStream_t s) {
+    const int T = setk_stft_num_frames(h, N);
+    if (T < 0) return T;
+    const int F = h->n_fft / 2 + 1;
+    arena_reset(h);
+    const float* d_audio;
+    int rc = stage_in(h, audio, (size_t)C * N, s, &d_audio);
+    if (rc) return rc;
+    OutBuf ob;
+    rc = stage_out(h, spec, (size_t)C * T * F * sizeof(float2), &ob);
+    if (rc) return rc;
+    HIP_TRY(h, launch_stft_generic(d_audio, C, N, T, h->n_fft, h->hop, h->center ? h->n_fft / 2 : 0,
+                                   h->d_window, reinterpret_cast<const float*>(h->d_twn),
+                                   static_cast<float*>(ob.dev), s));
+    rc = copy_back(h, ob, s);
+    if (rc) return rc;
+    if (ob.host) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
+static int istft_generic(setk_handle_t h, const float* spec, int B, int T, int nsamps,
+                         const float* norm, float* wave, hipStream_t s) {
+    const int F = h->n_fft / 2 + 1;
+    const int L = setk_istft_num_samples(h, T, nsamps);
+    int T_eff = T;
+    if (nsamps >= 0) {
+        const long padded = (long)nsamps + (h->center ? h->n_fft : 0);
+        T_eff = (int)std::max<long>(1, std::min<long>(T, (padded + h->hop - 1) / h->hop));
+    }
+    arena_reset(h);
+    const float* d_spec;
+    int rc = stage_in(h, spec, (size_t)B * T * F * 2, s, &d_spec);
+    if (rc) return rc;
+    OutBuf ob;
+    rc = stage_out(h, wave, (size_t)B * L * sizeof(float), &ob);
+    if (rc) return rc;
+    std::vector<float> hn(B, -1.f);
+    if (norm) {
+        if (is_device_ptr(norm))
+            HIP_TRY(h, hipMemcpy(hn.data(), norm, B * sizeof(float), hipMemcpyDeviceToHost));
+        else
+            memcpy(hn.data(), norm, B * sizeof(float));
+    }
+    void* d_norm;
+    rc = upload(h, hn.data(), B * sizeof(float), s, &d_norm);
+    if (rc) return rc;
+    float* d_frames = static_cast<float*>(arena_alloc(h, (size_t)B * T * h->n_fft * 4));
+    unsigned* d_omax = static_cast<unsigned*>(arena_alloc(h, (size_t)B * 4));
+    if (!d_frames || !d_omax) return fail(h, SETK_ERR_NOMEM, "arena");
+    HIP_TRY(h, hipMemsetAsync(d_omax, 0, (size_t)B * 4, s));
+    // the frames kernel indexes spec with the caller's T; only T_eff frames are overlap-added
+    HIP_TRY(h, launch_istft_generic(d_spec, B, T, h->n_fft, h->hop, h->center ? h->n_fft / 2 : 0, L,
+                                    h->d_window, h->d_winsq,
+                                    reinterpret_cast<const float*>(h->d_twn), d_frames,
+                                    static_cast<float*>(ob.dev), d_omax,
+                                    norm ? static_cast<const float*>(d_norm) : nullptr, T_eff, s));
+    rc = copy_back(h, ob, s);
+    if (rc) return rc;
+    if (ob.host) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
 int setk_stft(setk_handle_t h, const float* audio, int num_channels, int num_samples,
               float* spec, void* stream) {
     if (!h || !audio || !spec || num_channels <= 0) return fail(h, SETK_ERR_INVALID, "bad args");
+    if (h->planned && h->n_fft != kNfft) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        return stft_generic(h, audio, num_channels, num_samples, spec,
+                            static_cast<hipStream_t>(stream));
+    }
     int rc = require_plan512(h);
     if (rc) return rc;
     const int T = setk_stft_num_frames(h, num_samples);
@@ -408,6 +490,11 @@ int setk_istft(setk_handle_t h, const float* spec, int batch, int num_frames, in
                const float* norm, float* wave, void* stream) {
     if (!h || !spec || !wave || batch <= 0 || num_frames <= 0)
         return fail(h, SETK_ERR_INVALID, "bad args");
+    if (h->planned && h->n_fft != kNfft) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        return istft_generic(h, spec, batch, num_frames, nsamps, norm, wave,
+                             static_cast<hipStream_t>(stream));
+    }
     int rc = require_plan512(h);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -126,6 +126,13 @@ hipError_t launch_covar_spec_finalize(int C, const float* partials, int nparts, 
 hipError_t launch_pack_covar(const float* fcc, int F, int C, float* planes, int plane0,
                              hipStream_t s);
 hipError_t launch_unpack_weight(const float* wplanes, int F, int C, float* w_fc, hipStream_t s);
+hipError_t launch_stft_generic(const float* audio, int C, int n_samp, int T, int n_fft, int hop,
+                               int pad, const float* window, const float* tw, float* spec,
+                               hipStream_t s);
+hipError_t launch_istft_generic(const float* spec, int B, int T, int n_fft, int hop, int pad,
+                                int out_len, const float* window, const float* winsq,
+                                const float* tw, float* frames, float* wave, unsigned* outmax,
+                                const float* norm, int T_eff, hipStream_t s);
 hipError_t launch_cgmm(int C, const float* spec, int T, int F, int num_iters,
                        const float* init_mask, float* gamma, float* phi, float* mask_out,
                        void* scratch, size_t scratch_bytes, hipStream_t s);

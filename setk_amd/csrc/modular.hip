@@ -111,3 +111,169 @@ hipError_t launch_covar_spec_finalize(int C, const float* partials, int nparts, 
 }
 
 }  // namespace setk
+
+// ---------------------------------------------------------------------------
+// Generic power-of-two STFT / iSTFT (n_fft in [64, 4096], != 512): one
+// workgroup per (channel | batch item, frame), iterative radix-2 in LDS.
+// Simple and bandwidth-unfriendly on purpose: the n_fft = 512 kernels are the
+// hot path, these keep the python API (library default frame_len = 1024) whole.
+// ---------------------------------------------------------------------------
+namespace setk {
+
+SETK_DEV int reflect_idx_g(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// in-place radix-2 DIT on bit-reversed input; tw[k] = exp(-2 pi i k / n), k < n/2
+template <int DIR>
+SETK_DEV void fft_radix2_lds(cf* buf, const cf* tw, int n, int logn) {
+    for (int s = 1; s <= logn; ++s) {
+        const int half = 1 << (s - 1);
+        const int stride = n >> s;  // twiddle step
+        __syncthreads();
+        for (int b = threadIdx.x; b < n / 2; b += blockDim.x) {
+            const int grp = b / half, pos = b - grp * half;
+            const int i0 = grp * 2 * half + pos, i1 = i0 + half;
+            cf w = tw[pos * stride];
+            if (DIR > 0) w.y = -w.y;
+            const cf u = buf[i0];
+            const cf t = cmul(buf[i1], w);
+            buf[i0] = cadd(u, t);
+            buf[i1] = csub(u, t);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void stft_generic_kernel(const float* __restrict__ audio,
+                                                           int n_samp, int T, int n_fft, int logn,
+                                                           int hop, int pad,
+                                                           const float* __restrict__ window,
+                                                           const cf* __restrict__ twg,
+                                                           cf* __restrict__ spec) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    cf* buf = reinterpret_cast<cf*>(gsm);  // [n_fft]
+    cf* tw = buf + n_fft;                  // [n_fft / 2]
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int F = n_fft / 2 + 1;
+    const float* x = audio + (size_t)c * n_samp;
+    const int s0 = t * hop - pad;
+    for (int i = threadIdx.x; i < n_fft / 2; i += blockDim.x) tw[i] = twg[i];
+    for (int i = threadIdx.x; i < n_fft; i += blockDim.x) {
+        const int r = (int)(__brev((unsigned)i) >> (32 - logn));
+        // window[i] is the 0.5-scaled table (see capi.hip): undo the 1/2 here
+        buf[r] = make_float2(2.f * window[i] * x[reflect_idx_g(s0 + i, n_samp)], 0.f);
+    }
+    fft_radix2_lds<-1>(buf, tw, n_fft, logn);
+    cf* out = spec + ((size_t)c * T + t) * F;
+    for (int k = threadIdx.x; k < F; k += blockDim.x) out[k] = buf[k];
+}
+
+// spec[b][t][F] -> windowed time frames[b][t][n_fft]
+__global__ __launch_bounds__(256) void istft_frames_kernel(const cf* __restrict__ spec, int T,
+                                                           int n_fft, int logn,
+                                                           const float* __restrict__ window,
+                                                           const cf* __restrict__ twg,
+                                                           float* __restrict__ frames) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    cf* buf = reinterpret_cast<cf*>(gsm);
+    cf* tw = buf + n_fft;
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int F = n_fft / 2 + 1;
+    const cf* in = spec + ((size_t)b * T + t) * F;
+    for (int i = threadIdx.x; i < n_fft / 2; i += blockDim.x) tw[i] = twg[i];
+    for (int i = threadIdx.x; i < n_fft; i += blockDim.x) {
+        const int r = (int)(__brev((unsigned)i) >> (32 - logn));
+        cf v;
+        if (i < F) {
+            v = in[i];
+            if (i == 0 || i == n_fft / 2) v.y = 0.f;  // numpy irfft drops these
+        } else {
+            const cf m = in[n_fft - i];
+            v = make_float2(m.x, -m.y);
+        }
+        buf[r] = v;
+    }
+    fft_radix2_lds<+1>(buf, tw, n_fft, logn);
+    float* out = frames + ((size_t)b * T + t) * n_fft;
+    const float sc = 2.f / (float)n_fft;  // window table is 0.5-scaled
+    for (int i = threadIdx.x; i < n_fft; i += blockDim.x) out[i] = buf[i].x * sc * window[i];
+}
+
+// overlap-add, / sum(window^2) where > tiny, centre trim, max |y|
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames,
+                                                        int t_stride, int T, int n_fft, int hop,
+                                                        int pad, int out_len,
+                                                        const float* __restrict__ winsq,
+                                                        float* __restrict__ wave,
+                                                        unsigned* __restrict__ outmax) {
+    const int b = blockIdx.y;
+    float mx = 0.f;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < out_len; o += gridDim.x * 256) {
+        const int n = o + pad;
+        float v = 0.f, wss = 0.f;
+        if (n < n_fft + hop * (T - 1)) {
+            const int t_hi = min(n / hop, T - 1);
+            const int t_lo = (n < n_fft) ? 0 : (n - n_fft) / hop + 1;
+            for (int t = t_lo; t <= t_hi; ++t) {
+                const int off = n - t * hop;
+                v += frames[((size_t)b * t_stride + t) * n_fft + off];
+                wss += winsq[off];
+            }
+            if (wss > 1.17549435e-38f) v /= wss;
+        }
+        wave[(size_t)b * out_len + o] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+    if ((threadIdx.x & 63) == 0) atomicMax(outmax + b, __float_as_uint(mx));
+}
+
+// wave[b] *= norm[b] / (max|wave[b]| + eps) where norm[b] > 0
+__global__ void istft_scale_kernel(float* __restrict__ wave, int out_len,
+                                   const float* __restrict__ norm,
+                                   const unsigned* __restrict__ outmax) {
+    const int b = blockIdx.y;
+    const float nv = norm[b];
+    if (!(nv > 0.f)) return;
+    const float sc = nv / (__uint_as_float(outmax[b]) + 1.1920928955078125e-07f);
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < out_len; o += gridDim.x * 256)
+        wave[(size_t)b * out_len + o] *= sc;
+}
+
+hipError_t launch_stft_generic(const float* audio, int C, int n_samp, int T, int n_fft, int hop,
+                               int pad, const float* window, const float* tw, float* spec,
+                               hipStream_t s) {
+    int logn = 0;
+    while ((1 << logn) < n_fft) ++logn;
+    const size_t lds = (size_t)n_fft * sizeof(cf) + (size_t)(n_fft / 2) * sizeof(cf);
+    hipLaunchKernelGGL(stft_generic_kernel, dim3(T, C), dim3(256), lds, s, audio, n_samp, T, n_fft,
+                       logn, hop, pad, window, reinterpret_cast<const cf*>(tw),
+                       reinterpret_cast<cf*>(spec));
+    return hipGetLastError();
+}
+
+hipError_t launch_istft_generic(const float* spec, int B, int T, int n_fft, int hop, int pad,
+                                int out_len, const float* window, const float* winsq,
+                                const float* tw, float* frames, float* wave, unsigned* outmax,
+                                const float* norm, int T_eff, hipStream_t s) {
+    int logn = 0;
+    while ((1 << logn) < n_fft) ++logn;
+    const size_t lds = (size_t)n_fft * sizeof(cf) + (size_t)(n_fft / 2) * sizeof(cf);
+    hipLaunchKernelGGL(istft_frames_kernel, dim3(T_eff, B), dim3(256), lds, s,
+                       reinterpret_cast<const cf*>(spec), T, n_fft, logn, window,
+                       reinterpret_cast<const cf*>(tw), frames);
+    int bx = (out_len + 256 * 4 - 1) / (256 * 4);
+    bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
+    hipLaunchKernelGGL(istft_ola_kernel, dim3(bx, B), dim3(256), 0, s, frames, T, T_eff, n_fft, hop, pad,
+                       out_len, winsq, wave, outmax);
+    if (norm)
+        hipLaunchKernelGGL(istft_scale_kernel, dim3(bx, B), dim3(256), 0, s, wave, out_len, norm,
+                           outmax);
+    return hipGetLastError();
+}
+
+}  // namespace setk

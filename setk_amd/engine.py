@@ -115,7 +115,66 @@ class BatchEnhancer(object):
                 self._run(utts, batch, C, has_itf, results)
         return results
 
+    def _run_unfused(self, utts, batch, C, has_itf, results):
+        """n_fft != 512: the same stages through the stand-alone operators
+        (setk_stft -> setk_covar x2 -> setk_weights -> setk_beamform -> setk_istft),
+        everything resident on the device, one utterance at a time."""
+        torch, ctx, dev, F = self.torch, self.ctx, self.dev, self.num_bins
+        mpdr = self.opts_kw["kind"] in (_ffi.BF_MPDR, _ffi.BF_MPDR_WHITEN)
+        for i in batch:
+            samps, mask, itf = utts[i]
+            samps = np.ascontiguousarray(samps, dtype=np.float32)
+            if samps.ndim == 1:
+                samps = samps[None]
+            N = samps.shape[1]
+            T = ctx.num_frames(N)
+            mask = self.condition_mask(mask, T)
+            if has_itf:
+                itf = self.condition_mask(itf, T)
+            else:
+                mask = np.minimum(mask, 1)
+            a = torch.from_numpy(samps).to(dev)
+            spec = torch.empty((C, T, F), dtype=torch.complex64, device=dev)
+            ctx.stft(a, spec)
+            if 0.5 < self.vad_proportion < 1:
+                vad, _ = compute_vad_masks(spec[0].cpu().numpy().T, self.vad_proportion)
+                mask = np.where(vad, 1.0e-4, mask)
+                if has_itf:
+                    itf = np.where(vad, 1.0e-4, itf)
+            ms = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.float32)).to(dev)
+            mn = torch.from_numpy(np.ascontiguousarray(itf, dtype=np.float32)).to(dev) \
+                if has_itf else (1 - ms).contiguous()
+            Rs = torch.empty((F, C, C), dtype=torch.complex64, device=dev)
+            Rn = torch.empty_like(Rs)
+            ctx.covar(spec, mn, C, T, F, Rn)
+            ctx.covar(spec, ms, C, T, F, Rs)
+            Ry = None
+            if mpdr:
+                Ry = torch.empty_like(Rs)
+                ctx.covar(spec, torch.ones_like(ms), C, T, F, Ry)
+            w = torch.empty((F, C), dtype=torch.complex64, device=dev)
+            status = np.zeros(F, dtype=np.int32)
+            flags = self.base_flags & _ffi.FLAG_BAN
+            ctx.weights(_ffi.BfOpts(flags=flags, **self.opts_kw), Rs, Rn, Ry, F, C, w, status)
+            if status.any():
+                results[i] = (None, int(status.max()))
+                continue
+            enh = torch.empty((T, F), dtype=torch.complex64, device=dev)
+            ctx.beamform(w, spec, C, T, F, enh)
+            if self.base_flags & _ffi.FLAG_POST_MASK:
+                enh = (enh * ms).contiguous()
+            L = ctx.istft_num_samples(T)
+            wave = torch.empty((1, L), dtype=torch.float32, device=dev)
+            norm = a.abs().max().reshape(1).contiguous()
+            ctx.istft(enh.reshape(1, T, F), 1, T, None, norm, wave)
+            out = wave[0]
+            if self.pcm16:
+                out = torch.round(out * 32767.0).to(torch.int16)
+            results[i] = (out.cpu().numpy(), 0)
+
     def _run(self, utts, batch, C, has_itf, results):
+        if self.stft["n_fft"] != 512:
+            return self._run_unfused(utts, batch, C, has_itf, results)
         torch, ctx, dev = self.torch, self.ctx, self.dev
         audio, masks, itfs, waves, ns = [], [], [], [], []
         flags = self.base_flags | (0 if has_itf else _ffi.FLAG_CLAMP_MASK)

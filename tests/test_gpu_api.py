@@ -27,10 +27,6 @@ def test_forward_inverse_stft_mirror():
         x = g[f"{name}.x"]
         n_fft = o.nextpow2(fl) if rp2 else fl
         kw = dict(frame_len=fl, frame_hop=hop, center=center, window=window)
-        if n_fft != 512:
-            with pytest.raises(_ffi.SetkUnsupported):
-                utils.forward_stft(x, round_power_of_two=rp2, transpose=False, **kw)
-            continue
         S = utils.forward_stft(x, round_power_of_two=rp2, transpose=False, **kw)
         ref = g[f"{name}.S"]
         assert S.shape == ref.shape and S.dtype == np.complex64
@@ -46,6 +42,25 @@ def test_forward_inverse_stft_mirror():
         assert rms(yn, g[f"{name}.y_norm"]) < tol, name
     with pytest.raises(RuntimeError):
         utils.forward_stft(np.zeros((2, 4000), np.float32), frame_len=512)
+    # n_fft that is not a power of two has no kernel (round_power_of_two=False, frame_len 400)
+    with pytest.raises(_ffi.SetkUnsupported):
+        utils.forward_stft(np.zeros(4000, np.float32), frame_len=400, round_power_of_two=False)
+
+
+@pytest.mark.parametrize("frame_len,hop", [(1024, 256), (256, 64), (2048, 512), (400, 160)])
+def test_enhance_other_fft_sizes(frame_len, hop):
+    """n_fft != 512 runs through the stand-alone operators (generic radix-2 FFT)."""
+    from setk_amd.engine import BatchEnhancer
+    mix, sp, nz = o.synth_utterance(90, 4, 24000, return_parts=True)
+    kw = dict(frame_len=frame_len, frame_hop=hop, center=True, window="hann")
+    mask = o.irm_mask(sp, nz, frame_len=frame_len, frame_hop=hop)
+    for kind in ("mvdr", "pmwf-0", "gevd"):
+        eng = BatchEnhancer(beamformer=kind, **kw)
+        (wav, st), = eng.enhance([(mix, mask, None)])
+        assert st == 0
+        ref = o.enhance_utterance(mix, mask, kind=kind, gauge=True, **kw)
+        assert wav.shape == ref.shape
+        assert rms(wav, ref) / rms(ref) < 1e-3, (frame_len, kind)
 
 
 def test_config0_roundtrip_on_device():

@@ -55,12 +55,13 @@ def test_stft_goldens(ctx):
     g = load_golden("ref_stft.npz")
     for name, N, fl, hop, center, rp2, window in mg.STFT_CASES:
         n_fft = o.nextpow2(fl) if rp2 else fl
-        if n_fft != 512:
-            continue
         win = o.make_window(window, fl).astype(np.float32)
         ctx.stft_plan(fl, hop, n_fft, center, win)
         x = g[f"{name}.x"]
-        got = gpu_stft(ctx, x[None])[0]
+        T = ctx.num_frames(x.shape[0])
+        got = np.empty((1, T, n_fft // 2 + 1), dtype=np.complex64)
+        ctx.stft(np.ascontiguousarray(x[None]), got)
+        got = got[0]
         ref = g[f"{name}.S"].T
         assert got.shape == ref.shape, name
         assert rel_rms(got, ref) < 1e-4, name
