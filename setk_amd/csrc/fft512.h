@@ -82,8 +82,10 @@ SETK_DEV void dft16(cf (&v)[16]) {
 // Stage A: lane `la` holds v[j] = z[la + 16 j].  Radix-16 over j, twiddle by
 // W256^{la q}, store transposed into the 256-entry LDS slot (XOR swizzle).
 // tw: LDS table tw[q*16 + la] = exp(-2 pi i la q / 256).
+// `la` may carry a swizzle bit: callers pass la ^ (quad-row & 1) as `ls` so that
+// the two quad-rows sharing a 32-lane ds_read_b64 group hit complementary banks.
 template <int DIR>
-SETK_DEV void fft256_stage_a(cf (&v)[16], cf* slot, const cf* tw, int la) {
+SETK_DEV void fft256_stage_a(cf (&v)[16], cf* slot, const cf* tw, int la, int ls) {
     dft16<DIR>(v);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -93,16 +95,16 @@ SETK_DEV void fft256_stage_a(cf (&v)[16], cf* slot, const cf* tw, int la) {
             if (DIR > 0) w.y = -w.y;
             t = cmul(t, w);
         }
-        slot[q * 16 + (la ^ q)] = t;
+        slot[q * 16 + (ls ^ q)] = t;
     }
 }
 
 // Stage B (after a barrier): lane `la` gathers sub-transform `la`, radix-16,
 // leaves Z[la + 16 kb] in v[dft16_pos(kb)].
 template <int DIR>
-SETK_DEV void fft256_stage_b(cf (&v)[16], const cf* slot, int la) {
+SETK_DEV void fft256_stage_b(cf (&v)[16], const cf* slot, int la, int ls) {
 #pragma unroll
-    for (int n = 0; n < 16; ++n) v[n] = slot[la * 16 + (n ^ la)];
+    for (int n = 0; n < 16; ++n) v[n] = slot[la * 16 + (n ^ ls)];
     dft16<DIR>(v);
 }
 

@@ -96,8 +96,8 @@ SETK_DEV void load_raw(cf (&v)[16], const float* __restrict__ x, int n_samp, int
 // (no workgroup barrier: the 16 lanes share a wavefront, and the LDS operations
 // of a wavefront complete in order).  After stage 3 the slot holds X[0..255]
 // and *nyq = X[256].
-SETK_DEV void qr_stage1(cf (&v)[16], cf* slot, const cf* tw, int la) {
-    fft256_stage_a<-1>(v, slot, tw, la);
+SETK_DEV void qr_stage1(cf (&v)[16], cf* slot, const cf* tw, int la, int ls) {
+    fft256_stage_a<-1>(v, slot, tw, la, ls);
 }
 // lane la <- value of lane (16 - la) & 15 of the same quad-row (a DPP row):
 // row_mirror (la -> 15 - la) followed by row_ror:1
@@ -111,9 +111,9 @@ SETK_DEV float qr_partner(float x) {
 // owns Z[la + 16 kb]; the mirror bin 256 - k of k = la + 16 m lives in lane
 // (16 - la) & 15, register 15 - m (lane 0: its own register 16 - m), fetched with
 // two DPP moves instead of an LDS round trip.  Writes X[k], X[256-k], m < 8.
-SETK_DEV void qr_stage23(cf* slot, float* nyq, const cf* tw5, int la) {
+SETK_DEV void qr_stage23(cf* slot, float* nyq, const cf* tw5, int la, int ls) {
     cf v[16];
-    fft256_stage_b<-1>(v, slot, la);
+    fft256_stage_b<-1>(v, slot, la, ls);
     const bool lane0 = (la == 0);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256 * NQ, NQ) void stft_covar_kernel(Pass1Args a) {
             v[j] = make_float2(d.x * w.x, d.y * w.y);
         }
         if (tb_next_own < wi.t1) fetch_raw(tb_next_own);
-        qr_stage1(v, slot, tw, la);
+        qr_stage1(v, slot, tw, la, la ^ (grp & 1));
     };
     // mask rows [tile][F] are contiguous in memory: staged flat, coalesced,
     // one tile ahead, through registers into LDS (clamp applied here)
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256 * NQ, NQ) void stft_covar_kernel(Pass1Args a) {
         cf* slot = xt0 + my_i * 256;
         stage1(slot, wi.t0 + NS * TB);
         __builtin_amdgcn_wave_barrier();
-        qr_stage23(slot, xn0 + my_i, tw5, la);
+        qr_stage23(slot, xn0 + my_i, tw5, la, la ^ (grp & 1));
     }
     __syncthreads();
     int buf = 0;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256 * NQ, NQ) void stft_covar_kernel(Pass1Args a) {
             for (int tt = 0; tt < FB; ++tt) consume(tt);
         }
         __builtin_amdgcn_wave_barrier();
-        if (prod) qr_stage23(slot, xn0 + (buf ^ 1) * 32 + my_i, tw5, la);
+        if (prod) qr_stage23(slot, xn0 + (buf ^ 1) * 32 + my_i, tw5, la, la ^ (grp & 1));
         if (!DUMP) {
 #pragma unroll
             for (int tt = FB; tt < TB; ++tt) consume(tt);

@@ -199,9 +199,9 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                 if (c + 1 < C)
                     load_raw(nxt, ud.audio + (size_t)(c + 1) * n_samp, n_samp, t * hop - a.g.pad,
                              la, tvalid);
-                fft256_stage_a<-1>(v, slot, tw, la);
+                fft256_stage_a<-1>(v, slot, tw, la, la ^ (grp & 1));
                 __builtin_amdgcn_wave_barrier();
-                fft256_stage_b<-1>(v, slot, la);  // v[pos(kb)] = Z[la + 16 kb]
+                fft256_stage_b<-1>(v, slot, la, la ^ (grp & 1));  // v[pos(kb)] = Z[la + 16 kb]
                 const cf* wc = wtab + c * F;
                 // Hermitian split in registers: the mirror bin of k = la + 16 m is
                 // register 15 - m of lane (16 - la) & 15 (lane 0: own register 16 - m)
@@ -281,9 +281,9 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                 v[j].x = lane0 ? own.x : pv.x;
                 v[j].y = lane0 ? own.y : pv.y;
             }
-            fft256_stage_a<+1>(v, slot, tw, la);
+            fft256_stage_a<+1>(v, slot, tw, la, la ^ (grp & 1));
             __builtin_amdgcn_wave_barrier();
-            fft256_stage_b<+1>(v, slot, la);
+            fft256_stage_b<+1>(v, slot, la, la ^ (grp & 1));
             const float sc = tvalid ? (1.f / 256.f) : 0.f;
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) {

@@ -54,26 +54,26 @@ SD int rr_partner(int r, int j) {
 }
 
 // One-sided Jacobi on the columns of a Hermitian PSD matrix: lane j passes
-// column j in g.  Returns the principal eigenvector replicated in `out`
-// (unit 2-norm), its eigenvalue, and raises `noconv` on sweep exhaustion.
+// column j in g.  Rotating column pairs until all are mutually orthogonal turns
+// G = A into A V = V Lambda, so the column of largest norm IS lambda_max v_max:
+// the principal eigenvector is that column normalised -- V itself is never
+// accumulated (half the shuffles and flops of the textbook form).  Returns the
+// vector replicated in `out` (unit 2-norm), its eigenvalue, and raises `noconv`
+// on sweep exhaustion.
 template <int C>
 SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
-    cd v[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) v[i] = make_double2((i == j) ? 1.0 : 0.0, 0.0);
     const double tol2 = 1e-20;  // |g_p^H g_q| <= 1e-10 |g_p||g_q| (outputs are float32)
     bool done = false;
     for (int sweep = 0; sweep < 40 && !done; ++sweep) {
         bool rot = false;
         for (int r = 0; r < 7; ++r) {
             const int p = rr_partner(r, j);
-            cd gp[C], vp[C];
+            cd gp[C];
             double m = 0.0, o = 0.0;
             cd d = make_double2(0.0, 0.0);
 #pragma unroll
             for (int i = 0; i < C; ++i) {
                 gp[i] = zshfl(g[i], p);
-                vp[i] = zshfl(v[i], p);
                 m += zabs2(g[i]);
                 o += zabs2(gp[i]);
                 d = zadd(d, zcmul(g[i], gp[i]));
@@ -89,10 +89,7 @@ SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
                 const double f = sigma * sn / absd;
                 const cd ph = make_double2(d.x * f, -d.y * f);  // sigma*sn*conj(d)/|d|
 #pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    g[i] = zsub(zscale(g[i], cs), zmul(ph, gp[i]));
-                    v[i] = zsub(zscale(v[i], cs), zmul(ph, vp[i]));
-                }
+                for (int i = 0; i < C; ++i) g[i] = zsub(zscale(g[i], cs), zmul(ph, gp[i]));
                 rot = true;
             }
         }
@@ -114,9 +111,13 @@ SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
             bj = oj;
         }
     }
-#pragma unroll
-    for (int i = 0; i < C; ++i) out[i] = zshfl(v[i], bj);
     lam = sqrt(best);
+    const double inv = (lam > 0.0) ? 1.0 / lam : 0.0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        out[i] = zscale(zshfl(g[i], bj), inv);
+        if (!(lam > 0.0)) out[i] = make_double2((i == 0) ? 1.0 : 0.0, 0.0);
+    }
 }
 
 template <int C>
