@@ -139,8 +139,14 @@ SD void fix_gauge(cd (&v)[C]) {
 // at eps_f32 * max diag(M) (the noise level of the float32-accumulated input);
 // only an all-zero / non-finite / negative-diagonal matrix reports 1.
 template <int C>
-SD int chol_lds(const cd* M, cd* L, double* piv, int j) {
-    double scale = (j < C) ? M[j * C + j].x : 0.0;
+SD int chol_lds(const cd (&col)[C], cd* L, double* piv, int j) {
+    // col[i] = M[i][j] (lane j owns column j of the Hermitian M), so the row
+    // element M[j][k] is conj(col[k])
+    double diag = 0.0;
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+        if (i == j) diag = col[i].x;
+    double scale = diag;
 #pragma unroll
     for (int s = 1; s < 8; s <<= 1) scale = fmax(scale, __shfl_xor(scale, s, 8));
     int bad = !(scale > 0.0);
@@ -149,7 +155,7 @@ SD int chol_lds(const cd* M, cd* L, double* piv, int j) {
     for (int k = 0; k < C; ++k) {
         cd s = make_double2(0.0, 0.0);
         if (j >= k && j < C) {
-            s = M[k * C + j];  // M[j][k]
+            s = make_double2(col[k].x, -col[k].y);  // M[j][k]
             for (int m = 0; m < k; ++m) s = zsub(s, zmulc(L[m * C + j], L[m * C + k]));
         }
         if (j == k) *piv = s.x;
@@ -196,11 +202,11 @@ SD double group_sum(double v) {
 // generalised principal eigenvector of (Rs, Rn) with L = chol(Rn) already in
 // LDS: returns v = L^-H y, ||y|| = 1 (so v^H Rn v = 1), gauge on y.
 template <int C>
-SD void gev_vector(const cd* Rs, const cd* L, cd* Wk, int j, bool gauge, cd (&vout)[C],
+SD void gev_vector(const cd (&rs)[C], const cd* L, cd* Wk, int j, bool gauge, cd (&vout)[C],
                    int& noconv) {
     cd x[C];
 #pragma unroll
-    for (int i = 0; i < C; ++i) x[i] = (j < C) ? Rs[j * C + i] : make_double2(0.0, 0.0);
+    for (int i = 0; i < C; ++i) x[i] = rs[i];
     fwd_solve<C>(L, x);  // column j of X = L^-1 Rs
     __syncthreads();
     if (j < C) {
@@ -228,15 +234,26 @@ SD void gev_vector(const cd* Rs, const cd* L, cd* Wk, int j, bool gauge, cd (&vo
     for (int i = 0; i < C; ++i) vout[i] = y[i];
 }
 
+// y = M x for a Hermitian M held one column per lane (col[i] = M[i][j]):
+// lane j forms (M x)_j = sum_m conj(col[m]) x[m], the results are all-gathered.
 template <int C>
-__global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch) {
+SD void herm_matvec(const cd (&col)[C], const cd (&x)[C], cd (&y)[C]) {
+    cd mine = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int m = 0; m < C; ++m) mine = zadd(mine, zcmul(col[m], x[m]));
+#pragma unroll
+    for (int i = 0; i < C; ++i) y[i] = zshfl(mine, i);
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch, int lds_mats) {
     constexpr int NP = npairs(C);
-    __shared__ cd sRs[8][C * C];
-    __shared__ cd sRn[8][C * C];
-    __shared__ cd sRy[8][C * C];
-    __shared__ cd sL[8][C * C];
-    __shared__ cd sWk[8][C * C];
-    __shared__ double sPiv[8];
+    // dynamic LDS, 8 problems per workgroup: [L | Wk | Rs | Rn] (lds_mats of them).
+    // L: Cholesky factor (all kinds but plain pevd); Wk: transposes of the reduced
+    // pencil; Rs, Rn: full matrices, only for the PMWF reference-channel search.
+    extern __shared__ __attribute__((aligned(16))) char solve_smem[];
+    cd* mats = reinterpret_cast<cd*>(solve_smem);
+    double* sPiv = reinterpret_cast<double*>(mats + (size_t)lds_mats * 8 * C * C);
 
     const int tid = threadIdx.x;
     const int j = tid & 7, q = tid >> 3;
@@ -247,72 +264,71 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch) {
     if (!live) prob = n_prob - 1;  // keep the lanes in step; no stores
     const int u = (int)(prob / F), f = (int)(prob % F);
 
-    cd* Rs = sRs[q];
-    cd* Rn = sRn[q];
-    cd* Ry = sRy[q];
-    cd* L = sL[q];
-    cd* Wk = sWk[q];
+    cd* L = mats + ((size_t)0 * 8 + q) * C * C;
+    cd* Wk = mats + ((size_t)(lds_mats > 1 ? 1 : 0) * 8 + q) * C * C;
+    cd* Rsf = mats + ((size_t)(lds_mats > 2 ? 2 : 0) * 8 + q) * C * C;
+    cd* Rnf = mats + ((size_t)(lds_mats > 3 ? 3 : 0) * 8 + q) * C * C;
     double* piv = &sPiv[q];
 
     const int kind = a.kind;
     const bool gauge = (a.flags & SETK_FLAG_NO_GAUGE) == 0;
-    const bool need_rn = !(kind == kKindPevd && a.planes < 4 * NP) && kind != SETK_BF_MPDR;
+    const bool have_rn = a.planes >= 4 * NP && kind != SETK_BF_MPDR;
     const bool need_ry = (kind == SETK_BF_MPDR || kind == SETK_BF_MPDR_WHITEN);
 
-    // ---- load column j of each matrix from the packed planes ----
+    // ---- column j of each Hermitian matrix from the packed planes ----
+    cd rs[C], rn[C], ry[C];
     const float* base = a.covar + (size_t)u * a.planes * pitch + f;
     bool finite = true;
-    if (j < C) {
 #pragma unroll
-        for (int i = 0; i < C; ++i) {
+    for (int i = 0; i < C; ++i) {
+        rs[i] = rn[i] = ry[i] = make_double2(0.0, 0.0);
+        if (j < C) {
             const int lo = i < j ? i : j, hi = i < j ? j : i;
             const int e = pair_index(lo, hi, C);
             const double sgn = (i <= j) ? 1.0 : -1.0;  // (i,j) stored for i<=j
             const float sr = base[(size_t)(0 * NP + e) * pitch];
             const float si = base[(size_t)(1 * NP + e) * pitch];
-            Rs[j * C + i] = make_double2(sr, (i == j) ? 0.0 : sgn * si);
+            rs[i] = make_double2(sr, (i == j) ? 0.0 : sgn * si);
             finite = finite && isfinite(sr) && isfinite(si);
-            if (need_rn || kind == SETK_BF_MPDR_WHITEN) {
+            if (have_rn) {
                 const float nr = base[(size_t)(2 * NP + e) * pitch];
                 const float ni = base[(size_t)(3 * NP + e) * pitch];
-                Rn[j * C + i] = make_double2(nr, (i == j) ? 0.0 : sgn * ni);
+                rn[i] = make_double2(nr, (i == j) ? 0.0 : sgn * ni);
                 finite = finite && isfinite(nr) && isfinite(ni);
             }
             if (need_ry) {
                 const float yr = base[(size_t)(4 * NP + e) * pitch];
                 const float yi = base[(size_t)(5 * NP + e) * pitch];
-                Ry[j * C + i] = make_double2(yr, (i == j) ? 0.0 : sgn * yi);
+                ry[i] = make_double2(yr, (i == j) ? 0.0 : sgn * yi);
                 finite = finite && isfinite(yr) && isfinite(yi);
             }
         }
     }
-    __syncthreads();
 
     int st_sing = 0, st_noconv = 0;
     cd w[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) w[i] = make_double2(0.0, 0.0);
-    const cd* ban_mat = Rn;
 
-    if (kind == kKindPevd && !need_rn) {
+    if (kind == kKindPevd && !have_rn) {
         cd g[C];
 #pragma unroll
-        for (int i = 0; i < C; ++i) g[i] = (j < C) ? Rs[j * C + i] : make_double2(0.0, 0.0);
+        for (int i = 0; i < C; ++i) g[i] = rs[i];
         double lam;
         jacobi_pevd<C>(g, j, w, lam, st_noconv);
         if (gauge) fix_gauge<C>(w);
     } else if (kind == kKindPevd || kind == SETK_BF_GEVD) {
-        st_sing |= chol_lds<C>(Rn, L, piv, j);
-        gev_vector<C>(Rs, L, Wk, j, gauge, w, st_noconv);
+        st_sing |= chol_lds<C>(rn, L, piv, j);
+        gev_vector<C>(rs, L, Wk, j, gauge, w, st_noconv);
     } else if (kind == SETK_BF_MVDR) {
         cd g[C];
 #pragma unroll
-        for (int i = 0; i < C; ++i) g[i] = (j < C) ? Rs[j * C + i] : make_double2(0.0, 0.0);
+        for (int i = 0; i < C; ++i) g[i] = rs[i];
         cd d[C];
         double lam;
         jacobi_pevd<C>(g, j, d, lam, st_noconv);
         if (gauge) fix_gauge<C>(d);
-        st_sing |= chol_lds<C>(Rn, L, piv, j);
+        st_sing |= chol_lds<C>(rn, L, piv, j);
         cd num[C];
 #pragma unroll
         for (int i = 0; i < C; ++i) num[i] = d[i];
@@ -328,24 +344,18 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch) {
         if (kind == SETK_BF_MPDR) {
             cd g[C];
 #pragma unroll
-            for (int i = 0; i < C; ++i) g[i] = (j < C) ? Rs[j * C + i] : make_double2(0.0, 0.0);
+            for (int i = 0; i < C; ++i) g[i] = rs[i];
             double lam;
             jacobi_pevd<C>(g, j, sv, lam, st_noconv);
             if (gauge) fix_gauge<C>(sv);
         } else {
-            st_sing |= chol_lds<C>(Rn, L, piv, j);
+            st_sing |= chol_lds<C>(rn, L, piv, j);
             cd v[C];
-            gev_vector<C>(Rs, L, Wk, j, gauge, v, st_noconv);
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                cd s = make_double2(0.0, 0.0);
-#pragma unroll
-                for (int m = 0; m < C; ++m) s = zadd(s, zmul(Rn[m * C + i], v[m]));
-                sv[i] = s;
-            }
+            gev_vector<C>(rs, L, Wk, j, gauge, v, st_noconv);
+            herm_matvec<C>(rn, v, sv);
             __syncthreads();
         }
-        st_sing |= chol_lds<C>(Ry, L, piv, j);
+        st_sing |= chol_lds<C>(ry, L, piv, j);
         cd num[C];
 #pragma unroll
         for (int i = 0; i < C; ++i) num[i] = sv[i];
@@ -357,48 +367,39 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch) {
 #pragma unroll
         for (int i = 0; i < C; ++i) w[i] = zdiv(num[i], den);
     } else if (kind == SETK_BF_PMWF) {
-        st_sing |= chol_lds<C>(Rn, L, piv, j);
+        st_sing |= chol_lds<C>(rn, L, piv, j);
         if (a.rank1 != SETK_RANK1_NONE) {
             cd pv[C];
             if (a.rank1 == SETK_RANK1_EIG) {
                 cd g[C];
 #pragma unroll
-                for (int i = 0; i < C; ++i)
-                    g[i] = (j < C) ? Rs[j * C + i] : make_double2(0.0, 0.0);
+                for (int i = 0; i < C; ++i) g[i] = rs[i];
                 double lam;
                 jacobi_pevd<C>(g, j, pv, lam, st_noconv);
             } else {
                 cd v[C];
-                gev_vector<C>(Rs, L, Wk, j, false, v, st_noconv);
-#pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    cd s = make_double2(0.0, 0.0);
-#pragma unroll
-                    for (int m = 0; m < C; ++m) s = zadd(s, zmul(Rn[m * C + i], v[m]));
-                    pv[i] = s;
-                }
+                gev_vector<C>(rs, L, Wk, j, false, v, st_noconv);
+                herm_matvec<C>(rn, v, pv);
             }
-            double tr = 0.0, pn = 0.0;
+            double dj = 0.0, pn = 0.0;
 #pragma unroll
             for (int i = 0; i < C; ++i) {
-                tr += Rs[i * C + i].x;
+                if (i == j) dj = rs[i].x;
                 pn += zabs2(pv[i]);
             }
+            const double tr = group_sum(dj);
             const double sc = tr / fmax(pn, kEpsF32);
-            __syncthreads();
-            if (j < C) {
-                cd pj = make_double2(0.0, 0.0);
+            cd pj = make_double2(0.0, 0.0);
 #pragma unroll
-                for (int i = 0; i < C; ++i)
-                    if (i == j) pj = pv[i];
+            for (int i = 0; i < C; ++i)
+                if (i == j) pj = pv[i];
 #pragma unroll
-                for (int i = 0; i < C; ++i) Rs[j * C + i] = zscale(zmulc(pv[i], pj), sc);
-            }
-            __syncthreads();
+            for (int i = 0; i < C; ++i)
+                rs[i] = (j < C) ? zscale(zmulc(pv[i], pj), sc) : make_double2(0.0, 0.0);
         }
         cd x[C];
 #pragma unroll
-        for (int i = 0; i < C; ++i) x[i] = (j < C) ? Rs[j * C + i] : make_double2(0.0, 0.0);
+        for (int i = 0; i < C; ++i) x[i] = rs[i];
         fwd_solve<C>(L, x);
         bwd_solve<C>(L, x);  // column j of Rn^-1 Rs
         cd diag = make_double2(0.0, 0.0);
@@ -412,24 +413,28 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch) {
 #pragma unroll
             for (int i = 0; i < C; ++i) w[i] = zshfl(x[i], a.pmwf_ref);
         } else {
-            // estimated SNR of every candidate column (libs/beamformer.py:620-630)
-            cd us[C], un[C];
+            // estimated SNR of every candidate column (libs/beamformer.py:620-630):
+            // needs the full (possibly rank-1 replaced) Rs and Rn in every lane
+            __syncthreads();
+            if (j < C) {
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    Rsf[j * C + i] = rs[i];
+                    Rnf[j * C + i] = rn[i];
+                }
+            }
+            __syncthreads();
+            double ps = 0.0, pn = 0.0;
 #pragma unroll
             for (int i = 0; i < C; ++i) {
                 cd s1 = make_double2(0.0, 0.0), s2 = s1;
 #pragma unroll
                 for (int m = 0; m < C; ++m) {
-                    s1 = zadd(s1, zmul(Rs[m * C + i], x[m]));
-                    s2 = zadd(s2, zmul(Rn[m * C + i], x[m]));
+                    s1 = zadd(s1, zmul(Rsf[m * C + i], x[m]));
+                    s2 = zadd(s2, zmul(Rnf[m * C + i], x[m]));
                 }
-                us[i] = s1;
-                un[i] = s2;
-            }
-            double ps = 0.0, pn = 0.0;
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                ps += zcmul(x[i], us[i]).x;
-                pn += zcmul(x[i], un[i]).x;
+                ps += zcmul(x[i], s1).x;
+                pn += zcmul(x[i], s2).x;
             }
             if (live && j < C) {
                 atomicAdd(&a.snr_acc[((size_t)u * C + j) * 2 + 0], ps);
@@ -443,15 +448,13 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch) {
 
     // ---- blind analytic normalisation (do_ban) ----
     if ((a.flags & SETK_FLAG_BAN) && !(kind == SETK_BF_PMWF && a.pmwf_ref < 0)) {
-        cd uj = make_double2(0.0, 0.0);
+        cd uj = make_double2(0.0, 0.0);  // (Rn w)_j = sum_m conj(Rn[m][j]) w[m]
         cd wj = make_double2(0.0, 0.0);
-        if (j < C) {
 #pragma unroll
-            for (int m = 0; m < C; ++m) uj = zadd(uj, zmul(ban_mat[m * C + j], w[m]));
+        for (int m = 0; m < C; ++m) uj = zadd(uj, zcmul(rn[m], w[m]));
 #pragma unroll
-            for (int i = 0; i < C; ++i)
-                if (i == j) wj = w[i];
-        }
+        for (int i = 0; i < C; ++i)
+            if (i == j) wj = w[i];
         const double nom = group_sum(zabs2(uj));
         const double den = group_sum(zcmul(wj, uj).x);
         const double filt = sqrt(nom) / fmax(den, kEpsF32);
@@ -487,9 +490,15 @@ hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
     const long n_prob = (long)a.n_utts * a.num_bins;
     const int blocks = (int)((n_prob + 7) / 8);
     const int pitch = (a.num_bins == kBins) ? kBinsPad : ((a.num_bins + 7) / 8) * 8;
+    // L only: MVDR, MPDR; + Wk: the reduced-pencil kinds; + Rs, Rn: PMWF SNR search
+    int lds_mats = 2;
+    if (a.kind == SETK_BF_MVDR || a.kind == SETK_BF_MPDR) lds_mats = 1;
+    if (a.kind == SETK_BF_PMWF) lds_mats = 4;
 #define SETK_CASE(c)                                                                   \
     case c:                                                                            \
-        hipLaunchKernelGGL(solve_kernel<c>, dim3(blocks), dim3(64), 0, s, a, pitch);   \
+        hipLaunchKernelGGL(solve_kernel<c>, dim3(blocks), dim3(64),                    \
+                           (size_t)lds_mats * 8 * c * c * sizeof(cd) + 64, s, a, pitch,\
+                           lds_mats);                                                  \
         break;
     switch (a.num_channels) {
         SETK_CASE(1)
