@@ -180,6 +180,14 @@ int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int nu
                     int num_bins, int num_iters, const float* init_mask, float* gamma_out,
                     float* mask_out, void* stream);
 
+/* Batched form: n_utts utterances per EM stage launch (device pointers only;
+ * spec[u] = [C][num_frames[u]][F], mask_out[u] = [num_frames[u]][F], init_mask
+ * NULL or per-utterance NULL-able table).  Asynchronous on `stream`. */
+int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
+                          const float* const* spec, const int* num_frames, int num_bins,
+                          int num_iters, const float* const* init_mask, float* const* mask_out,
+                          void* stream);
+
 /* ---- fused hot path ------------------------------------------------------
  * The compute body of apply_adaptive_beamformer.py:130-178 for a batch of
  * utterances that share the channel count, in four kernel stages:

@@ -46,7 +46,8 @@ def exported_symbols():
         "setk_abi_version", "setk_create", "setk_destroy", "setk_last_error",
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
-        "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks", "setk_enhance_batch", "setk_set_profiling",
+        "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks", "setk_cgmm_masks_batch", "setk_enhance_batch",
+        "setk_set_profiling",
         "setk_last_stage_ms"
     ]
 
@@ -87,6 +88,8 @@ def load_library():
     lib.setk_rank1.argtypes = [H, fp, fp, c_int, c_int, fp, fp, c_void_p]
     lib.setk_beamform.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, c_void_p]
     lib.setk_cgmm_masks.argtypes = [H, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_void_p]
+    lib.setk_cgmm_masks_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int), c_int,
+                                          c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p]
     lib.setk_enhance_batch.argtypes = [
         H, POINTER(BfOpts), c_int, c_int, POINTER(c_void_p), POINTER(c_int),
         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int),
@@ -248,6 +251,17 @@ class Context:
             self._lib.setk_cgmm_masks(self._h, _ptr(spec), C, T, F, int(num_iters),
                                       _ptr(init_mask), _ptr(gamma_out), _ptr(mask_out),
                                       current_stream_ptr() if stream is None else stream))
+
+    def cgmm_masks_batch(self, C, spec_ptrs, num_frames, F, num_iters, init_ptrs, out_ptrs,
+                         stream=None):
+        n = len(spec_ptrs)
+        S = (c_void_p * n)(*spec_ptrs)
+        O = (c_void_p * n)(*out_ptrs)
+        I = (c_void_p * n)(*init_ptrs) if init_ptrs is not None else None
+        T = (c_int * n)(*[int(v) for v in num_frames])
+        self.check(
+            self._lib.setk_cgmm_masks_batch(self._h, n, int(C), S, T, int(F), int(num_iters), I, O,
+                                            current_stream_ptr() if stream is None else stream))
 
     # -- fused hot path ---------------------------------------------------------
     def enhance_batch(self, opts, num_channels, audio_ptrs, num_samples, mask_ptrs,

@@ -795,6 +795,41 @@ int setk_beamform(setk_handle_t h, const float* weight, const float* spec, int n
     return SETK_OK;
 }
 
+int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
+                          const float* const* spec, const int* num_frames, int num_bins,
+                          int num_iters, const float* const* init_mask, float* const* mask_out,
+                          void* stream) {
+    if (!h || n_utts <= 0 || !spec || !num_frames || !mask_out || num_bins <= 0 || num_iters < 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    if (num_channels < 1 || num_channels > kMaxChannels)
+        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h);
+    const int C = num_channels, F = num_bins;
+    const size_t ab = cgmm_args_bytes();
+    std::vector<char> tbl((size_t)n_utts * ab);
+    int max_frames = 0;
+    for (int u = 0; u < n_utts; ++u) {
+        if (!spec[u] || !mask_out[u] || num_frames[u] <= 0)
+            return fail(h, SETK_ERR_INVALID, "null utterance pointer");
+        if (!is_device_ptr(spec[u]) || !is_device_ptr(mask_out[u]) ||
+            (init_mask && init_mask[u] && !is_device_ptr(init_mask[u])))
+            return fail(h, SETK_ERR_INVALID, "setk_cgmm_masks_batch takes device pointers");
+        const int T = num_frames[u];
+        max_frames = std::max(max_frames, T);
+        void* scr = arena_alloc(h, cgmm_scratch_bytes(C, T, F));
+        if (!scr) return fail(h, SETK_ERR_NOMEM, "arena");
+        cgmm_fill_args(tbl.data() + (size_t)u * ab, C, spec[u], T, F,
+                       init_mask ? init_mask[u] : nullptr, nullptr, mask_out[u], scr);
+    }
+    void* d_tbl;
+    int rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
+    if (rc) return rc;
+    HIP_TRY(h, launch_cgmm_batch(C, d_tbl, n_utts, F, max_frames, num_iters, s));
+    return SETK_OK;
+}
+
 int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int num_frames,
                     int num_bins, int num_iters, const float* init_mask, float* gamma_out,
                     float* mask_out, void* stream) {
@@ -816,20 +851,20 @@ int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int nu
     OutBuf om, og;
     rc = stage_out(h, mask_out, (size_t)T * F * 4, &om);
     if (rc) return rc;
-    float* d_gamma;
+    float* d_gamma = nullptr;
     if (gamma_out) {
         rc = stage_out(h, gamma_out, (size_t)2 * T * F * 4, &og);
         if (rc) return rc;
         d_gamma = static_cast<float*>(og.dev);
-    } else {
-        d_gamma = static_cast<float*>(arena_alloc(h, (size_t)2 * T * F * 4));
     }
-    float* d_phi = static_cast<float*>(arena_alloc(h, (size_t)2 * T * F * 4));
-    const size_t sb = cgmm_scratch_bytes(C, T, F);
-    void* d_scr = arena_alloc(h, sb);
-    if (!d_gamma || !d_phi || !d_scr) return fail(h, SETK_ERR_NOMEM, "arena");
-    HIP_TRY(h, launch_cgmm(C, d_spec, T, F, num_iters, d_init, d_gamma, d_phi,
-                           static_cast<float*>(om.dev), d_scr, sb, s));
+    void* d_scr = arena_alloc(h, cgmm_scratch_bytes(C, T, F));
+    if (!d_scr) return fail(h, SETK_ERR_NOMEM, "arena");
+    std::vector<char> tbl(cgmm_args_bytes());
+    cgmm_fill_args(tbl.data(), C, d_spec, T, F, d_init, d_gamma, static_cast<float*>(om.dev), d_scr);
+    void* d_tbl;
+    rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
+    if (rc) return rc;
+    HIP_TRY(h, launch_cgmm_batch(C, d_tbl, 1, F, T, num_iters, s));
     rc = copy_back(h, om, s);
     if (rc) return rc;
     if (gamma_out) {

@@ -51,8 +51,11 @@ struct CgmmArgs {
 
 // ---- M-step: weighted outer products, 32 bins x 2 classes per wavefront ----
 template <int C>
-__global__ __launch_bounds__(64) void cgmm_accum_kernel(CgmmArgs a) {
+__global__ __launch_bounds__(64) void cgmm_accum_kernel(const CgmmArgs* __restrict__ tbl, int em) {
     constexpr int NP = npairs(C);
+    CgmmArgs a = tbl[blockIdx.z];
+    if (em) a.mode = kCgEm;
+    if ((int)blockIdx.y >= a.nchunks) return;
     const int lane = threadIdx.x;
     const int f = blockIdx.x * 32 + (lane & 31);
     const int k = lane >> 5;
@@ -105,10 +108,12 @@ __global__ __launch_bounds__(64) void cgmm_accum_kernel(CgmmArgs a) {
 }
 
 // sum the frame chunks in fp64, normalise (cluster.py:203-205 / 419-440)
-__global__ void cgmm_finalize_kernel(CgmmArgs a, int C) {
+__global__ void cgmm_finalize_kernel(const CgmmArgs* __restrict__ tbl, int em, int C) {
+    CgmmArgs a = tbl[blockIdx.z];
+    if (em) a.mode = kCgEm;
     const int f = blockIdx.x * 256 + threadIdx.x;
-    const int e = blockIdx.y, k = blockIdx.z;
     const int NP = npairs(C);
+    const int e = blockIdx.y % (2 * NP), k = blockIdx.y / (2 * NP);
     if (f >= a.F) return;
     double* out = a.R + ((size_t)k * 2 * NP + e) * a.pitch;
     if (a.mode == kCgInitId && k == 1) {
@@ -142,8 +147,9 @@ ZD int cg_partner(int r, int j) {
 }
 
 template <int C>
-__global__ __launch_bounds__(64) void cgmm_eig_kernel(CgmmArgs a) {
+__global__ __launch_bounds__(64) void cgmm_eig_kernel(const CgmmArgs* __restrict__ tbl) {
     constexpr int NP = npairs(C);
+    const CgmmArgs a = tbl[blockIdx.z];
     const int tid = threadIdx.x;
     const int j = tid & 7;
     const int F = a.F;
@@ -226,7 +232,10 @@ __global__ __launch_bounds__(64) void cgmm_eig_kernel(CgmmArgs a) {
 
 // ---- E-step: phi, posterior gamma (cluster.py:207-212, 214-235, 261-287) ----
 template <int C>
-__global__ __launch_bounds__(64) void cgmm_estep_kernel(CgmmArgs a) {
+__global__ __launch_bounds__(64) void cgmm_estep_kernel(const CgmmArgs* __restrict__ tbl, int last) {
+    CgmmArgs a = tbl[blockIdx.z];
+    if (!last) a.mask_out = nullptr;
+    if ((int)blockIdx.y >= a.nchunks) return;
     const int lane = threadIdx.x;
     const int f = blockIdx.x * 32 + (lane & 31);
     const int k = lane >> 5;
@@ -275,35 +284,31 @@ __global__ __launch_bounds__(64) void cgmm_estep_kernel(CgmmArgs a) {
 }
 
 template <int C>
-static hipError_t cgmm_run_t(CgmmArgs a, int num_iters, hipStream_t s) {
+static hipError_t cgmm_run_t(const CgmmArgs* d_tbl, int n_utts, int F, int max_chunks,
+                             int num_iters, hipStream_t s) {
     const int NP = npairs(C);
-    dim3 g_tf((a.F + 31) / 32, a.nchunks);
-    dim3 g_fin((a.F + 255) / 256, 2 * NP, 2);
-    const int eig_blocks = (2 * a.F + 7) / 8;
-    float* mask_out = a.mask_out;
-    a.mask_out = nullptr;
-    a.mode = a.init_mask ? kCgInitMask : kCgInitId;
+    dim3 g_tf((F + 31) / 32, max_chunks, n_utts);
+    dim3 g_fin((F + 255) / 256, 2 * NP * 2, n_utts);
+    dim3 g_eig((2 * F + 7) / 8, 1, n_utts);
     for (int it = 0; it <= num_iters; ++it) {
-        hipLaunchKernelGGL(cgmm_accum_kernel<C>, g_tf, dim3(64), 0, s, a);
-        hipLaunchKernelGGL(cgmm_finalize_kernel, g_fin, dim3(256), 0, s, a, C);
-        hipLaunchKernelGGL(cgmm_eig_kernel<C>, dim3(eig_blocks), dim3(64), 0, s, a);
-        if (it == num_iters) a.mask_out = mask_out;
-        hipLaunchKernelGGL(cgmm_estep_kernel<C>, g_tf, dim3(64), 0, s, a);
-        a.mode = kCgEm;
+        const int em = it > 0;
+        hipLaunchKernelGGL(cgmm_accum_kernel<C>, g_tf, dim3(64), 0, s, d_tbl, em);
+        hipLaunchKernelGGL(cgmm_finalize_kernel, g_fin, dim3(256), 0, s, d_tbl, em, C);
+        hipLaunchKernelGGL(cgmm_eig_kernel<C>, g_eig, dim3(64), 0, s, d_tbl);
+        hipLaunchKernelGGL(cgmm_estep_kernel<C>, g_tf, dim3(64), 0, s, d_tbl,
+                           (int)(it == num_iters));
     }
     return hipGetLastError();
 }
 
-// scratch floats needed besides gamma/phi (host computes the arena layout)
-hipError_t launch_cgmm(int C, const float* spec, int T, int F, int num_iters,
-                       const float* init_mask, float* gamma, float* phi, float* mask_out,
-                       void* scratch, size_t scratch_bytes, hipStream_t s) {
+// Fill one utterance's argument block; `scratch` is carved for its work arrays
+// (gamma, phi included).  Returns bytes used.
+size_t cgmm_fill_args(void* args_out, int C, const float* spec, int T, int F,
+                      const float* init_mask, float* gamma_opt, float* mask_out, void* scratch) {
     const int NP = npairs(C);
     CgmmArgs a;
     std::memset(&a, 0, sizeof(a));
     a.spec = reinterpret_cast<const cf*>(spec);
-    a.gamma = gamma;
-    a.phi = phi;
     a.init_mask = init_mask;
     a.mask_out = mask_out;
     a.T = T;
@@ -311,38 +316,51 @@ hipError_t launch_cgmm(int C, const float* spec, int T, int F, int num_iters,
     a.pitch = ((F + 7) / 8) * 8;
     a.tchunk = 64;
     a.nchunks = (T + a.tchunk - 1) / a.tchunk;
+    a.mode = init_mask ? kCgInitMask : kCgInitId;
     char* p = static_cast<char*>(scratch);
     auto take = [&](size_t bytes) {
         char* r = p;
         p += (bytes + 255) & ~(size_t)255;
         return r;
     };
+    a.gamma = gamma_opt ? gamma_opt : reinterpret_cast<float*>(take((size_t)2 * T * F * 4));
+    a.phi = reinterpret_cast<float*>(take((size_t)2 * T * F * 4));
     a.partials = reinterpret_cast<float*>(take((size_t)a.nchunks * 2 * (2 * NP + 1) * a.pitch * 4));
     a.R = reinterpret_cast<double*>(take((size_t)2 * 2 * NP * a.pitch * 8));
     a.V = reinterpret_cast<cf*>(take((size_t)2 * F * C * C * 8));
     a.invw = reinterpret_cast<float*>(take((size_t)2 * F * C * 4));
     a.logdet = reinterpret_cast<float*>(take((size_t)2 * F * 4));
-    if ((size_t)(p - static_cast<char*>(scratch)) > scratch_bytes) return hipErrorInvalidValue;
-    switch (C) {
-        case 1: return cgmm_run_t<1>(a, num_iters, s);
-        case 2: return cgmm_run_t<2>(a, num_iters, s);
-        case 3: return cgmm_run_t<3>(a, num_iters, s);
-        case 4: return cgmm_run_t<4>(a, num_iters, s);
-        case 5: return cgmm_run_t<5>(a, num_iters, s);
-        case 6: return cgmm_run_t<6>(a, num_iters, s);
-        case 7: return cgmm_run_t<7>(a, num_iters, s);
-        case 8: return cgmm_run_t<8>(a, num_iters, s);
-    }
-    return hipErrorInvalidValue;
+    std::memcpy(args_out, &a, sizeof(a));
+    return (size_t)(p - static_cast<char*>(scratch));
 }
+
+size_t cgmm_args_bytes() { return sizeof(CgmmArgs); }
 
 size_t cgmm_scratch_bytes(int C, int T, int F) {
     const int NP = npairs(C);
     const size_t pitch = ((F + 7) / 8) * 8;
     const size_t nchunks = (T + 63) / 64;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return al(nchunks * 2 * (2 * NP + 1) * pitch * 4) + al((size_t)2 * 2 * NP * pitch * 8) +
-           al((size_t)2 * F * C * C * 8) + al((size_t)2 * F * C * 4) + al((size_t)2 * F * 4) + 1024;
+    return 2 * al((size_t)2 * T * F * 4) + al(nchunks * 2 * (2 * NP + 1) * pitch * 4) +
+           al((size_t)2 * 2 * NP * pitch * 8) + al((size_t)2 * F * C * C * 8) +
+           al((size_t)2 * F * C * 4) + al((size_t)2 * F * 4) + 1024;
+}
+
+hipError_t launch_cgmm_batch(int C, const void* d_tbl, int n_utts, int F, int max_frames,
+                             int num_iters, hipStream_t s) {
+    const CgmmArgs* t = static_cast<const CgmmArgs*>(d_tbl);
+    const int max_chunks = (max_frames + 63) / 64;
+    switch (C) {
+        case 1: return cgmm_run_t<1>(t, n_utts, F, max_chunks, num_iters, s);
+        case 2: return cgmm_run_t<2>(t, n_utts, F, max_chunks, num_iters, s);
+        case 3: return cgmm_run_t<3>(t, n_utts, F, max_chunks, num_iters, s);
+        case 4: return cgmm_run_t<4>(t, n_utts, F, max_chunks, num_iters, s);
+        case 5: return cgmm_run_t<5>(t, n_utts, F, max_chunks, num_iters, s);
+        case 6: return cgmm_run_t<6>(t, n_utts, F, max_chunks, num_iters, s);
+        case 7: return cgmm_run_t<7>(t, n_utts, F, max_chunks, num_iters, s);
+        case 8: return cgmm_run_t<8>(t, n_utts, F, max_chunks, num_iters, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace setk

@@ -133,10 +133,12 @@ hipError_t launch_istft_generic(const float* spec, int B, int T, int n_fft, int 
                                 int out_len, const float* window, const float* winsq,
                                 const float* tw, float* frames, float* wave, unsigned* outmax,
                                 const float* norm, int T_eff, hipStream_t s);
-hipError_t launch_cgmm(int C, const float* spec, int T, int F, int num_iters,
-                       const float* init_mask, float* gamma, float* phi, float* mask_out,
-                       void* scratch, size_t scratch_bytes, hipStream_t s);
+size_t cgmm_fill_args(void* args_out, int C, const float* spec, int T, int F,
+                      const float* init_mask, float* gamma_opt, float* mask_out, void* scratch);
+size_t cgmm_args_bytes();
 size_t cgmm_scratch_bytes(int C, int T, int F);
+hipError_t launch_cgmm_batch(int C, const void* d_tbl, int n_utts, int F, int max_frames,
+                             int num_iters, hipStream_t s);
 hipError_t launch_ban(const float* w, const float* Rn, int F, int C, float* out, hipStream_t s);
 hipError_t launch_rank1(const float* pv, const float* Rs, const float* Rn, int F, int C,
                         float* out, hipStream_t s);

@@ -213,3 +213,65 @@ class BatchEnhancer(object):
                                    [t.data_ptr() for t in waves], want_status=True)
         for j, i in enumerate(batch):
             results[i] = (waves[j].cpu().numpy() if status[j] == 0 else None, status[j])
+
+
+class CgmmEstimator(object):
+    """Batched blind mask estimation (estimate_cgmm_masks.py:19-71, K = 2): STFT
+    and all EM iterations on the device, n utterances per kernel launch
+    (setk_cgmm_masks_batch).  n_fft must be 512 for the device STFT used here."""
+
+    def __init__(self, frame_len=512, frame_hop=256, center=True, round_power_of_two=True,
+                 window="hann", num_iters=20, device=None, ctx=None):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _ffi.SetkError("CgmmEstimator needs an MI355X (no CPU fallback)")
+        self.ctx = ctx or _ffi.default_context(device)
+        self.dev = torch.device("cuda", self.ctx.device)
+        n_fft = nextpow2(frame_len) if round_power_of_two else frame_len
+        self.stft = dict(frame_len=frame_len, frame_hop=frame_hop, n_fft=n_fft, center=center,
+                         window=stft_window(window, frame_len))
+        self.num_bins = n_fft // 2 + 1
+        self.num_iters = num_iters
+
+    def _plan(self):
+        s = self.stft
+        self.ctx.stft_plan(s["frame_len"], s["frame_hop"], s["n_fft"], s["center"], s["window"])
+
+    def estimate_device(self, audio, init_masks=None):
+        """audio: list of device float32 tensors C x N (same C).  Returns the
+        list of device speech masks T x F (float32)."""
+        torch, ctx, dev, F = self.torch, self.ctx, self.dev, self.num_bins
+        self._plan()
+        C = audio[0].shape[0]
+        specs, masks, frames = [], [], []
+        for a in audio:
+            T = ctx.num_frames(a.shape[1])
+            sp = torch.empty((C, T, F), dtype=torch.complex64, device=dev)
+            ctx.stft(a, sp)
+            specs.append(sp)
+            masks.append(torch.empty((T, F), dtype=torch.float32, device=dev))
+            frames.append(T)
+        init = None
+        if init_masks is not None:
+            init = [0 if m is None else m.data_ptr() for m in init_masks]
+        ctx.cgmm_masks_batch(C, [t.data_ptr() for t in specs], frames, F, self.num_iters, init,
+                             [t.data_ptr() for t in masks])
+        torch.cuda.current_stream().synchronize()  # specs must outlive the launches
+        return masks
+
+    def estimate(self, utts):
+        """utts: list of C x N float32 numpy arrays -> list of T x F float32 masks."""
+        out = [None] * len(utts)
+        groups = {}
+        for i, s in enumerate(utts):
+            s = np.asarray(s)
+            groups.setdefault(1 if s.ndim == 1 else s.shape[0], []).append(i)
+        for C, idx in groups.items():
+            audio = []
+            for i in idx:
+                s = np.ascontiguousarray(utts[i], dtype=np.float32)
+                audio.append(self.torch.from_numpy(s[None] if s.ndim == 1 else s).to(self.dev))
+            for i, m in zip(idx, self.estimate_device(audio)):
+                out[i] = m.cpu().numpy()
+        return out

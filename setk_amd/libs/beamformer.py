@@ -24,7 +24,7 @@ from .. import _ffi
 from .utils import EPSILON
 
 __all__ = [
-    "compute_covar", "solve_pevd", "do_ban", "rank1_constraint", "Beamformer",
+    "compute_covar", "solve_pevd", "do_ban", "rank1_constraint", "Beamformer", "FixedBeamformer",
     "SupervisedBeamformer", "MvdrBeamformer", "MpdrBeamformer", "PmwfBeamformer",
     "GevdBeamformer", "OnlineSupervisedBeamformer", "OnlineMvdrBeamformer",
     "OnlineGevdBeamformer"
@@ -120,6 +120,19 @@ class Beamformer(object):
         enh = out.T  # F x T view
         wide = weight.dtype == np.complex128 or obs.dtype == np.complex128
         return enh.astype(np.complex128) if wide else enh
+
+
+class FixedBeamformer(Beamformer):
+    """Beamformer with predefined weights F x N (reference :323-340); the
+    geometry that produces such weights (DS / SD steer vectors) is out of scope,
+    the beamforming itself is the device kernel."""
+
+    def __init__(self, weight):
+        super(FixedBeamformer, self).__init__()
+        self.weight = weight
+
+    def run(self, obs):
+        return self.beamform(self.weight, obs)
 
 
 class SupervisedBeamformer(Beamformer):

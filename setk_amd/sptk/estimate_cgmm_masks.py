@@ -14,6 +14,7 @@ import numpy as np
 
 from setk_amd import _ffi
 from setk_amd.dist import Shard
+from setk_amd.engine import CgmmEstimator
 from setk_amd.libs.cluster import CgmmTrainer
 from setk_amd.libs.data_handler import NumpyReader, NumpyWriter, ScriptReader, SpectrogramReader
 from setk_amd.libs.opts import StftParser, strtobool
@@ -40,6 +41,8 @@ def build_parser():
                         help="If true, update alpha in M-step")
     parser.add_argument("--mask-format", type=str, dest="fmt", default="numpy",
                         choices=["kaldi", "numpy"], help="Mask storage format")
+    parser.add_argument("--batch-utts", type=int, default=32,
+                        help="[setk_amd] utterances per EM launch (n_fft = 512, no --init-mask)")
     return parser
 
 
@@ -50,6 +53,9 @@ def run(args):
                        round_power_of_two=args.round_power_of_two, window=args.window,
                        center=args.center, transpose=False)
     shard = Shard()
+    n_fft = 2**int(np.ceil(np.log2(args.frame_len))) if args.round_power_of_two else args.frame_len
+    if n_fft == 512 and not args.init_mask:
+        return run_batched(args, shard)
     reader = SpectrogramReader(args.wav_scp, **stft_kwargs)
     MaskReader = {"numpy": NumpyReader, "kaldi": ScriptReader}
     init_reader = MaskReader[args.fmt](args.init_mask) if args.init_mask else None
@@ -72,6 +78,47 @@ def run(args):
             num_done += 1
             writer.write(key, masks[0].astype(np.float32))
             logger.info(f"Training utterance {key} ... Done")
+    shard.barrier()
+    if shard.world > 1:
+        num_done = int(round(shard.sum_counts([num_done])[0]))
+    if shard.rank == 0:
+        logger.info(f"Train {num_done:d} utterances over {len(reader):d}")
+    shard.close()
+
+
+def run_batched(args, shard):
+    """Fast path: waves in, masks out, STFT + EM for a batch of utterances on the GPU."""
+    from setk_amd.libs.data_handler import WaveReader
+    reader = WaveReader(args.wav_scp)
+    est = CgmmEstimator(frame_len=args.frame_len, frame_hop=args.frame_hop,
+                        center=bool(args.center), round_power_of_two=True, window=args.window,
+                        num_iters=args.num_iters,
+                        device=shard.device if shard.world > 1 else None)
+    num_done = 0
+    with NumpyWriter(args.dst_dir) as writer:
+        dst_dir = Path(args.dst_dir)
+        pending = []
+
+        def flush():
+            nonlocal num_done
+            if not pending:
+                return
+            masks = est.estimate([s for _, s in pending])
+            for (key, _), m in zip(pending, masks):
+                writer.write(key, m.astype(np.float32))
+                logger.info(f"Training utterance {key} ... Done")
+                num_done += 1
+            pending.clear()
+
+        for key in shard.assign(reader.index_keys):
+            if (dst_dir / f"{key}.npy").exists():
+                logger.info(f"Training utterance {key} ... Skip")
+                continue
+            samps = reader.read(key)
+            pending.append((key, samps[None] if samps.ndim == 1 else samps))
+            if len(pending) >= args.batch_utts:
+                flush()
+        flush()
     shard.barrier()
     if shard.world > 1:
         num_done = int(round(shard.sum_counts([num_done])[0]))

@@ -95,3 +95,23 @@ def test_cgmm_cli_then_mvdr_cli(tmp_path):
     sr, y = scipy.io.wavfile.read(os.path.join(td, "enh", "u.wav"))
     ref = o.enhance_utterance(samps, mask, kind="mvdr", gauge=True)
     assert rms(y.astype(np.float64) / 32767, ref) / rms(ref) < 2e-3
+
+
+def test_cgmm_batched_ragged_equals_single():
+    """Several utterances of different length per EM launch == one at a time."""
+    from setk_amd.engine import CgmmEstimator
+    from setk_amd.libs.cluster import CgmmTrainer
+    lens = [9000, 20000, 5000, 14001]
+    utts = [o.synth_utterance(110 + i, 6, n) for i, n in enumerate(lens)]
+    est = CgmmEstimator(num_iters=6)
+    masks = est.estimate(utts)
+    from setk_amd.libs.data_handler import device_stft
+    for u, m in zip(utts, masks):
+        # same (device) spectrogram for both paths: EM is sensitive to 1e-7 input
+        # differences near the decision boundary
+        obs = np.transpose(device_stft(u, 512, 256, True, True, "hann"), (0, 2, 1))
+        single = CgmmTrainer(obs, 2).train(6)[0].T
+        assert m.shape == single.shape
+        assert np.max(np.abs(m - single)) < 1e-5
+        ref = o.cgmm_masks(o.multichannel_stft(u, transpose=False, **STFT_KW), 6)
+        assert np.mean(np.abs(m - ref)) < 2e-4
