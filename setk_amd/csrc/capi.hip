@@ -915,7 +915,7 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
         if (T < 0) return T;
         total_frames += T;
     }
-    constexpr int TBq[9] = {0, 8, 8, 8, 4, 6, 5, 4, 4};
+    constexpr int TBq[9] = {0, 8, 8, 8, 8, 6, 5, 4, 4};
     std::vector<int> all_frames(n_utts);
     for (int u = 0; u < n_utts; ++u) all_frames[u] = setk_stft_num_frames(h, num_samples[u]);
     const int target1 = choose_target(all_frames, h->p1_items, TBq[C], TBq[C] * 8);

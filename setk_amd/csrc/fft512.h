@@ -108,6 +108,39 @@ SETK_DEV void fft256_stage_b(cf (&v)[16], const cf* slot, int la, int ls) {
     dft16<DIR>(v);
 }
 
+// Padded-transpose variants: the 16x16 exchange uses row stride 17 instead of
+// the XOR swizzle, so every LDS address is one base register plus an immediate
+// (the swizzle costs ~30 loop-invariant address registers, which matters at a
+// 128-VGPR budget).  The slot must hold kSlotPad entries and consecutive slots
+// must be an odd multiple of 128 bytes apart for the two quad-rows of a
+// 32-lane LDS group to use complementary banks.
+constexpr int kSlotPad = 16 * 17;  // 272 complex entries
+
+template <int DIR>
+SETK_DEV void fft256_stage_a_pad(cf (&v)[16], cf* slot, const cf* tw, int la) {
+    dft16<DIR>(v);
+    cf* dst = slot + la;
+    const cf* twl = tw + la;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        cf t = v[dft16_pos(q)];
+        if (q) {
+            cf w = twl[q * 16];
+            if (DIR > 0) w.y = -w.y;
+            t = cmul(t, w);
+        }
+        dst[q * 17] = t;
+    }
+}
+
+template <int DIR>
+SETK_DEV void fft256_stage_b_pad(cf (&v)[16], const cf* slot, int la) {
+    const cf* src = slot + la * 17;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) v[n] = src[n];
+    dft16<DIR>(v);
+}
+
 // Hermitian split of the packed transform: from Zk = Z[k], Zm = Z[256-k]
 // (Z[256] == Z[0]) produce X[k] and X[256-k] of the 512-point real DFT.
 // w = exp(-2 pi i k / 512).  The 1/2 of E = (Zk + conj Zm)/2, O = (Zk - conj Zm)/2i

@@ -111,9 +111,13 @@ SETK_DEV float qr_partner(float x) {
 // owns Z[la + 16 kb]; the mirror bin 256 - k of k = la + 16 m lives in lane
 // (16 - la) & 15, register 15 - m (lane 0: its own register 16 - m), fetched with
 // two DPP moves instead of an LDS round trip.  Writes X[k], X[256-k], m < 8.
+template <bool PAD = false>
 SETK_DEV void qr_stage23(cf* slot, float* nyq, const cf* tw5, int la, int ls) {
     cf v[16];
-    fft256_stage_b<-1>(v, slot, la, ls);
+    if (PAD)
+        fft256_stage_b_pad<-1>(v, slot, la);
+    else
+        fft256_stage_b<-1>(v, slot, la, ls);
     const bool lane0 = (la == 0);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -459,6 +463,274 @@ __global__ __launch_bounds__(256 * NQ, NQ) void stft_covar_kernel(Pass1Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Wave-specialised variant: a 1024-thread workgroup = 8 transform waves + 8
+// covariance waves (4 waves per SIMD at <= 128 VGPRs: each role alone fits
+// the budget that the merged roles overflow).  Tile k+1 is transformed into one
+// half of the LDS tile while tile k is folded from the other; one s_barrier
+// per tile.  Mask rows go global -> registers (one tile ahead) in the
+// covariance waves; the Nyquist-bin weights travel with the transforms.
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr int ws_tile_frames(int c) { return (32 / c) < 8 ? (32 / c) : 8; }
+
+SETK_DEV void wg_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int C, bool DUMP>
+__global__ __launch_bounds__(1024, 4) void stft_covar_ws_kernel(Pass1Args a) {
+    constexpr int NT = 1024;
+    constexpr int TB = ws_tile_frames(C);
+    constexpr int NF = TB * C;            // transforms per tile (<= 32)
+    constexpr int NP = npairs(C);
+    constexpr int NPQ = (NP + 1) / 2;     // accumulator pairs per covariance thread
+    constexpr int NS = 32 / NF;           // producer sets
+    constexpr int F = kBins, FP = kBinsPad;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SL = kSlotPad;                      // slot stride (padded transpose)
+    cf* xt0 = reinterpret_cast<cf*>(smem);            // [2][NF][SL]
+    cf* tw = xt0 + 2 * NF * SL;                       // [16][16]
+    cf* tw5 = tw + 256;                               // [128]
+    float* win = reinterpret_cast<float*>(tw5 + 128);  // [512]
+    float* xn0 = win + kNfft;                         // [2][32] nyquist bins (real)
+    float* nym = xn0 + 64;                            // [2][2][8] bin-256 weights (speech|noise)
+    float* red = nym + 32;                            // [16]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WorkItem wi = a.items[blockIdx.x];
+    const UttDesc ud = a.utts[wi.utt];
+    const int n_samp = ud.num_samples;
+    const int T = ud.num_frames;
+    const bool clamp = (a.flags & 0x2) != 0;
+    const bool has_mn = ud.mask_n != nullptr;
+
+    if (tid < 256) tw[tid] = a.tw256[tid];
+    if (tid < 128) tw5[tid] = a.tw512[tid];
+    if (tid < kNfft) win[tid] = a.window[tid];
+
+    float mx = 0.f;
+    // covariance-role state (declared here: the epilogue stores it)
+    const int ct = tid - 512;
+    const int f = ct & 255, q = (ct >> 8) & 1;
+    cf acc_s[NPQ], acc_n[NPQ];
+    float sum_s = 0.f, sum_n = 0.f, ny_acc = 0.f;
+    const bool ny_active = !DUMP && ct >= 0 && ct < 2 * NP + 2;
+
+    if (wave < 8) {
+#ifndef SETK_ONLY_CONS
+        // ================= transform waves =================
+        const int la = tid & 15, grp = tid >> 4;
+        const int my_set = grp / NF;
+        const int my_i = grp - my_set * NF;
+        const int my_tt = my_i / C, my_c = my_i - my_tt * C;
+        const bool producer = my_set < NS;
+        const float* my_audio = ud.audio + (size_t)my_c * n_samp;
+        const float2* w2 = reinterpret_cast<const float2*>(win);
+        const bool ny_lane = !DUMP && producer && my_c == 0 && la == 0;
+
+        cf raw[16];
+        float raw_ms = 0.f, raw_mn = 0.f;
+        bool raw_ok = false;
+        auto fetch = [&](int tb_tile) {
+            const int t = tb_tile + my_tt;
+            raw_ok = t < wi.t1;
+            load_raw(raw, my_audio, n_samp, t * a.g.hop - a.g.pad, la, raw_ok);
+            if (ny_lane) {
+                raw_ms = 0.f;
+                raw_mn = 0.f;
+                if (raw_ok) {
+                    raw_ms = ud.mask_s[(size_t)t * F + 256];
+                    if (has_mn) raw_mn = ud.mask_n[(size_t)t * F + 256];
+                }
+            }
+        };
+        auto produce = [&](int b, int tb_next_own) {
+            cf* slot = xt0 + (b * NF + my_i) * SL;
+            cf v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float2 d = raw[j];
+                const float2 w = w2[la + 16 * j];
+                mx = fmaxf(mx, fmaxf(fabsf(d.x), fabsf(d.y)));
+                v[j] = make_float2(d.x * w.x, d.y * w.y);
+            }
+            if (ny_lane) {
+                const float s = clamp ? fminf(raw_ms, 1.f) : raw_ms;
+                nym[(b * 2 + 0) * 8 + my_tt] = s;
+                nym[(b * 2 + 1) * 8 + my_tt] = raw_ok ? (has_mn ? raw_mn : 1.f - s) : 0.f;
+            }
+            fft256_stage_a_pad<-1>(v, slot, tw, la);
+            __builtin_amdgcn_wave_barrier();
+            qr_stage23<true>(slot, xn0 + b * 32 + my_i, tw5, la, 0);
+            // the next frame is requested only now: held across the transform it
+            // would push the role past 128 VGPRs (the spill reloads then serialise
+            // behind the very loads they make room for)
+            if (tb_next_own < wi.t1) fetch(tb_next_own);
+        };
+
+        wg_barrier();  // tables ready
+        if (producer) fetch(wi.t0 + my_set * TB);
+        if (producer && my_set == 0) produce(0, wi.t0 + NS * TB);
+        wg_barrier();
+        int buf = 0, next_set = 1 % NS;
+#pragma unroll 1
+        for (int tb = wi.t0; tb < wi.t1; tb += TB, buf ^= 1) {
+            const bool prod = producer && (my_set == next_set) && (tb + TB < wi.t1);
+            next_set = (next_set + 1 == NS) ? 0 : next_set + 1;
+            if (prod) produce(buf ^ 1, tb + TB + NS * TB);
+            wg_barrier();
+        }
+#endif
+    } else {
+#ifndef SETK_ONLY_PROD
+        // ================= covariance waves =================
+#pragma unroll
+        for (int e = 0; e < NPQ; ++e) {
+            acc_s[e] = make_float2(0.f, 0.f);
+            acc_n[e] = make_float2(0.f, 0.f);
+        }
+        // nyquist-bin items (bin 256 is purely real): covariance threads [0, 2*NP+2)
+        int ny_i = 0, ny_j = 0;
+        {
+            const int e = (ct < NP) ? ct : ct - NP;
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < C; ++i)
+#pragma unroll
+                for (int j = i; j < C; ++j) {
+                    if (cnt == e) { ny_i = i; ny_j = j; }
+                    ++cnt;
+                }
+        }
+        float cur_s[TB], cur_n[TB], nxt_s[TB], nxt_n[TB];
+        auto fetch_masks = [&](int tb_tile, float (&ms)[TB], float (&mn)[TB]) {
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt) {
+                const int t = tb_tile + tt;
+                float vs = 0.f, vn = 0.f;
+                if (t < wi.t1) {
+                    vs = ud.mask_s[(size_t)t * F + f];
+                    if (has_mn) vn = ud.mask_n[(size_t)t * F + f];
+                }
+                ms[tt] = vs;
+                mn[tt] = vn;
+            }
+        };
+        if (!DUMP) fetch_masks(wi.t0, cur_s, cur_n);
+        wg_barrier();  // tables ready
+        wg_barrier();  // tile 0 transformed
+        int buf = 0;
+#pragma unroll 1
+        for (int tb = wi.t0; tb < wi.t1; tb += TB, buf ^= 1) {
+            const cf* xt = xt0 + buf * NF * SL;
+            const float* xn = xn0 + buf * 32;
+            if (DUMP) {
+                // spec[c][t][f], f fastest
+                for (int i = q; i < NF; i += 2) {
+                    const int tt = i / C, c = i - tt * C;
+                    const int t = tb + tt;
+                    if (t < wi.t1) {
+                        float2* dst =
+                            reinterpret_cast<float2*>(a.spec_dump) + ((size_t)c * T + t) * F;
+                        dst[f] = xt[i * SL + f];
+                        if (f == 0) dst[256] = make_float2(xn[i], 0.f);
+                    }
+                }
+            } else {
+                if (tb + TB < wi.t1) fetch_masks(tb + TB, nxt_s, nxt_n);
+#pragma unroll
+                for (int tt = 0; tt < TB; ++tt) {
+                    cf x[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) x[c] = xt[(tt * C + c) * SL + f];
+                    const bool fvalid = tb + tt < wi.t1;
+                    const float ws = clamp ? fminf(cur_s[tt], 1.f) : cur_s[tt];
+                    const float wn = fvalid ? (has_mn ? cur_n[tt] : 1.f - ws) : 0.f;
+                    if (q == 0) {
+                        sum_s += ws;
+                        sum_n += wn;
+                        accumulate_pairs<C, 0, NP / 2>(x, ws, wn, acc_s, acc_n);
+                    } else {
+                        accumulate_pairs<C, NP / 2, NP>(x, ws, wn, acc_s, acc_n);
+                    }
+                    if (ny_active) {
+                        const float prod_ny =
+                            (ct < 2 * NP) ? xn[tt * C + ny_i] * xn[tt * C + ny_j] : 1.f;
+                        const bool speech = (ct < NP) || (ct == 2 * NP);
+                        const float w256 = nym[(buf * 2 + (speech ? 0 : 1)) * 8 + tt];
+                        ny_acc = fmaf(w256, prod_ny, ny_acc);
+                    }
+                }
+#pragma unroll
+                for (int tt = 0; tt < TB; ++tt) {
+                    cur_s[tt] = nxt_s[tt];
+                    cur_n[tt] = nxt_n[tt];
+                }
+            }
+            wg_barrier();
+        }
+#endif
+    }
+
+    if (!DUMP) {
+        // ---- max |audio| (the renorm target, WaveReader.maxabs) ----
+        if (wi.last) {
+            const int covered = (T - 1) * a.g.hop - a.g.pad + kNfft;
+            for (int c = 0; c < C; ++c)
+                for (int i = covered + tid; i < n_samp; i += NT)
+                    mx = fmaxf(mx, fabsf(ud.audio[(size_t)c * n_samp + i]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            float bm = red[0];
+#pragma unroll
+            for (int w = 1; w < NT / 64; ++w) bm = fmaxf(bm, red[w]);
+            atomicMax(a.norm_bits + wi.utt, __float_as_uint(bm));
+        }
+        if (wave >= 8) {
+            float* P = a.partials + (size_t)wi.part * nplanes_partial(C) * FP;
+            if (q == 0) {
+                store_pairs<C, 0, NP / 2>(P, f, acc_s, acc_n);
+                P[(4 * NP + 0) * FP + f] = sum_s;
+                P[(4 * NP + 1) * FP + f] = sum_n;
+            } else {
+                store_pairs<C, NP / 2, NP>(P, f, acc_s, acc_n);
+            }
+            if (ny_active) {
+                if (ct < NP) {
+                    P[(0 * NP + ct) * FP + 256] = ny_acc;
+                    P[(1 * NP + ct) * FP + 256] = 0.f;
+                } else if (ct < 2 * NP) {
+                    P[(2 * NP + ct - NP) * FP + 256] = ny_acc;
+                    P[(3 * NP + ct - NP) * FP + 256] = 0.f;
+                } else {
+                    P[(4 * NP + ct - 2 * NP) * FP + 256] = ny_acc;
+                }
+            }
+        }
+    }
+}
+
+template <int C, bool DUMP>
+static hipError_t launch_pass1_ws_t(const Pass1Args& a, int n_items, hipStream_t s) {
+    constexpr int NF = ws_tile_frames(C) * C;
+    const size_t lds = (size_t)2 * NF * kSlotPad * sizeof(cf) + 256 * sizeof(cf) + 128 * sizeof(cf) +
+                       kNfft * sizeof(float) + (64 + 32 + 16) * sizeof(float);
+    auto k = stft_covar_ws_kernel<C, DUMP>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(n_items), dim3(1024), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int C, bool DUMP, int NQ>
 static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s) {
     constexpr int TB = tile_frames(C), NF = TB * C;
@@ -483,8 +755,16 @@ static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s)
 hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s) {
     // NQ = 2 (512 threads, 2 waves/SIMD).  NQ = 4 (1024 threads, <= 128 VGPRs)
     // was measured 3x slower on MI355X: spills plus 4x redundant tile reads.
+    static const bool ws = [] {
+        const char* e = getenv("SETK_P1_WS");
+        return !e || atoi(e) != 0;
+    }();
 #define SETK_CASE(c)                                                                      \
     case c:                                                                               \
+        if (ws) {                                                                         \
+            if (dump) return launch_pass1_ws_t<c, true>(a, n_items, s);                    \
+            return launch_pass1_ws_t<c, false>(a, n_items, s);                             \
+        }                                                                                 \
         if (dump) return launch_pass1_t<c, true, 2>(a, n_items, s);                        \
         return launch_pass1_t<c, false, 2>(a, n_items, s);
     switch (C) {
