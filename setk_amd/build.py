@@ -40,10 +40,16 @@ def build_library(force=False, verbose=False):
              # SLP packing into v_pk_* costs more moves than it saves here (measured:
              # stft_covar 2.27 -> 1.86 ms, beamform_istft 1.46 -> 1.30 ms)
              "-fno-slp-vectorize",
-             # the streaming kernels are long straight-line blocks: the max-ILP
-             # machine scheduler measured 1-2 % faster than the default
-             "-mllvm", "-amdgpu-sched-strategy=max-ilp",
              "-Wno-unused-result"] + os.environ.get("SETK_HIPCC_FLAGS", "").split()
+    # pass 2 is one long straight-line block per frame: the max-ILP machine
+    # scheduler measured 1-2 % faster there.  Pass 1 runs at a 128-VGPR budget
+    # where the same scheduler spills (measured 1.14 vs 1.03 ms), so it keeps the
+    # default.
+    extra = {"pass2.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+             "solve.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+             "modular.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+             "cgmm.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+             "capi.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
     jobs = []
     objs = []
     for src in SOURCES:
@@ -51,7 +57,7 @@ def build_library(force=False, verbose=False):
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([_hipcc()] + flags + ["-c", s, "-o", o])
+            jobs.append([_hipcc()] + flags + extra.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

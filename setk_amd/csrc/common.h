@@ -61,6 +61,7 @@ struct Pass1Args {
     float* spec_dump;       // DUMP mode: [C][T][F]
     StftGeom g;
     int flags;
+    unsigned long long* trace;  // SETK_TRACE builds: [items][16 waves][16] cycle sums
 };
 
 struct FinalizeArgs {

@@ -16,6 +16,19 @@ typedef float2 cf;
 
 #define SETK_DEV __device__ __forceinline__
 
+// Pointers fetched from descriptor tables in memory are generic to the
+// compiler, and generic loads (flat_load) count against BOTH vmcnt and lgkmcnt:
+// every LDS wait then also waits for the streaming loads in flight.  gptr()
+// states that the pointer is global memory so that global_load is emitted.
+#define SETK_GLOBAL __attribute__((address_space(1)))
+typedef const SETK_GLOBAL float* gcfloat_p;
+typedef float v2f __attribute__((ext_vector_type(2)));  // float2 is a class: no AS-qualified copies
+typedef const SETK_GLOBAL v2f* gcfloat2_p;
+template <class T>
+SETK_DEV const SETK_GLOBAL T* gptr(const T* p) {
+    return (const SETK_GLOBAL T*)p;
+}
+
 SETK_DEV cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
 SETK_DEV cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
 SETK_DEV cf cmul(cf a, cf b) {

@@ -35,7 +35,7 @@ SETK_DEV int reflect_index(int i, int n) {
 // Load one windowed frame as 16 packed complex points per lane:
 // v[j] = (x[s+2n] w[2n], x[s+2n+1] w[2n+1]),  n = la + 16 j.
 // mx accumulates max |x| over the raw samples.
-SETK_DEV void load_frame(cf (&v)[16], const float* __restrict__ x, int n_samp, int s,
+SETK_DEV void load_frame(cf (&v)[16], gcfloat_p x, int n_samp, int s,
                          int la, const float* win, bool valid, float& mx) {
     const float2* w2 = reinterpret_cast<const float2*>(win);
     if (!valid) {
@@ -44,13 +44,13 @@ SETK_DEV void load_frame(cf (&v)[16], const float* __restrict__ x, int n_samp, i
         return;
     }
     const bool interior = (s >= 0) && (s + kNfft <= n_samp) &&
-                          ((reinterpret_cast<uintptr_t>(x + s) & 7) == 0);
+                          ((((uintptr_t)(x + s)) & 7) == 0);
     if (interior) {
-        const float2* p = reinterpret_cast<const float2*>(x + s);
+        gcfloat2_p p = (gcfloat2_p)(x + s);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int n = la + 16 * j;
-            const float2 d = p[n];
+            const v2f d = p[n];
             const float2 w = w2[n];
             mx = fmaxf(mx, fmaxf(fabsf(d.x), fabsf(d.y)));
             v[j] = make_float2(d.x * w.x, d.y * w.y);
@@ -69,7 +69,7 @@ SETK_DEV void load_frame(cf (&v)[16], const float* __restrict__ x, int n_samp, i
 }
 
 // raw (un-windowed) frame points: v[j] = (x[s+2n], x[s+2n+1]), n = la + 16 j
-SETK_DEV void load_raw(cf (&v)[16], const float* __restrict__ x, int n_samp, int s, int la,
+SETK_DEV void load_raw(cf (&v)[16], gcfloat_p x, int n_samp, int s, int la,
                        bool valid) {
     if (!valid) {
 #pragma unroll
@@ -77,11 +77,14 @@ SETK_DEV void load_raw(cf (&v)[16], const float* __restrict__ x, int n_samp, int
         return;
     }
     const bool interior = (s >= 0) && (s + kNfft <= n_samp) &&
-                          ((reinterpret_cast<uintptr_t>(x + s) & 7) == 0);
+                          ((((uintptr_t)(x + s)) & 7) == 0);
     if (interior) {
-        const float2* p = reinterpret_cast<const float2*>(x + s);
+        gcfloat2_p p = (gcfloat2_p)(x + s);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = p[la + 16 * j];
+        for (int j = 0; j < 16; ++j) {
+            const v2f d = p[la + 16 * j];
+            v[j] = make_float2(d.x, d.y);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256 * NQ, NQ) void stft_covar_kernel(Pass1Args a) {
     // tile): while tile k is consumed from buffer k&1, tile k+1 is transformed
     // into the other buffer by producer set (k+1) % NS, its three LDS-separated
     // stages interleaved with the consume frames of the same waves.
-    const float* my_audio = ud.audio + (size_t)my_c * n_samp;
+    gcfloat_p my_audio = gptr(ud.audio) + (size_t)my_c * n_samp;
     const float2* w2 = reinterpret_cast<const float2*>(win);
     __syncthreads();  // tables ready
 
@@ -294,8 +297,8 @@ __global__ __launch_bounds__(256 * NQ, NQ) void stft_covar_kernel(Pass1Args a) {
     float mreg_s[MKL], mreg_n[MKL];
     auto fetch_masks = [&](int tb_tile) {
         const int nvalid = min(TB, wi.t1 - tb_tile) * F;
-        const float* src_s = ud.mask_s + (size_t)tb_tile * F;
-        const float* src_n = has_mn ? ud.mask_n + (size_t)tb_tile * F : nullptr;
+        gcfloat_p src_s = gptr(ud.mask_s) + (size_t)tb_tile * F;
+        gcfloat_p src_n = gptr(ud.mask_n) + (size_t)tb_tile * F;
 #pragma unroll
         for (int r = 0; r < MKL; ++r) {
             const int i = tid + r * NT;
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(256 * NQ, NQ) void stft_covar_kernel(Pass1Args a) {
             const int covered = (T - 1) * a.g.hop - a.g.pad + kNfft;
             for (int c = 0; c < C; ++c)
                 for (int i = covered + tid; i < n_samp; i += NT)
-                    mx = fmaxf(mx, fabsf(ud.audio[(size_t)c * n_samp + i]));
+                    mx = fmaxf(mx, fabsf(gptr(ud.audio)[(size_t)c * n_samp + i]));
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_ws_kernel(Pass1Args a) {
         const int my_i = grp - my_set * NF;
         const int my_tt = my_i / C, my_c = my_i - my_tt * C;
         const bool producer = my_set < NS;
-        const float* my_audio = ud.audio + (size_t)my_c * n_samp;
+        gcfloat_p my_audio = gptr(ud.audio) + (size_t)my_c * n_samp;
         const float2* w2 = reinterpret_cast<const float2*>(win);
         const bool ny_lane = !DUMP && producer && my_c == 0 && la == 0;
 
@@ -538,13 +541,17 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_ws_kernel(Pass1Args a) {
         auto fetch = [&](int tb_tile) {
             const int t = tb_tile + my_tt;
             raw_ok = t < wi.t1;
+#ifdef SETK_NO_GLOAD
+            load_raw(raw, my_audio, n_samp, t * a.g.hop - a.g.pad, la, raw_ok && n_samp < 0);
+#else
             load_raw(raw, my_audio, n_samp, t * a.g.hop - a.g.pad, la, raw_ok);
+#endif
             if (ny_lane) {
                 raw_ms = 0.f;
                 raw_mn = 0.f;
                 if (raw_ok) {
-                    raw_ms = ud.mask_s[(size_t)t * F + 256];
-                    if (has_mn) raw_mn = ud.mask_n[(size_t)t * F + 256];
+                    raw_ms = gptr(ud.mask_s)[(size_t)t * F + 256];
+                    if (has_mn) raw_mn = gptr(ud.mask_n)[(size_t)t * F + 256];
                 }
             }
         };
@@ -565,13 +572,23 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_ws_kernel(Pass1Args a) {
             }
             fft256_stage_a_pad<-1>(v, slot, tw, la);
             __builtin_amdgcn_wave_barrier();
+#ifdef SETK_FETCH_MID
+            __builtin_amdgcn_sched_barrier(0);
+            if (tb_next_own < wi.t1) fetch(tb_next_own);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             qr_stage23<true>(slot, xn0 + b * 32 + my_i, tw5, la, 0);
             // the next frame is requested only now: held across the transform it
             // would push the role past 128 VGPRs (the spill reloads then serialise
             // behind the very loads they make room for)
+#ifndef SETK_FETCH_MID
             if (tb_next_own < wi.t1) fetch(tb_next_own);
+#endif
         };
 
+#ifdef SETK_PROD_PRIO
+        __builtin_amdgcn_s_setprio(SETK_PROD_PRIO);
+#endif
         wg_barrier();  // tables ready
         if (producer) fetch(wi.t0 + my_set * TB);
         if (producer && my_set == 0) produce(0, wi.t0 + NS * TB);
@@ -613,8 +630,8 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_ws_kernel(Pass1Args a) {
                 const int t = tb_tile + tt;
                 float vs = 0.f, vn = 0.f;
                 if (t < wi.t1) {
-                    vs = ud.mask_s[(size_t)t * F + f];
-                    if (has_mn) vn = ud.mask_n[(size_t)t * F + f];
+                    vs = gptr(ud.mask_s)[(size_t)t * F + f];
+                    if (has_mn) vn = gptr(ud.mask_n)[(size_t)t * F + f];
                 }
                 ms[tt] = vs;
                 mn[tt] = vn;
@@ -682,7 +699,7 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_ws_kernel(Pass1Args a) {
             const int covered = (T - 1) * a.g.hop - a.g.pad + kNfft;
             for (int c = 0; c < C; ++c)
                 for (int i = covered + tid; i < n_samp; i += NT)
-                    mx = fmaxf(mx, fabsf(ud.audio[(size_t)c * n_samp + i]));
+                    mx = fmaxf(mx, fabsf(gptr(ud.audio)[(size_t)c * n_samp + i]));
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -731,6 +748,439 @@ static hipError_t launch_pass1_ws_t(const Pass1Args& a, int n_items, hipStream_t
     return hipGetLastError();
 }
 
+// ---- Hermitian pairs split over the two covariance halves -------------------
+// Half H owns the diagonals (i, i) with i % 2 == H (real: one accumulator per
+// mask) and every other off-diagonal pair of the (i < j) enumeration.  Keeping
+// the diagonals apart saves their imaginary accumulators (8 VGPRs at C = 8).
+// Planes in the partial slab stay in the global (i <= j) order: pair_index()
+// of common.h.
+template <int C>
+struct PairSplit {
+    static constexpr int ND = (C + 1) / 2;                 // diagonals per half (max)
+    static constexpr int NO = (C * (C - 1) / 2 + 1) / 2;   // off-diagonal pairs per half (max)
+};
+
+template <int C, int H>
+SETK_DEV void accumulate_half(const cf (&x)[C], float ws, float wn, float* ds, float* dn, cf* os,
+                              cf* on) {
+#pragma unroll
+    for (int i = H; i < C; i += 2) {
+        const float p = fmaf(x[i].x, x[i].x, x[i].y * x[i].y);
+        ds[i / 2] = fmaf(ws, p, ds[i / 2]);
+        dn[i / 2] = fmaf(wn, p, dn[i / 2]);
+    }
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+#pragma unroll
+        for (int j = i + 1; j < C; ++j) {
+            if ((k & 1) == H) {
+                const cf p = cmulc(x[i], x[j]);
+                os[k / 2].x = fmaf(ws, p.x, os[k / 2].x);
+                on[k / 2].x = fmaf(wn, p.x, on[k / 2].x);
+                os[k / 2].y = fmaf(ws, p.y, os[k / 2].y);
+                on[k / 2].y = fmaf(wn, p.y, on[k / 2].y);
+            }
+            ++k;
+        }
+}
+
+template <int C, int H>
+SETK_DEV void store_half(float* P, int f, const float* ds, const float* dn, const cf* os,
+                         const cf* on) {
+    constexpr int NP = npairs(C);
+    constexpr int FP = kBinsPad;
+#pragma unroll
+    for (int i = H; i < C; i += 2) {
+        const int e = pair_index(i, i, C);
+        P[(0 * NP + e) * FP + f] = ds[i / 2];
+        P[(1 * NP + e) * FP + f] = 0.f;
+        P[(2 * NP + e) * FP + f] = dn[i / 2];
+        P[(3 * NP + e) * FP + f] = 0.f;
+    }
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+#pragma unroll
+        for (int j = i + 1; j < C; ++j) {
+            if ((k & 1) == H) {
+                const int e = pair_index(i, j, C);
+                P[(0 * NP + e) * FP + f] = os[k / 2].x;
+                P[(1 * NP + e) * FP + f] = os[k / 2].y;
+                P[(2 * NP + e) * FP + f] = on[k / 2].x;
+                P[(3 * NP + e) * FP + f] = on[k / 2].y;
+            }
+            ++k;
+        }
+}
+
+// ---------------------------------------------------------------------------
+// v3: wave-specialised, with the raw samples DMA'd straight into LDS.
+//
+// The transform of a frame is split over TWO tile periods and the frames'
+// samples are fetched global -> LDS (global_load_lds_dwordx4, no registers)
+// into the very slot the spectrum will occupy, one period before they are
+// needed.  Four X buffers of TB = 16/C frames rotate:
+//   period it:  covariance waves fold tile it           (buffer  it      & 3)
+//               set  (it+1)&1 : stage b + split, tile it+1 (buffer (it+1) & 3)
+//                               then DMA for tile it+3   (buffer (it+3) & 3,
+//                               folded during period it-1, free again)
+//               set   it   &1 : window + stage a, tile it+2 (buffer (it+2) & 3,
+//                               its DMA was issued in period it-1)
+// Each set is 4 waves = 16 quad-rows; one s_barrier per period.  No global
+// load sits on a transform's critical path, and the transform waves need no
+// prefetch registers.
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr int v3_tile_frames(int c) { return (16 / c) < 8 ? (16 / c) : 8; }
+
+#define SETK_LDS __attribute__((address_space(3)))
+
+template <int C, bool DUMP>
+__global__ __launch_bounds__(1024, 4) void stft_covar_v3_kernel(Pass1Args a) {
+    constexpr int NT = 1024;
+    constexpr int TB = v3_tile_frames(C);
+    constexpr int NF = TB * C;            // transforms per tile (<= 16)
+    constexpr int NB = 4;                 // X buffers
+    constexpr int NP = npairs(C);
+    constexpr int ND = PairSplit<C>::ND, NO = PairSplit<C>::NO;
+    constexpr int F = kBins, FP = kBinsPad;
+    constexpr int SL = kSlotPad;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* xt0 = reinterpret_cast<cf*>(smem);            // [NB][NF][SL]
+    cf* tw = xt0 + NB * NF * SL;                      // [16][16]
+    cf* tw5 = tw + 256;                               // [128]
+    float* win = reinterpret_cast<float*>(tw5 + 128);  // [512]
+    float* xn0 = win + kNfft;                         // [NB][16] nyquist bins (real)
+    float* nym = xn0 + NB * 16;                       // [NB][2][8] bin-256 weights
+    float* red = nym + NB * 16;                       // [16]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WorkItem wi = a.items[blockIdx.x];
+    const UttDesc ud = a.utts[wi.utt];
+    const int n_samp = ud.num_samples;
+    const int T = ud.num_frames;
+    const bool clamp = (a.flags & 0x2) != 0;
+    const bool has_mn = ud.mask_n != nullptr;
+    const int ntiles = (wi.t1 - wi.t0 + TB - 1) / TB;
+
+    if (tid < 256) tw[tid] = a.tw256[tid];
+    if (tid < 128) tw5[tid] = a.tw512[tid];
+    if (tid < kNfft) win[tid] = a.window[tid];
+
+#ifdef SETK_TRACE
+    unsigned long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = []() {
+        unsigned long long t;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    };
+#define SETK_T(var) const unsigned long long var = now()
+#define SETK_ACC(k, a, b) tr[k] += (b) - (a)
+#else
+#define SETK_T(var)
+#define SETK_ACC(k, a, b)
+#endif
+    float mx = 0.f;
+    const int ct = tid - 512;
+    const int f = ct & 255, q = (ct >> 8) & 1;
+    float dg_s[ND], dg_n[ND];  // diagonal (real) sums of this half
+    cf of_s[NO > 0 ? NO : 1], of_n[NO > 0 ? NO : 1];
+    // aux0/aux1: mask sums in the q == 0 half; the q == 1 half has them free and
+    // carries the Nyquist-bin items (bin 256 is purely real) in aux0:
+    //   item < NP: speech pair | item < 2 NP: noise pair | 2NP, 2NP+1: mask sums
+    float aux0 = 0.f, aux1 = 0.f;
+    const int ny_item = ct - 256;
+    const bool ny_active = !DUMP && ny_item >= 0 && ny_item < 2 * NP + 2;
+
+    if (wave < 8) {
+        // ================= transform waves =================
+        const int la = tid & 15, lane = tid & 63;
+        const int set = wave >> 2;                 // tiles of this parity
+        const int qi = (tid >> 4) & 15;            // quad-row within the set
+        const bool producer = qi < NF;
+        const int my_tt = qi / C, my_c = qi - my_tt * C;
+        gcfloat_p my_audio = gptr(ud.audio) + (size_t)my_c * n_samp;
+        const float2* w2 = reinterpret_cast<const float2*>(win);
+        const bool ny_lane = !DUMP && producer && my_c == 0 && la == 0;
+        float raw_ms = 0.f, raw_mn = 0.f, nxt_ms = 0.f, nxt_mn = 0.f;
+
+        // frame of tile j handled by this quad-row
+        auto frame_of = [&](int j, int tt) { return wi.t0 + j * TB + tt; };
+        // DMA the frames of tile j (a tile of this wave's set) into their slots;
+        // the whole wave copies each of its four quad-rows' frames (2 KB each).
+        auto issue_dma = [&](int j) {
+            if (j >= ntiles) return;
+            // (mask load first: waiting for it must not wait for the younger DMAs)
+            if (ny_lane) {
+                const int t = frame_of(j, my_tt);
+                nxt_ms = 0.f;
+                nxt_mn = 0.f;
+                if (t < wi.t1) {
+                    nxt_ms = gptr(ud.mask_s)[(size_t)t * F + 256];
+                    if (has_mn) nxt_mn = gptr(ud.mask_n)[(size_t)t * F + 256];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qr = (wave & 3) * 4 + r;  // wave-uniform
+                if (qr < NF) {
+                    const int tt = qr / C, c = qr - tt * C;
+                    const int t = frame_of(j, tt);
+                    const int s = t * a.g.hop - a.g.pad;
+#ifdef SETK_NO_DMA
+                    if (t < wi.t1 && s >= 0 && s + kNfft <= n_samp && n_samp < 0) {
+#else
+                    if (t < wi.t1 && s >= 0 && s + kNfft <= n_samp) {
+#endif
+                        gcfloat_p src = gptr(ud.audio) + (size_t)c * n_samp + s + lane * 4;
+                        SETK_LDS char* dst =
+                            (SETK_LDS char*)(xt0 + ((j & 3) * NF + qr) * SL);
+                        __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(src + 256, dst + 1024, 16, 0, 0);
+                    }
+                }
+            }
+        };
+        // window + first radix-16 + transposed store (in place in the slot)
+        auto phase_a = [&](int j) {
+            if (j >= ntiles || !producer) return;
+            cf* slot = xt0 + ((j & 3) * NF + qi) * SL;
+            const int t = frame_of(j, my_tt);
+            const int s = t * a.g.hop - a.g.pad;
+            const bool valid = t < wi.t1;
+            const bool dma = valid && s >= 0 && s + kNfft <= n_samp;
+            cf v[16];
+            if (dma) {
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) v[jj] = slot[la + 16 * jj];
+            } else {
+                load_raw(v, my_audio, n_samp, s, la, valid);  // edge (reflect) / padding frame
+            }
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const float2 w = w2[la + 16 * jj];
+                mx = fmaxf(mx, fmaxf(fabsf(v[jj].x), fabsf(v[jj].y)));
+                v[jj] = make_float2(v[jj].x * w.x, v[jj].y * w.y);
+            }
+            __builtin_amdgcn_wave_barrier();
+            fft256_stage_a_pad<-1>(v, slot, tw, la);
+        };
+        // second radix-16 + Hermitian split; X[0..255] in the slot, X[256] aside
+        auto phase_b = [&](int j) {
+            if (j >= ntiles || !producer) return;
+            const int b = j & 3;
+            cf* slot = xt0 + (b * NF + qi) * SL;
+            qr_stage23<true>(slot, xn0 + b * 16 + qi, tw5, la, 0);
+            if (ny_lane) {
+                const bool valid = frame_of(j, my_tt) < wi.t1;
+                const float sp = clamp ? fminf(raw_ms, 1.f) : raw_ms;
+                nym[(b * 2 + 0) * 8 + my_tt] = sp;
+                nym[(b * 2 + 1) * 8 + my_tt] = valid ? (has_mn ? raw_mn : 1.f - sp) : 0.f;
+            }
+        };
+
+#ifndef SETK_ONLY_CONS
+        wg_barrier();  // tables ready
+        // periods -3 .. ntiles-1 (see the header); the barrier-free period -3 only
+        // starts the first DMA
+#pragma unroll 1
+        for (int it = -3; it < ntiles; ++it) {
+            const bool b_set = ((it + 1) & 1) == set;  // phase b of tile it+1, DMA of tile it+3
+            SETK_T(t0);
+            if (b_set) {
+                // buffer (it+3)&3 was folded in period it-1: start its DMA first, the
+                // copy then has this whole period to land
+                issue_dma(it + 3);
+                SETK_T(t1);
+                if (it + 1 >= 0) phase_b(it + 1);
+                raw_ms = nxt_ms;
+                raw_mn = nxt_mn;
+                SETK_T(t2);
+                SETK_ACC(0, t0, t1);  // DMA issue
+                SETK_ACC(1, t1, t2);  // stage b + split
+                if (it >= -2) wg_barrier();
+                SETK_T(t3);
+                SETK_ACC(2, t2, t3);  // barrier wait (b set)
+            } else {
+                if (it + 2 >= 0) {
+                    // the DMA of tile it+2 was issued one period ago by this wave
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    SETK_T(t1);
+                    phase_a(it + 2);
+                    SETK_T(t2);
+                    SETK_ACC(3, t0, t1);  // DMA wait
+                    SETK_ACC(4, t1, t2);  // window + stage a
+                }
+                SETK_T(t2b);
+                if (it >= -2) wg_barrier();
+                SETK_T(t3);
+                SETK_ACC(5, t2b, t3);  // barrier wait (a set)
+            }
+        }
+#endif
+    } else {
+#ifndef SETK_ONLY_PROD
+        // ================= covariance waves =================
+#pragma unroll
+        for (int e = 0; e < ND; ++e) dg_s[e] = dg_n[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < NO; ++e) {
+            of_s[e] = make_float2(0.f, 0.f);
+            of_n[e] = make_float2(0.f, 0.f);
+        }
+        int ny_i = 0, ny_j = 0;
+        {
+            const int e = (ny_item < NP) ? ny_item : ny_item - NP;
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < C; ++i)
+#pragma unroll
+                for (int j = i; j < C; ++j) {
+                    if (cnt == e) { ny_i = i; ny_j = j; }
+                    ++cnt;
+                }
+        }
+        // mask rows: global -> registers, two tiles ahead
+        float ma_s[TB], ma_n[TB], mb_s[TB], mb_n[TB];
+        auto fetch_masks = [&](int j, float (&ms)[TB], float (&mn)[TB]) {
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt) {
+                const int t = wi.t0 + j * TB + tt;
+                float vs = 0.f, vn = 0.f;
+                if (t < wi.t1) {
+                    vs = gptr(ud.mask_s)[(size_t)t * F + f];
+                    if (has_mn) vn = gptr(ud.mask_n)[(size_t)t * F + f];
+                }
+                ms[tt] = vs;
+                mn[tt] = vn;
+            }
+        };
+        if (!DUMP) {
+            fetch_masks(0, ma_s, ma_n);
+            fetch_masks(1, mb_s, mb_n);
+        }
+        wg_barrier();  // tables ready
+        wg_barrier();  // period -2
+        wg_barrier();  // period -1
+        // one period: fold tile `it` with its mask rows m, then refill m for tile it+2
+        auto period = [&](int it, float (&m_s)[TB], float (&m_n)[TB]) {
+            SETK_T(c0);
+            const int b = it & 3;
+            const cf* xt = xt0 + b * NF * SL;
+            const float* xn = xn0 + b * 16;
+            const int tb = wi.t0 + it * TB;
+            if (DUMP) {
+                for (int i = q; i < NF; i += 2) {
+                    const int tt = i / C, c = i - tt * C;
+                    const int t = tb + tt;
+                    if (t < wi.t1) {
+                        float2* dst =
+                            reinterpret_cast<float2*>(a.spec_dump) + ((size_t)c * T + t) * F;
+                        dst[f] = xt[i * SL + f];
+                        if (f == 0) dst[256] = make_float2(xn[i], 0.f);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < TB; ++tt) {
+                    cf x[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) x[c] = xt[(tt * C + c) * SL + f];
+                    const bool fvalid = tb + tt < wi.t1;
+                    const float ws = clamp ? fminf(m_s[tt], 1.f) : m_s[tt];
+                    const float wn = fvalid ? (has_mn ? m_n[tt] : 1.f - ws) : 0.f;
+                    if (q == 0) {
+                        aux0 += ws;
+                        aux1 += wn;
+                        accumulate_half<C, 0>(x, ws, wn, dg_s, dg_n, of_s, of_n);
+                    } else {
+                        accumulate_half<C, 1>(x, ws, wn, dg_s, dg_n, of_s, of_n);
+                    }
+                    if (ny_active) {
+                        const float prod_ny =
+                            (ny_item < 2 * NP) ? xn[tt * C + ny_i] * xn[tt * C + ny_j] : 1.f;
+                        const bool speech = (ny_item < NP) || (ny_item == 2 * NP);
+                        const float w256 = nym[(b * 2 + (speech ? 0 : 1)) * 8 + tt];
+                        aux0 = fmaf(w256, prod_ny, aux0);
+                    }
+                }
+                fetch_masks(it + 2, m_s, m_n);
+            }
+            SETK_T(c1);
+            wg_barrier();
+            SETK_T(c2);
+            SETK_ACC(0, c0, c1);  // fold
+            SETK_ACC(1, c1, c2);  // barrier wait
+        };
+#pragma unroll 1
+        for (int it = 0; it < ntiles; it += 2) {
+            period(it, ma_s, ma_n);
+            if (it + 1 < ntiles) period(it + 1, mb_s, mb_n);
+        }
+#endif
+    }
+
+#ifdef SETK_TRACE
+    if (a.trace && (tid & 63) == 0)
+        for (int k = 0; k < 12; ++k) a.trace[((size_t)blockIdx.x * 16 + wave) * 16 + k] = tr[k];
+#endif
+    if (!DUMP) {
+        // ---- max |audio| (the renorm target, WaveReader.maxabs) ----
+        if (wi.last) {
+            const int covered = (T - 1) * a.g.hop - a.g.pad + kNfft;
+            for (int c = 0; c < C; ++c)
+                for (int i = covered + tid; i < n_samp; i += NT)
+                    mx = fmaxf(mx, fabsf(gptr(ud.audio)[(size_t)c * n_samp + i]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            float bm = red[0];
+#pragma unroll
+            for (int w = 1; w < NT / 64; ++w) bm = fmaxf(bm, red[w]);
+            atomicMax(a.norm_bits + wi.utt, __float_as_uint(bm));
+        }
+        if (wave >= 8) {
+            float* P = a.partials + (size_t)wi.part * nplanes_partial(C) * FP;
+            if (q == 0) {
+                store_half<C, 0>(P, f, dg_s, dg_n, of_s, of_n);
+                P[(4 * NP + 0) * FP + f] = aux0;
+                P[(4 * NP + 1) * FP + f] = aux1;
+            } else {
+                store_half<C, 1>(P, f, dg_s, dg_n, of_s, of_n);
+            }
+            if (ny_active) {
+                if (ny_item < NP) {
+                    P[(0 * NP + ny_item) * FP + 256] = aux0;
+                    P[(1 * NP + ny_item) * FP + 256] = 0.f;
+                } else if (ny_item < 2 * NP) {
+                    P[(2 * NP + ny_item - NP) * FP + 256] = aux0;
+                    P[(3 * NP + ny_item - NP) * FP + 256] = 0.f;
+                } else {
+                    P[(4 * NP + ny_item - 2 * NP) * FP + 256] = aux0;
+                }
+            }
+        }
+    }
+}
+
+template <int C, bool DUMP>
+static hipError_t launch_pass1_v3_t(const Pass1Args& a, int n_items, hipStream_t s) {
+    constexpr int NF = v3_tile_frames(C) * C;
+    const size_t lds = (size_t)4 * NF * kSlotPad * sizeof(cf) + 256 * sizeof(cf) +
+                       128 * sizeof(cf) + kNfft * sizeof(float) + (64 + 64 + 16) * sizeof(float);
+    auto k = stft_covar_v3_kernel<C, DUMP>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(n_items), dim3(1024), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int C, bool DUMP, int NQ>
 static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s) {
     constexpr int TB = tile_frames(C), NF = TB * C;
@@ -755,12 +1205,16 @@ static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s)
 hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s) {
     // NQ = 2 (512 threads, 2 waves/SIMD).  NQ = 4 (1024 threads, <= 128 VGPRs)
     // was measured 3x slower on MI355X: spills plus 4x redundant tile reads.
-    static const bool ws = [] {
+    static const int ws = [] {
         const char* e = getenv("SETK_P1_WS");
-        return !e || atoi(e) != 0;
+        return e ? atoi(e) : 2;
     }();
 #define SETK_CASE(c)                                                                      \
     case c:                                                                               \
+        if (ws == 2) {                                                                    \
+            if (dump) return launch_pass1_v3_t<c, true>(a, n_items, s);                    \
+            return launch_pass1_v3_t<c, false>(a, n_items, s);                             \
+        }                                                                                 \
         if (ws) {                                                                         \
             if (dump) return launch_pass1_ws_t<c, true>(a, n_items, s);                    \
             return launch_pass1_ws_t<c, false>(a, n_items, s);                             \
