@@ -176,7 +176,7 @@ def main():
                          "beamform_istft": round(stage_ms[2], 4),
                          "renorm": round(stage_ms[3], 4)},
             "roofline": {
-                "kernel": f"stft_covar_kernel<{C}, false, 2>",
+                "kernel": f"stft_covar_kernel<{C}, false>",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,

@@ -915,10 +915,9 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
         if (T < 0) return T;
         total_frames += T;
     }
-    constexpr int TBq[9] = {0, 8, 8, 5, 4, 3, 2, 2, 2};  // pass-1 tile frames (16 / C, <= 8)
     std::vector<int> all_frames(n_utts);
     for (int u = 0; u < n_utts; ++u) all_frames[u] = setk_stft_num_frames(h, num_samples[u]);
-    const int target1 = choose_target(all_frames, h->p1_items, TBq[C], TBq[C] * 8);
+    const int target1 = choose_target(all_frames, h->p1_items, pass1_tile_frames(C), pass1_tile_frames(C) * 8);
     const int target2 = choose_target(all_frames, h->p2_items, kSuperTile, kSuperTile * 4);
     int nparts_total = 0;
     for (int u = 0; u < n_utts; ++u) {
@@ -935,7 +934,7 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
         ud.wave_out = wave[u];
         max_len = std::max(max_len, ud.out_len);
         std::vector<std::pair<int, int>> r1, r2;
-        split_frames(ud.num_frames, target1, TBq[C], &r1);
+        split_frames(ud.num_frames, target1, pass1_tile_frames(C), &r1);
         split_frames(ud.num_frames, target2, kSuperTile, &r2);
         ud.part0 = nparts_total;
         ud.nparts = (int)r1.size();
@@ -1026,29 +1025,7 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
     p1.norm_bits = d_norm;
     p1.g = g;
     p1.flags = opts->flags;
-    // SETK_P1_TRACE=1 with a -DSETK_TRACE build of pass1.hip: per-role cycle sums
-    static const bool p1_trace = getenv("SETK_P1_TRACE") != nullptr;
-    const size_t trace_n = items1.size() * 16 * 16;
-    if (p1_trace) {
-        p1.trace = static_cast<unsigned long long*>(arena_alloc(h, trace_n * 8));
-        if (!p1.trace) return fail(h, SETK_ERR_NOMEM, "arena");
-        HIP_TRY(h, hipMemsetAsync(p1.trace, 0, trace_n * 8, s));
-    }
     HIP_TRY(h, launch_pass1(C, false, p1, (int)items1.size(), s));
-    if (p1_trace) {
-        std::vector<unsigned long long> tr(trace_n);
-        HIP_TRY(h, hipMemcpyAsync(tr.data(), p1.trace, trace_n * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipStreamSynchronize(s));
-        double sum[2][16] = {{0}};
-        for (size_t it = 0; it < items1.size(); ++it)
-            for (int w = 0; w < 16; ++w)
-                for (int k = 0; k < 16; ++k) sum[w >= 8][k] += (double)tr[(it * 16 + w) * 16 + k];
-        for (int r = 0; r < 2; ++r) {
-            fprintf(stderr, "[setk trace] %s waves, mean cycles per workgroup-wave:", r ? "covariance" : "transform");
-            for (int k = 0; k < 12; ++k) fprintf(stderr, " %.0f", sum[r][k] / (items1.size() * 8.0));
-            fprintf(stderr, "\n");
-        }
-    }
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[1], s));
     FinalizeArgs fa;
     memset(&fa, 0, sizeof(fa));

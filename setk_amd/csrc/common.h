@@ -15,6 +15,9 @@ constexpr int kMaxKeep = 7;       // ceil(512 / hop) - 1 for hop >= 64
 
 // number of Hermitian pairs (i <= j)
 __host__ __device__ constexpr int npairs(int c) { return c * (c + 1) / 2; }
+// pass 1: frames per tile -- 32/C transforms fill the 32 transform quad-rows,
+// capped at 8 (small C then rotates several quad-row sets)
+__host__ __device__ constexpr int pass1_tile_frames(int c) { return (32 / c) < 8 ? (32 / c) : 8; }
 // planes of one packed covariance pair set: [s.re | s.im | n.re | n.im | sums(2)]
 __host__ __device__ constexpr int nplanes_partial(int c) { return 4 * npairs(c) + 2; }
 // upper-triangular row-major pair index, i <= j
@@ -61,7 +64,6 @@ struct Pass1Args {
     float* spec_dump;       // DUMP mode: [C][T][F]
     StftGeom g;
     int flags;
-    unsigned long long* trace;  // SETK_TRACE builds: [items][16 waves][16] cycle sums
 };
 
 struct FinalizeArgs {

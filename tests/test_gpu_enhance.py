@@ -56,7 +56,8 @@ KINDS = {
 
 
 @pytest.mark.parametrize("kind", list(KINDS))
-@pytest.mark.parametrize("C,N", [(4, 16000), (8, 20000), (5, 9001), (2, 7000), (1, 6000)])
+@pytest.mark.parametrize("C,N", [(4, 16000), (8, 20000), (5, 9001), (2, 7000), (1, 6000),
+                                  (3, 8000), (7, 10001), (6, 5000)])
 def test_enhance_matches_oracle(ctx, kind, C, N):
     from setk_amd import _ffi
     if C == 1 and kind not in ("mvdr", "pmwf-0"):
