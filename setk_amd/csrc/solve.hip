@@ -179,6 +179,9 @@ SD void fwd_solve(const cd* L, cd (&b)[C]) {
         b[k] = zscale(b[k], r);
 #pragma unroll
         for (int i = k + 1; i < C; ++i) b[i] = zsub(b[i], zmul(L[k * C + i], b[k]));
+        // keep the LDS loads of later columns from being hoisted up here: all 36
+        // entries of L in flight at once cost 144 VGPRs
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 // L^H x = y (in place on y)
@@ -190,6 +193,7 @@ SD void bwd_solve(const cd* L, cd (&y)[C]) {
 #pragma unroll
         for (int i = k + 1; i < C; ++i) s = zsub(s, zcmul(L[k * C + i], y[i]));
         y[k] = zscale(s, 1.0 / L[k * C + k].x);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -245,8 +249,18 @@ SD void herm_matvec(const cd (&col)[C], const cd (&x)[C], cd (&y)[C]) {
     for (int i = 0; i < C; ++i) y[i] = zshfl(mine, i);
 }
 
-template <int C>
-__global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch, int lds_mats) {
+// KIND is a template parameter: every beamformer gets its own register
+// allocation (a single runtime-switched kernel needed 354 VGPRs because the
+// allocator sees the union of all branches), and the matrices are fetched when
+// a step needs them instead of up front: 0.225 -> 0.178 ms for the reduce+solve
+// stage of the 125 x 257-bin MVDR batch.  Forcing 3 or 4 waves per SIMD
+// (168 / 128 VGPRs, spilling the eigenvector across the Cholesky) measured the
+// same time, so the budget stays at 2.
+#ifndef SETK_SOLVE_WAVES
+#define SETK_SOLVE_WAVES 2
+#endif
+template <int C, int KIND>
+__global__ __launch_bounds__(64, SETK_SOLVE_WAVES) void solve_kernel(SolveArgs a, int pitch, int lds_mats) {
     constexpr int NP = npairs(C);
     // dynamic LDS, 8 problems per workgroup: [L | Wk | Rs | Rn] (lds_mats of them).
     // L: Cholesky factor (all kinds but plain pevd); Wk: transposes of the reduced
@@ -270,40 +284,29 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch, int l
     cd* Rnf = mats + ((size_t)(lds_mats > 3 ? 3 : 0) * 8 + q) * C * C;
     double* piv = &sPiv[q];
 
-    const int kind = a.kind;
+    constexpr int kind = KIND;
     const bool gauge = (a.flags & SETK_FLAG_NO_GAUGE) == 0;
     const bool have_rn = a.planes >= 4 * NP && kind != SETK_BF_MPDR;
-    const bool need_ry = (kind == SETK_BF_MPDR || kind == SETK_BF_MPDR_WHITEN);
 
-    // ---- column j of each Hermitian matrix from the packed planes ----
-    cd rs[C], rn[C], ry[C];
+    // ---- column j of a Hermitian matrix from the packed planes (pair `which`:
+    // 0 speech, 1 noise, 2 observation) ----
     const float* base = a.covar + (size_t)u * a.planes * pitch + f;
     bool finite = true;
+    auto load_col = [&](int which, cd (&m)[C]) {
 #pragma unroll
-    for (int i = 0; i < C; ++i) {
-        rs[i] = rn[i] = ry[i] = make_double2(0.0, 0.0);
-        if (j < C) {
-            const int lo = i < j ? i : j, hi = i < j ? j : i;
-            const int e = pair_index(lo, hi, C);
-            const double sgn = (i <= j) ? 1.0 : -1.0;  // (i,j) stored for i<=j
-            const float sr = base[(size_t)(0 * NP + e) * pitch];
-            const float si = base[(size_t)(1 * NP + e) * pitch];
-            rs[i] = make_double2(sr, (i == j) ? 0.0 : sgn * si);
-            finite = finite && isfinite(sr) && isfinite(si);
-            if (have_rn) {
-                const float nr = base[(size_t)(2 * NP + e) * pitch];
-                const float ni = base[(size_t)(3 * NP + e) * pitch];
-                rn[i] = make_double2(nr, (i == j) ? 0.0 : sgn * ni);
-                finite = finite && isfinite(nr) && isfinite(ni);
-            }
-            if (need_ry) {
-                const float yr = base[(size_t)(4 * NP + e) * pitch];
-                const float yi = base[(size_t)(5 * NP + e) * pitch];
-                ry[i] = make_double2(yr, (i == j) ? 0.0 : sgn * yi);
-                finite = finite && isfinite(yr) && isfinite(yi);
+        for (int i = 0; i < C; ++i) {
+            m[i] = make_double2(0.0, 0.0);
+            if (j < C) {
+                const int lo = i < j ? i : j, hi = i < j ? j : i;
+                const int e = pair_index(lo, hi, C);
+                const double sgn = (i <= j) ? 1.0 : -1.0;  // (i,j) stored for i<=j
+                const float re = base[(size_t)((2 * which + 0) * NP + e) * pitch];
+                const float im = base[(size_t)((2 * which + 1) * NP + e) * pitch];
+                m[i] = make_double2(re, (i == j) ? 0.0 : sgn * im);
+                finite = finite && isfinite(re) && isfinite(im);
             }
         }
-    }
+    };
 
     int st_sing = 0, st_noconv = 0;
     cd w[C];
@@ -312,23 +315,33 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch, int l
 
     if (kind == kKindPevd && !have_rn) {
         cd g[C];
-#pragma unroll
-        for (int i = 0; i < C; ++i) g[i] = rs[i];
+        load_col(0, g);
         double lam;
         jacobi_pevd<C>(g, j, w, lam, st_noconv);
         if (gauge) fix_gauge<C>(w);
     } else if (kind == kKindPevd || kind == SETK_BF_GEVD) {
-        st_sing |= chol_lds<C>(rn, L, piv, j);
+        {
+            cd rn[C];
+            load_col(1, rn);
+            st_sing |= chol_lds<C>(rn, L, piv, j);
+        }
+        cd rs[C];
+        load_col(0, rs);
         gev_vector<C>(rs, L, Wk, j, gauge, w, st_noconv);
     } else if (kind == SETK_BF_MVDR) {
-        cd g[C];
-#pragma unroll
-        for (int i = 0; i < C; ++i) g[i] = rs[i];
         cd d[C];
-        double lam;
-        jacobi_pevd<C>(g, j, d, lam, st_noconv);
+        {
+            cd g[C];
+            load_col(0, g);
+            double lam;
+            jacobi_pevd<C>(g, j, d, lam, st_noconv);
+        }
         if (gauge) fix_gauge<C>(d);
-        st_sing |= chol_lds<C>(rn, L, piv, j);
+        {
+            cd rn[C];
+            load_col(1, rn);
+            st_sing |= chol_lds<C>(rn, L, piv, j);
+        }
         cd num[C];
 #pragma unroll
         for (int i = 0; i < C; ++i) num[i] = d[i];
@@ -343,19 +356,28 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch, int l
         cd sv[C];
         if (kind == SETK_BF_MPDR) {
             cd g[C];
-#pragma unroll
-            for (int i = 0; i < C; ++i) g[i] = rs[i];
+            load_col(0, g);
             double lam;
             jacobi_pevd<C>(g, j, sv, lam, st_noconv);
             if (gauge) fix_gauge<C>(sv);
         } else {
+            cd rn[C];
+            load_col(1, rn);
             st_sing |= chol_lds<C>(rn, L, piv, j);
             cd v[C];
-            gev_vector<C>(rs, L, Wk, j, gauge, v, st_noconv);
+            {
+                cd rs[C];
+                load_col(0, rs);
+                gev_vector<C>(rs, L, Wk, j, gauge, v, st_noconv);
+            }
             herm_matvec<C>(rn, v, sv);
             __syncthreads();
         }
-        st_sing |= chol_lds<C>(ry, L, piv, j);
+        {
+            cd ry[C];
+            load_col(2, ry);
+            st_sing |= chol_lds<C>(ry, L, piv, j);
+        }
         cd num[C];
 #pragma unroll
         for (int i = 0; i < C; ++i) num[i] = sv[i];
@@ -367,6 +389,9 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch, int l
 #pragma unroll
         for (int i = 0; i < C; ++i) w[i] = zdiv(num[i], den);
     } else if (kind == SETK_BF_PMWF) {
+        cd rs[C], rn[C];
+        load_col(0, rs);
+        load_col(1, rn);
         st_sing |= chol_lds<C>(rn, L, piv, j);
         if (a.rank1 != SETK_RANK1_NONE) {
             cd pv[C];
@@ -448,6 +473,10 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a, int pitch, int l
 
     // ---- blind analytic normalisation (do_ban) ----
     if ((a.flags & SETK_FLAG_BAN) && !(kind == SETK_BF_PMWF && a.pmwf_ref < 0)) {
+        cd rn[C];  // zero when the call carries no noise covariance (as before)
+#pragma unroll
+        for (int i = 0; i < C; ++i) rn[i] = make_double2(0.0, 0.0);
+        if (have_rn) load_col(1, rn);
         cd uj = make_double2(0.0, 0.0);  // (Rn w)_j = sum_m conj(Rn[m][j]) w[m]
         cd wj = make_double2(0.0, 0.0);
 #pragma unroll
@@ -494,11 +523,20 @@ hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
     int lds_mats = 2;
     if (a.kind == SETK_BF_MVDR || a.kind == SETK_BF_MPDR) lds_mats = 1;
     if (a.kind == SETK_BF_PMWF) lds_mats = 4;
+#define SETK_LAUNCH(c, k)                                                              \
+    hipLaunchKernelGGL((solve_kernel<c, k>), dim3(blocks), dim3(64),                   \
+                       (size_t)lds_mats * 8 * c * c * sizeof(cd) + 64, s, a, pitch, lds_mats)
 #define SETK_CASE(c)                                                                   \
     case c:                                                                            \
-        hipLaunchKernelGGL(solve_kernel<c>, dim3(blocks), dim3(64),                    \
-                           (size_t)lds_mats * 8 * c * c * sizeof(cd) + 64, s, a, pitch,\
-                           lds_mats);                                                  \
+        switch (a.kind) {                                                              \
+            case SETK_BF_MVDR: SETK_LAUNCH(c, SETK_BF_MVDR); break;                    \
+            case SETK_BF_GEVD: SETK_LAUNCH(c, SETK_BF_GEVD); break;                    \
+            case SETK_BF_PMWF: SETK_LAUNCH(c, SETK_BF_PMWF); break;                    \
+            case SETK_BF_MPDR: SETK_LAUNCH(c, SETK_BF_MPDR); break;                    \
+            case SETK_BF_MPDR_WHITEN: SETK_LAUNCH(c, SETK_BF_MPDR_WHITEN); break;      \
+            case kKindPevd: SETK_LAUNCH(c, kKindPevd); break;                          \
+            default: return hipErrorInvalidValue;                                      \
+        }                                                                              \
         break;
     switch (a.num_channels) {
         SETK_CASE(1)
@@ -513,6 +551,7 @@ hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
             return hipErrorInvalidValue;
     }
 #undef SETK_CASE
+#undef SETK_LAUNCH
     return hipGetLastError();
 }
 
