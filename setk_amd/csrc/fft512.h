@@ -180,4 +180,91 @@ SETK_DEV void irfft_merge(cf Yk, cf Ym, cf w, cf& Zk, cf& Zm) {
     Zm = make_float2(E.x + O.y, -E.y + O.x);  // conj(E) + i conj(O)
 }
 
+// ---- frame loading and the quad-row real transform (both streaming passes) ----
+constexpr int kFrame = 512;
+
+// numpy "reflect" index (no edge repeat); valid for -N < i < 2N-1
+SETK_DEV int reflect_index(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// raw (un-windowed) frame points: v[j] = (x[s+2n], x[s+2n+1]), n = la + 16 j
+SETK_DEV void load_raw(cf (&v)[16], gcfloat_p x, int n_samp, int s, int la, bool valid) {
+    if (!valid) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = make_float2(0.f, 0.f);
+        return;
+    }
+    const bool interior = (s >= 0) && (s + kFrame <= n_samp) && ((((uintptr_t)(x + s)) & 7) == 0);
+    if (interior) {
+        gcfloat2_p p = (gcfloat2_p)(x + s);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const v2f d = p[la + 16 * j];
+            v[j] = make_float2(d.x, d.y);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int n = la + 16 * j;
+            v[j] = make_float2(x[reflect_index(s + 2 * n, n_samp)],
+                               x[reflect_index(s + 2 * n + 1, n_samp)]);
+        }
+    }
+}
+
+// lane la <- value of lane (16 - la) & 15 of the same quad-row (a DPP row):
+// row_mirror (la -> 15 - la) followed by row_ror:1
+SETK_DEV float qr_partner(float x) {
+    int v = __builtin_bit_cast(int, x);
+    v = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);  // row_mirror
+    v = __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, true);  // row_ror:1
+    return __builtin_bit_cast(float, v);
+}
+
+// Second radix-16 and the Hermitian split, in registers: lane la owns
+// Z[la + 16 kb]; the mirror bin 256 - k of k = la + 16 m lives in lane
+// (16 - la) & 15, register 15 - m (lane 0: its own register 16 - m), fetched with
+// two DPP moves instead of an LDS round trip.  Writes X[k], X[256-k] (m < 8) into
+// the slot and X[256] to *nyq.
+SETK_DEV void qr_stage23(cf* slot, float* nyq, const cf* tw5, int la) {
+    cf v[16];
+    fft256_stage_b_pad<-1>(v, slot, la);
+    const bool lane0 = (la == 0);
+    // bins k = la + 16 m and 256 - k as ONE base register each plus an immediate
+    // (written as slot[256 - k] the compiler keeps eight address registers)
+    cf* lo = slot + la;
+    cf* mir = slot + (256 - 16 * 7) - la;
+    const cf* t5 = tw5 + la;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const cf Zk = v[dft16_pos(m)];
+        const cf src = v[dft16_pos(15 - m)];
+        cf Zm = make_float2(qr_partner(src.x), qr_partner(src.y));
+        const cf own = v[dft16_pos((16 - m) & 15)];
+        Zm.x = lane0 ? own.x : Zm.x;
+        Zm.y = lane0 ? own.y : Zm.y;
+        cf Xk, Xm;
+        rfft_split(Zk, Zm, t5[16 * m], Xk, Xm);
+        if (m == 0) {
+            // lane 0: k = 0 pairs with itself (Z[256] == Z[0]): X[0], X[256]; and
+            // the self-paired bin 128 = conj(Z[128])
+            const cf Z128 = v[dft16_pos(8)];
+            if (lane0) {
+                slot[0] = make_float2(Xk.x, 0.f);
+                *nyq = Xm.x;
+                slot[128] = make_float2(2.f * Z128.x, -2.f * Z128.y);
+            } else {
+                lo[16 * m] = Xk;
+                mir[16 * (7 - m)] = Xm;
+            }
+        } else {
+            lo[16 * m] = Xk;
+            mir[16 * (7 - m)] = Xm;
+        }
+    }
+}
+
 }  // namespace setk

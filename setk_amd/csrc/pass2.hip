@@ -57,11 +57,11 @@ SETK_DEV void load_frame2(cf (&v)[16], const float* __restrict__ x, int n_samp, 
     }
 }
 
-// LDS plan (bytes): slots (16+keep)*2048 | wtab C*257*8 (BF mode) | tw 2048 |
+// LDS plan (bytes): slots (16+keep)*2176 (padded 16x16 transpose) | wtab C*257*8 (BF mode) | tw 2048 |
 // win 2048 | synwin 2048 | winsq 2048 | red 16
 size_t pass2_lds_bytes(int C, int keep) {
     size_t wt = ((size_t)C * kBins * sizeof(cf) + 15) & ~(size_t)15;
-    return (size_t)(kSuperTile + keep) * 2048 + wt + 4 * 2048 + 64;
+    return (size_t)(kSuperTile + keep) * kSlotPad * sizeof(cf) + wt + 4 * 2048 + 64;
 }
 
 // raw (un-windowed) frame points of one quad-row lane: v[j] = (x[s+2n], x[s+2n+1])
@@ -112,8 +112,9 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int keep = a.g.keep;
-    cf* slots = reinterpret_cast<cf*>(smem);  // [(keep + 16)][256]
-    char* p = smem + (size_t)(ST + keep) * 2048;
+    constexpr int SL = kSlotPad;              // slot stride in complex entries
+    cf* slots = reinterpret_cast<cf*>(smem);  // [(keep + 16)][SL]
+    char* p = smem + (size_t)(ST + keep) * SL * sizeof(cf);
     cf* wtab = reinterpret_cast<cf*>(p);  // [C][257]
     p += ((size_t)C * F * sizeof(cf) + 15) & ~(size_t)15;
     cf* tw = reinterpret_cast<cf*>(p);
@@ -156,11 +157,11 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
 
     // frames needed to complete the first output position of this range
     const int t_first = max(wi.t0 - keep, 0);
-    for (int i = tid; i < keep * 256; i += 256) slots[i] = make_float2(0.f, 0.f);
+    for (int i = tid; i < keep * SL; i += 256) slots[i] = make_float2(0.f, 0.f);
     const float2* w2 = reinterpret_cast<const float2*>(win);
 
     for (int ts = t_first; ts < wi.t1; ts += ST) {
-        cf* slot = slots + (keep + grp) * 256;  // this quad-row's frame slot
+        cf* slot = slots + (keep + grp) * SL;  // this quad-row's frame slot
         const int t = ts + grp;
         const bool tvalid = t < T;
         cf Yk[8], Ym[8];
@@ -199,10 +200,14 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                 if (c + 1 < C)
                     load_raw(nxt, ud.audio + (size_t)(c + 1) * n_samp, n_samp, t * hop - a.g.pad,
                              la, tvalid);
-                fft256_stage_a<-1>(v, slot, tw, la, la ^ (grp & 1));
+                fft256_stage_a_pad<-1>(v, slot, tw, la);
                 __builtin_amdgcn_wave_barrier();
-                fft256_stage_b<-1>(v, slot, la, la ^ (grp & 1));  // v[pos(kb)] = Z[la + 16 kb]
+                fft256_stage_b_pad<-1>(v, slot, la);  // v[pos(kb)] = Z[la + 16 kb]
                 const cf* wc = wtab + c * F;
+                // bins k = la + 16 m and 256 - k: one base register each + immediates
+                const cf* wlo = wc + la;
+                const cf* wmir = wc + (256 - 16 * 7) - la;
+                const cf* t5 = tw5 + la;
                 // Hermitian split in registers: the mirror bin of k = la + 16 m is
                 // register 15 - m of lane (16 - la) & 15 (lane 0: own register 16 - m)
 #pragma unroll
@@ -215,8 +220,8 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                     Zm.x = lane0 ? own.x : Zm.x;
                     Zm.y = lane0 ? own.y : Zm.y;
                     cf Xk, Xm;
-                    rfft_split(Zk, Zm, tw5[k], Xk, Xm);
-                    const cf wk = wc[k], wm = wc[256 - k];
+                    rfft_split(Zk, Zm, t5[16 * m], Xk, Xm);
+                    const cf wk = wlo[16 * m], wm = wmir[16 * (7 - m)];
                     const cf yk1 = cadd(Yk[m], cmulc(Xk, wk));
                     const cf ym1 = cadd(Ym[m], cmulc(Xm, wm));
                     if (m == 0) {
@@ -281,9 +286,9 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                 v[j].x = lane0 ? own.x : pv.x;
                 v[j].y = lane0 ? own.y : pv.y;
             }
-            fft256_stage_a<+1>(v, slot, tw, la, la ^ (grp & 1));
+            fft256_stage_a_pad<+1>(v, slot, tw, la);
             __builtin_amdgcn_wave_barrier();
-            fft256_stage_b<+1>(v, slot, la, la ^ (grp & 1));
+            fft256_stage_b_pad<+1>(v, slot, la);
             const float sc = tvalid ? (1.f / 256.f) : 0.f;
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) {
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
         __syncthreads();
         // ---- overlap-add: padded positions [pos0, pos1) are now complete ----
         {
-            const float* frames = reinterpret_cast<const float*>(slots);  // [(keep+16)][512]
+            const float* frames = reinterpret_cast<const float*>(slots);  // [(keep+16)][2 SL]
             int pos0 = max(ts, wi.t0) * hop;
             int pos1 = min(ts + ST, wi.t1) * hop;
             if (wi.last && ts + ST >= wi.t1) pos1 = (T - 1) * hop + kNfft;
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                 for (int tt = t_lo; tt <= t_hi; ++tt) {
                     const int off = n - tt * hop;
                     const int sl = tt - ts + keep;  // slot of frame tt
-                    v += frames[sl * kNfft + off];
+                    v += frames[sl * (2 * SL) + off];
                     wss += winsq[off];
                 }
                 if (wss > 1.17549435e-38f) v /= wss;
@@ -325,8 +330,8 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
         // (source slots [16, 16+keep) and destination slots [0, keep) are disjoint)
         {
             float4* dst = reinterpret_cast<float4*>(slots);
-            const float4* src = reinterpret_cast<const float4*>(slots + ST * 256);
-            const int n4 = keep * 128;  // float4 per slot = 128
+            const float4* src = reinterpret_cast<const float4*>(slots + ST * SL);
+            const int n4 = keep * (SL / 2);  // float4 per slot
             for (int i = tid; i < n4; i += 256) dst[i] = src[i];
         }
     }
