@@ -67,15 +67,24 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SETK_BENCH_SHARE_GPU=1 + SETK_BENCH_BACKEND=gloo: every rank on cuda:0 with a CPU
+    # rendezvous -- only for exercising the multi-rank control flow on a 1-GPU box
+    # (tests/test_gpu_api.py); the real launch is one rank per GPU over RCCL.
+    share = os.environ.get("SETK_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("SETK_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     C, U = args.channels, args.utts
     N = int(round(args.seconds * SR))
-    ctx = _ffi.Context(local_rank)
+    ctx = _ffi.Context(dev_index)
     ctx.stft_plan(512, 256, 512, True)
     T = ctx.num_frames(N)
     L = ctx.istft_num_samples(T)
@@ -128,7 +137,7 @@ def main():
     ctx.set_profiling(False)
     stage_ms = ctx.last_stage_ms()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

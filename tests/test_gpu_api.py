@@ -252,3 +252,47 @@ def test_cli_options_vad_postmask_itf_online(tmp_path):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_contract_single_and_two_ranks():
+    """bench.py prints ONE JSON line with the contract's fields; the two-rank
+    launch (as the driver starts it, but both ranks on this box's single GPU with
+    a gloo rendezvous) aggregates over ranks and reports from rank 0 only."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    small = ["--steps", "2", "--warmup", "1", "--utts", "6", "--seconds", "4", "--cpu-sample", "0"]
+    r = subprocess.run([sys.executable, bench, "--gpus", "1"] + small, capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    one = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in one, k
+    assert one["n_gpus"] == 1 and one["steps"] == 2 and one["scaling"] == "weak"
+    assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1
+
+    env = dict(os.environ, SETK_BENCH_SHARE_GPU="1", SETK_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), bench, "--gpus", "2"] + small
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["value"] > 0
+    # whole-job aggregate: audio of both ranks over the slower rank's time
+    audio = 2 * 6 * 4.0 * 2
+    assert abs(two["value"] * two["ms_per_step"] * 2 / 1e3 - audio) / audio < 1e-3
