@@ -151,6 +151,13 @@ int setk_weights(setk_handle_t h, const setk_bf_opts* opts, const float* Rs,
                  int num_channels, float* weight, int* status, int* ref_out,
                  void* stream);
 
+/* read_wav with dtype float32 + transpose (libs/utils.py:65-92,
+ * data_handler.py:372-393) for 16-bit PCM: interleaved frames pcm[n][c] ->
+ * audio[c][n] = pcm / 32768 (soundfile's scaling, exact in float32).  Lets a
+ * caller upload the 2-byte samples of a wav as they lie in the file. */
+int setk_pcm16_to_float(setk_handle_t h, const int16_t* pcm, int num_channels,
+                        int num_samples, float* audio, void* stream);
+
 /* do_ban (libs/beamformer.py:14-28) on an arbitrary weight:
  * out[f] = w[f] * sqrt(|w^H Rn Rn w|) / max(Re w^H Rn w, eps_f32). */
 int setk_ban(setk_handle_t h, const float* weight, const float* Rn, int num_bins,

@@ -46,8 +46,8 @@ def exported_symbols():
         "setk_abi_version", "setk_create", "setk_destroy", "setk_last_error",
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
-        "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks", "setk_cgmm_masks_batch", "setk_enhance_batch",
-        "setk_set_profiling",
+        "setk_pcm16_to_float", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
+        "setk_cgmm_masks_batch", "setk_enhance_batch", "setk_set_profiling",
         "setk_last_stage_ms"
     ]
 
@@ -85,6 +85,7 @@ def load_library():
     lib.setk_weights.argtypes = [H, POINTER(BfOpts), fp, fp, fp, c_int, c_int,
                                  fp, fp, POINTER(c_int), c_void_p]
     lib.setk_ban.argtypes = [H, fp, fp, c_int, c_int, fp, c_void_p]
+    lib.setk_pcm16_to_float.argtypes = [H, c_void_p, c_int, c_int, fp, c_void_p]
     lib.setk_rank1.argtypes = [H, fp, fp, c_int, c_int, fp, fp, c_void_p]
     lib.setk_beamform.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, c_void_p]
     lib.setk_cgmm_masks.argtypes = [H, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_void_p]
@@ -229,6 +230,12 @@ class Context:
                                    ctypes.byref(ref),
                                    current_stream_ptr() if stream is None else stream))
         return ref.value
+
+    def pcm16_to_float(self, pcm, C, N, out, stream=None):
+        """interleaved int16 frames pcm[N][C] -> float32 out[C][N] (= pcm / 32768)."""
+        self.check(
+            self._lib.setk_pcm16_to_float(self._h, _ptr(pcm), C, N, _ptr(out),
+                                          current_stream_ptr() if stream is None else stream))
 
     def ban(self, weight, Rn, F, C, out, stream=None):
         self.check(

@@ -739,6 +739,28 @@ int setk_ban(setk_handle_t h, const float* weight, const float* Rn, int num_bins
     return SETK_OK;
 }
 
+int setk_pcm16_to_float(setk_handle_t h, const int16_t* pcm, int num_channels, int num_samples,
+                        float* audio, void* stream) {
+    if (!h || !pcm || !audio || num_channels <= 0 || num_samples <= 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h);
+    const size_t n16 = (size_t)num_channels * num_samples;
+    const int16_t* d_pcm;
+    int rc = stage_in(h, pcm, n16, s, &d_pcm);
+    if (rc) return rc;
+    OutBuf ob;
+    rc = stage_out(h, audio, n16 * sizeof(float), &ob);
+    if (rc) return rc;
+    HIP_TRY(h, launch_pcm16_to_float(d_pcm, num_channels, num_samples,
+                                     static_cast<float*>(ob.dev), s));
+    rc = copy_back(h, ob, s);
+    if (rc) return rc;
+    if (ob.host) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
 int setk_rank1(setk_handle_t h, const float* Rs, const float* Rn, int num_bins,
                int num_channels, float* out, int* status, void* stream) {
     if (!h || !Rs || !out || num_bins <= 0) return fail(h, SETK_ERR_INVALID, "bad args");

@@ -276,4 +276,25 @@ hipError_t launch_istft_generic(const float* spec, int B, int T, int n_fft, int 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// PCM16 ingest: interleaved wav frames pcm[n][c] (int16) -> audio[c][n] float32
+// with soundfile's dtype="float32" scaling (x / 32768, exact), i.e. read_wav
+// (libs/utils.py:65-92) + the transpose to C x N on the device: half the PCIe
+// bytes of a float upload and no host conversion.  One thread per frame n reads
+// its C samples (contiguous) and scatters them to the C rows (coalesced per row).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pcm16_to_float_kernel(const int16_t* __restrict__ pcm, int C,
+                                                             int N, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int16_t* src = pcm + (size_t)n * C;
+    for (int c = 0; c < C; ++c) out[(size_t)c * N + n] = (float)src[c] * (1.0f / 32768.0f);
+}
+
+hipError_t launch_pcm16_to_float(const int16_t* pcm, int C, int N, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(pcm16_to_float_kernel, dim3((N + 255) / 256), dim3(256), 0, s, pcm, C, N,
+                       out);
+    return hipGetLastError();
+}
+
 }  // namespace setk

@@ -25,6 +25,37 @@ RANK1 = {"": _ffi.RANK1_NONE, "none": _ffi.RANK1_NONE, "eig": _ffi.RANK1_EIG,
          "gev": _ffi.RANK1_GEV}
 
 
+class Pcm16Frames(object):
+    """Interleaved 16-bit PCM frames [N, C] of one utterance, exactly as stored in
+    its wav (WaveReader.read_pcm16).  BatchEnhancer uploads the 2-byte samples and
+    converts / transposes them on the device (setk_pcm16_to_float)."""
+
+    def __init__(self, frames):
+        frames = np.asarray(frames)
+        if frames.dtype != np.int16 or frames.ndim != 2:
+            raise ValueError("Pcm16Frames expects an int16 array of shape N x C")
+        self.frames = np.ascontiguousarray(frames)
+
+    @property
+    def num_channels(self):
+        return self.frames.shape[1]
+
+    @property
+    def size(self):
+        return self.frames.size
+
+    def to_float(self):
+        """The reference's host view: C x N float32 (soundfile scaling)."""
+        return np.ascontiguousarray(self.frames.T.astype(np.float32) / np.float32(32768.0))
+
+
+def _channels_and_size(samps):
+    if isinstance(samps, Pcm16Frames):
+        return samps.num_channels, samps.size
+    samps = np.asarray(samps)
+    return (1 if samps.ndim == 1 else samps.shape[0]), samps.size
+
+
 def compute_vad_masks(spectrogram, proportion):
     """Energy based VAD mask of apply_adaptive_beamformer.py:50-71: keep
     proportion*100 % of the energy.  spectrogram F x T -> (T x F bool, index).
@@ -91,21 +122,18 @@ class BatchEnhancer(object):
         return mask
 
     def enhance(self, utts):
-        """utts: list of (samps C x N float32, speech mask, interferer mask|None).
+        """utts: list of (samps C x N float32 | Pcm16Frames, speech mask, interferer mask|None).
         Returns list of (wave ndarray | None, status) in input order; status != 0
         is the reference's LinAlgError case (the utterance is to be skipped)."""
         self._plan()
         results = [None] * len(utts)
         groups = {}
         for i, (samps, _, itf) in enumerate(utts):
-            samps = np.asarray(samps)
-            if samps.ndim == 1:
-                samps = samps[None]
-            groups.setdefault((samps.shape[0], itf is not None), []).append(i)
+            groups.setdefault((_channels_and_size(samps)[0], itf is not None), []).append(i)
         for (C, has_itf), idx in groups.items():
             batch, nsamp = [], 0
             for i in idx:
-                n = np.asarray(utts[i][0]).size
+                n = _channels_and_size(utts[i][0])[1]
                 if batch and nsamp + n > self.max_batch_samples:
                     self._run(utts, batch, C, has_itf, results)
                     batch, nsamp = [], 0
@@ -123,6 +151,8 @@ class BatchEnhancer(object):
         mpdr = self.opts_kw["kind"] in (_ffi.BF_MPDR, _ffi.BF_MPDR_WHITEN)
         for i in batch:
             samps, mask, itf = utts[i]
+            if isinstance(samps, Pcm16Frames):
+                samps = samps.to_float()
             samps = np.ascontiguousarray(samps, dtype=np.float32)
             if samps.ndim == 1:
                 samps = samps[None]
@@ -180,15 +210,23 @@ class BatchEnhancer(object):
         flags = self.base_flags | (0 if has_itf else _ffi.FLAG_CLAMP_MASK)
         for i in batch:
             samps, mask, itf = utts[i]
-            samps = np.ascontiguousarray(samps, dtype=np.float32)
-            if samps.ndim == 1:
-                samps = samps[None]
-            N = samps.shape[1]
+            if isinstance(samps, Pcm16Frames):
+                # the wav's 2-byte frames go up as they are; scaling and the
+                # transpose to C x N happen on the device
+                pcm = torch.from_numpy(samps.frames).to(dev)
+                N = samps.frames.shape[0]
+                a = torch.empty((C, N), dtype=torch.float32, device=dev)
+                ctx.pcm16_to_float(pcm, C, N, a)
+            else:
+                samps = np.ascontiguousarray(samps, dtype=np.float32)
+                if samps.ndim == 1:
+                    samps = samps[None]
+                N = samps.shape[1]
+                a = torch.from_numpy(samps).to(dev)
             T = ctx.num_frames(N)
             mask = self.condition_mask(mask, T)
             if has_itf:
                 itf = self.condition_mask(itf, T)
-            a = torch.from_numpy(samps).to(dev)
             if 0.5 < self.vad_proportion < 1:
                 spec0 = torch.empty((1, T, self.num_bins), dtype=torch.complex64, device=dev)
                 ctx.stft(a[:1], spec0)

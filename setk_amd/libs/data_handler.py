@@ -28,6 +28,8 @@ import _thread
 from io import BytesIO, TextIOWrapper
 from pathlib import Path
 
+from . import wavio
+
 import numpy as np
 
 from . import kaldi_io
@@ -260,6 +262,37 @@ class WaveReader(ScpReader):
         if beg is None and end is None:
             self._last = (key, samps)
         return samps
+
+    def read_pcm16(self, key):
+        """Interleaved int16 frames [N, C] of an entry that is ONE 16-bit PCM file
+        (plain path or path.ark:offset), else None: the device then converts and
+        transposes (setk_pcm16_to_float) what read() does on the host.  Only with
+        normalize=True (the x / 32768 scaling)."""
+        if not self.normalize:
+            return None
+        fname = self.index_dict[key].rstrip()
+        if fname[-1] == "|":
+            return None
+        wav_list = glob.glob(fname)
+        if ":" in fname and not wav_list:
+            wav_list = [fname]
+        if len(wav_list) != 1:
+            return None
+        addr = wav_list[0]
+        if ":" in addr:
+            tokens = addr.split(":")
+            if len(tokens) != 2:
+                raise RuntimeError(f"Value format error: {addr}")
+            if tokens[0] not in self.wav_ark_mgr:
+                self.wav_ark_mgr[tokens[0]] = open(tokens[0], "rb")
+            ark = self.wav_ark_mgr[tokens[0]]
+            ark.seek(int(tokens[1]))
+            pcm, sr = wavio.read_pcm16_frames(ark)
+        else:
+            pcm, sr = wavio.read_pcm16_frames(addr)
+        if sr != self.sr:
+            raise RuntimeError(f"Expect sr={self.sr} of {addr}, get {sr} instead")
+        return pcm
 
     def _load(self, key):
         return self.read(key)

@@ -119,6 +119,26 @@ def read(file, start=0, stop=None, dtype="float32"):
     return data, info["sr"]
 
 
+def read_pcm16_frames(file):
+    """Interleaved frames of a 16-bit PCM wave as they lie in the file:
+    (int16 array [N, C], sr), or (None, sr) when the stream is not PCM16 (the
+    caller then takes read()).  Feeds the device-side ingest
+    (setk_pcm16_to_float): no host conversion, half the upload."""
+    own = isinstance(file, (str, bytes)) or hasattr(file, "__fspath__")
+    fd = open(file, "rb") if own else file
+    try:
+        info = read_header(fd)
+        if info["fmt"] != WAVE_FORMAT_PCM or info["bits"] != 16:
+            return None, info["sr"]
+        ch = info["channels"]
+        raw = fd.read(info["data_bytes"])
+        raw = raw[:(len(raw) // (2 * ch)) * 2 * ch]
+        return np.frombuffer(raw, dtype="<i2").reshape(-1, ch), info["sr"]
+    finally:
+        if own:
+            fd.close()
+
+
 def float_to_pcm16(samps):
     """libsndfile float -> short: lrintf(x * 0x7FFF), no clipping (wraps)."""
     pcm = np.rint(np.asarray(samps, dtype=np.float64) * 32767.0)

@@ -15,8 +15,8 @@ Differences, all deliberate (DESIGN.md "Reference bugs"):
   * the block-online mode works (the reference raises TypeError, :42-45)
   * under ``torchrun`` (WORLD_SIZE > 1) every rank takes its share of the
     utterances -- the replacement for ``run.pl JOB=1:nj`` sharding
-  * extra options ``--batch-utts`` / ``--device`` (defaults keep the reference
-    behaviour)
+  * extra options ``--batch-utts`` / ``--device`` / ``--device-ingest`` (defaults
+    keep the reference behaviour)
 """
 import argparse
 import math
@@ -26,7 +26,7 @@ import numpy as np
 
 from setk_amd import _ffi
 from setk_amd.dist import Shard
-from setk_amd.engine import BatchEnhancer, compute_vad_masks
+from setk_amd.engine import BatchEnhancer, Pcm16Frames, compute_vad_masks
 from setk_amd.libs import wavio
 from setk_amd.libs.beamformer import OnlineGevdBeamformer, OnlineMvdrBeamformer
 from setk_amd.libs.data_handler import (NumpyReader, ScriptReader, SpectrogramReader,
@@ -65,6 +65,9 @@ _OPTIONS = (
                              help="[setk_amd] utterances enhanced per GPU batch")),
     (("--device",), dict(default=-1, type=int,
                          help="[setk_amd] GPU ordinal (default: LOCAL_RANK or 0)")),
+    (("--device-ingest",), dict(default=True, type=lambda v: str(v).lower() in ("true", "1", "yes"),
+                                help="[setk_amd] upload 16-bit PCM files as stored and "
+                                     "convert on the GPU (same samples as the host decode)")),
 )
 
 
@@ -190,10 +193,17 @@ def run_offline(args, shard):
         for key in keys:
             if key not in tgt:
                 continue
-            samps = wav_reader.read(key)
-            if samps.ndim == 1:
-                samps = samps[None]
-            power = np.linalg.norm(samps[0], 2)**2 / samps[0].size
+            pcm = wav_reader.read_pcm16(key) if args.device_ingest else None
+            if pcm is not None:
+                # 16-bit PCM file: upload the frames as stored, convert on the device
+                ch0 = pcm[:, 0].astype(np.float32) / np.float32(32768.0)
+                samps = Pcm16Frames(pcm)
+            else:
+                samps = wav_reader.read(key)
+                if samps.ndim == 1:
+                    samps = samps[None]
+                ch0 = samps[0]
+            power = np.linalg.norm(ch0, 2)**2 / ch0.size
             logger.info(f"Processing utterance {key}, " +
                         f"signal power {10 * np.log10(power + 1e-5):.2f}...")
             pending.append((key, samps, tgt[key], None if itf is None else itf[key]))

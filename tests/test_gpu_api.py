@@ -296,3 +296,39 @@ def test_bench_contract_single_and_two_ranks():
     # whole-job aggregate: audio of both ranks over the slower rank's time
     audio = 2 * 6 * 4.0 * 2
     assert abs(two["value"] * two["ms_per_step"] * 2 / 1e3 - audio) / audio < 1e-3
+
+
+def test_pcm16_device_ingest_is_bit_identical(tmp_path):
+    """setk_pcm16_to_float == read_wav's host decode (int16 / 32768, C x N), and the
+    batch engine fed with the stored frames returns the samples it returns for
+    the host-decoded float audio."""
+    import torch
+    from setk_amd import _ffi
+    from setk_amd.engine import BatchEnhancer, Pcm16Frames
+    from setk_amd.libs import wavio
+    from setk_amd.libs.data_handler import WaveReader
+    rng = np.random.default_rng(5)
+    ctx = _ffi.default_context()
+    for C, N in [(1, 777), (3, 4099), (8, 16000)]:
+        pcm = rng.integers(-32768, 32768, size=(N, C), dtype=np.int64).astype(np.int16)
+        out = np.empty((C, N), dtype=np.float32)
+        ctx.pcm16_to_float(pcm, C, N, out)                       # host pointers (staged)
+        assert np.array_equal(out, pcm.T.astype(np.float32) / np.float32(32768))
+        dout = torch.empty((C, N), dtype=torch.float32, device="cuda")
+        ctx.pcm16_to_float(torch.from_numpy(pcm).cuda(), C, N, dout)  # device pointers
+        assert np.array_equal(dout.cpu().numpy(), out)
+
+    mix, sp, nz = o.synth_utterance(3, 6, 24000, return_parts=True)
+    mask = o.irm_mask(sp, nz)
+    frames = wavio.float_to_pcm16(mix.T)
+    wavio.write_pcm16(str(tmp_path / "u.wav"), frames, 16000)
+    (tmp_path / "wav.scp").write_text(f"u {tmp_path}/u.wav\n")
+    reader = WaveReader(str(tmp_path / "wav.scp"), sr=16000)
+    raw = reader.read_pcm16("u")
+    assert raw.dtype == np.int16 and raw.shape == (24000, 6)
+    host = reader.read("u")
+    eng = BatchEnhancer(beamformer="mvdr", pcm16=True)
+    (w_dev, st_dev), (w_host, st_host) = eng.enhance([(Pcm16Frames(raw), mask, None),
+                                                      (host, mask, None)])
+    assert st_dev == 0 and st_host == 0
+    assert np.array_equal(w_dev, w_host)

@@ -101,6 +101,40 @@ def test_wavio_roundtrip_and_extensible(tmp_path):
 # ---------------------------------------------------------------------------
 # Kaldi I/O against the reference's vectors
 # ---------------------------------------------------------------------------
+def test_wave_reader_pcm16_frames(tmp_path):
+    """read_pcm16: the stored frames of single 16-bit PCM entries (plain file and
+    path.ark:offset), None for what the device ingest cannot take."""
+    from setk_amd.libs import wavio
+    from setk_amd.libs.data_handler import WaveReader
+    rng = np.random.default_rng(2)
+    pcm = rng.integers(-30000, 30000, size=(500, 4)).astype(np.int16)
+    wavio.write_pcm16(str(tmp_path / "a.wav"), pcm, 16000)
+    for c in range(2):
+        wavio.write_pcm16(str(tmp_path / f"b.CH{c}.wav"), pcm[:, c], 16000)
+    wavio.write(str(tmp_path / "f.wav"), (pcm[:, :2] / 32768.0).astype(np.float32), 16000)
+    # an "ark" holding the wav at an offset
+    blob = open(tmp_path / "a.wav", "rb").read()
+    with open(tmp_path / "w.ark", "wb") as fd:
+        fd.write(b"key ")
+        off = fd.tell()
+        fd.write(blob)
+    (tmp_path / "wav.scp").write_text(
+        f"a {tmp_path}/a.wav\nb {tmp_path}/b.CH*.wav\nf {tmp_path}/f.wav\n"
+        f"k {tmp_path}/w.ark:{off}\np cat {tmp_path}/a.wav |\n")
+    r = WaveReader(str(tmp_path / "wav.scp"), sr=16000)
+    for key in ("a", "k"):
+        got = r.read_pcm16(key)
+        assert got.dtype == np.int16 and np.array_equal(got, pcm)
+        assert np.array_equal(got.T.astype(np.float32) / np.float32(32768), r.read(key))
+    assert r.read_pcm16("b") is None      # one file per channel
+    assert r.read_pcm16("p") is None      # command pipe
+    # float wav: write() stores PCM16 too (libsndfile default) -> frames available
+    assert r.read_pcm16("f") is not None
+    with pytest.raises(RuntimeError):
+        WaveReader(str(tmp_path / "wav.scp"), sr=8000).read_pcm16("a")
+    assert WaveReader(str(tmp_path / "wav.scp"), sr=16000, normalize=False).read_pcm16("a") is None
+
+
 def test_kaldi_goldens():
     from setk_amd.libs import kaldi_io
     from setk_amd.libs.data_handler import ScriptReader, ArchiveReader
