@@ -195,6 +195,26 @@ int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
                           int num_iters, const float* const* init_mask, float* const* mask_out,
                           void* stream);
 
+/* directional_feats (libs/spatial.py:184-208, compute_df_on_mask.py:40-54):
+ * out[t][f] = mean over the n_pairs microphone pairs (i, j) = (pairs[2p],
+ * pairs[2p+1], host array) of cos((arg X_i - arg X_j) - (arg v_i - arg v_j)),
+ * spec [C][T][F] and steer_vector [F][C] complex64, out [T][F] float32. */
+int setk_directional_feats(setk_handle_t h, const float* spec, const float* steer_vector,
+                           const int* pairs, int n_pairs, int num_channels, int num_frames,
+                           int num_bins, float* out, void* stream);
+
+/* FixedBeamformer.run + inverse_stft for a batch (apply_fixed_beamformer.py:
+ * 38-48, libs/beamformer.py:323-340): wave[u] = istft(sum_c conj(w[f][c]) X_c),
+ * rescaled to max |audio[u]| (SpectrogramReader.maxabs).  weights: n_sets
+ * filters in the reference layout [set][F = 257][C] complex64 (host or device);
+ * weight_index[u] (host, may be NULL = set 0) picks the beam of utterance u.
+ * audio / wave: device pointers as for setk_enhance_batch; flags:
+ * SETK_FLAG_OUT_PCM16.  Needs the n_fft = 512 plan. */
+int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
+                             const float* const* audio, const int* num_samples,
+                             const float* weights, int n_sets, const int* weight_index,
+                             void* const* wave, int flags, void* stream);
+
 /* ---- fused hot path ------------------------------------------------------
  * The compute body of apply_adaptive_beamformer.py:130-178 for a batch of
  * utterances that share the channel count, in four kernel stages:

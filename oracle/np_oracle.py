@@ -311,6 +311,22 @@ def pmwf_weight(Rs, Rn, beta=0, ref_channel=-1, rank1_appro="", gauge=False):
     return wmat[..., ref_channel]
 
 
+def directional_feats(spectrogram, steer_vector, df_pair=None):
+    """libs/spatial.py:184-208: mean over microphone pairs of
+    cos((arg X_i - arg X_j) - (arg v_i - arg v_j)).  spectrogram M x F x T,
+    steer_vector M x F  ->  T x F.  (A common phase of v cancels: gauge free.)"""
+    M = spectrogram.shape[0]
+    arg_s, arg_t = np.angle(spectrogram), np.angle(steer_vector)
+    if df_pair is None:
+        df_pair = [(i, j) for i in range(M) for j in range(i + 1, M)]
+    df = []
+    for i, j in df_pair:
+        delta_s = arg_s[i] - arg_s[j]
+        delta_t = (arg_t[i] - arg_t[j])[:, None]
+        df.append(np.cos(delta_s - delta_t))
+    return np.transpose(np.average(np.stack(df), axis=0))
+
+
 def beamform(weight, obs):
     # libs/beamformer.py:220-234 ; weight F x N, obs N x F x T -> F x T
     if weight.shape[0] != obs.shape[1] or weight.shape[1] != obs.shape[0]:

@@ -47,7 +47,8 @@ def exported_symbols():
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
         "setk_pcm16_to_float", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
-        "setk_cgmm_masks_batch", "setk_enhance_batch", "setk_set_profiling",
+        "setk_cgmm_masks_batch", "setk_enhance_batch", "setk_apply_weights_batch",
+        "setk_directional_feats", "setk_set_profiling",
         "setk_last_stage_ms"
     ]
 
@@ -95,6 +96,12 @@ def load_library():
         H, POINTER(BfOpts), c_int, c_int, POINTER(c_void_p), POINTER(c_int),
         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int),
         c_void_p
+    ]
+    lib.setk_directional_feats.argtypes = [H, fp, fp, POINTER(c_int), c_int, c_int, c_int, c_int,
+                                           fp, c_void_p]
+    lib.setk_apply_weights_batch.argtypes = [
+        H, c_int, c_int, POINTER(c_void_p), POINTER(c_int), fp, c_int, POINTER(c_int),
+        POINTER(c_void_p), c_int, c_void_p
     ]
     for name in exported_symbols():
         fn = getattr(lib, name)
@@ -285,6 +292,29 @@ class Context:
                 self._h, ctypes.byref(opts), n, int(num_channels), A, NS, M, I, W, ST,
                 current_stream_ptr() if stream is None else stream))
         return list(ST) if want_status else None
+
+    def directional_feats(self, spec, sv, pairs, C, T, F, out, stream=None):
+        """spec [C][T][F], sv [F][C] complex64, pairs [(i, j), ...] -> out [T][F] float32."""
+        flat = [int(v) for p in pairs for v in p]
+        P = (c_int * len(flat))(*flat)
+        self.check(
+            self._lib.setk_directional_feats(self._h, _ptr(spec), _ptr(sv), P, len(flat) // 2, C, T,
+                                             F, _ptr(out),
+                                             current_stream_ptr() if stream is None else stream))
+
+    def apply_weights_batch(self, num_channels, audio_ptrs, num_samples, weights, n_sets,
+                            weight_index, wave_ptrs, flags=0, stream=None):
+        """Fixed beamformer + iSTFT + renorm for a batch; weights [n_sets][257][C]
+        complex64 (numpy or device tensor), weight_index: list of ints or None."""
+        n = len(audio_ptrs)
+        A = (c_void_p * n)(*audio_ptrs)
+        W = (c_void_p * n)(*wave_ptrs)
+        NS = (c_int * n)(*[int(v) for v in num_samples])
+        IDX = (c_int * n)(*[int(v) for v in weight_index]) if weight_index is not None else None
+        self.check(
+            self._lib.setk_apply_weights_batch(
+                self._h, n, int(num_channels), A, NS, _ptr(weights), int(n_sets), IDX, W,
+                int(flags), current_stream_ptr() if stream is None else stream))
 
     def set_profiling(self, on):
         self.check(self._lib.setk_set_profiling(self._h, 1 if on else 0))

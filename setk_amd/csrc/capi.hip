@@ -852,6 +852,39 @@ int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
     return SETK_OK;
 }
 
+int setk_directional_feats(setk_handle_t h, const float* spec, const float* steer_vector,
+                           const int* pairs, int n_pairs, int num_channels, int num_frames,
+                           int num_bins, float* out, void* stream) {
+    if (!h || !spec || !steer_vector || !pairs || !out || n_pairs <= 0 || num_channels <= 0 ||
+        num_frames <= 0 || num_bins <= 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    for (int p = 0; p < 2 * n_pairs; ++p)
+        if (pairs[p] < 0 || pairs[p] >= num_channels)
+            return fail(h, SETK_ERR_INVALID, "microphone pair out of range");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h);
+    const int C = num_channels, T = num_frames, F = num_bins;
+    const float *d_spec, *d_sv;
+    int rc = stage_in(h, spec, (size_t)C * T * F * 2, s, &d_spec);
+    if (rc) return rc;
+    rc = stage_in(h, steer_vector, (size_t)F * C * 2, s, &d_sv);
+    if (rc) return rc;
+    void* d_pairs;
+    rc = upload(h, pairs, (size_t)2 * n_pairs * sizeof(int), s, &d_pairs);
+    if (rc) return rc;
+    OutBuf ob;
+    rc = stage_out(h, out, (size_t)T * F * sizeof(float), &ob);
+    if (rc) return rc;
+    HIP_TRY(h, launch_directional_feats(d_spec, d_sv, static_cast<const int*>(d_pairs), n_pairs, C, T,
+                                        F, static_cast<float*>(ob.dev), s));
+    rc = copy_back(h, ob, s);
+    if (rc) return rc;
+    // `pairs` was uploaded from the caller's host array: drained before returning
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
 int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int num_frames,
                     int num_bins, int num_iters, const float* init_mask, float* gamma_out,
                     float* mask_out, void* stream) {
@@ -894,6 +927,114 @@ int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int nu
         if (rc) return rc;
     }
     if (om.host || (gamma_out && og.host)) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
+int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
+                             const float* const* audio, const int* num_samples,
+                             const float* weights, int n_sets, const int* weight_index,
+                             void* const* wave, int flags, void* stream) {
+    if (!h || n_utts <= 0 || !audio || !num_samples || !weights || n_sets <= 0 || !wave)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    int rc = require_plan512(h);
+    if (rc) return rc;
+    const int C = num_channels;
+    if (C < 1 || C > kMaxChannels) return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    if (weight_index)
+        for (int u = 0; u < n_utts; ++u)
+            if (weight_index[u] < 0 || weight_index[u] >= n_sets)
+                return fail(h, SETK_ERR_INVALID, "weight index out of range");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h);
+    const bool pcm16 = (flags & SETK_FLAG_OUT_PCM16) != 0;
+    const StftGeom g = geom_of(h);
+
+    std::vector<UttDesc> uds(n_utts);
+    std::vector<WorkItem> items;
+    std::vector<int> all_frames(n_utts);
+    for (int u = 0; u < n_utts; ++u) {
+        all_frames[u] = setk_stft_num_frames(h, num_samples[u]);
+        if (all_frames[u] < 0) return all_frames[u];
+    }
+    const int target = choose_target(all_frames, h->p2_items, kSuperTile, kSuperTile * 4);
+    int max_len = 0, max_samples = 0;
+    size_t f32_scratch = 0;
+    for (int u = 0; u < n_utts; ++u) {
+        UttDesc& ud = uds[u];
+        memset(&ud, 0, sizeof(ud));
+        if (!audio[u] || !wave[u]) return fail(h, SETK_ERR_INVALID, "null utterance pointer");
+        ud.audio = audio[u];
+        ud.num_samples = num_samples[u];
+        ud.num_frames = all_frames[u];
+        ud.out_len = setk_istft_num_samples(h, ud.num_frames, -1);
+        ud.wave_out = wave[u];
+        max_len = std::max(max_len, ud.out_len);
+        max_samples = std::max(max_samples, ud.num_samples);
+        std::vector<std::pair<int, int>> r;
+        split_frames(ud.num_frames, target, kSuperTile, &r);
+        for (auto& q : r) items.push_back({u, q.first, q.second, 0, q.second == ud.num_frames});
+        f32_scratch += ((size_t)ud.out_len * 4 + 255) & ~(size_t)255;
+    }
+    float* d_f32 = nullptr;
+    if (pcm16) {
+        d_f32 = static_cast<float*>(arena_alloc(h, f32_scratch));
+        if (!d_f32) return fail(h, SETK_ERR_NOMEM, "arena");
+    }
+    size_t off = 0;
+    for (int u = 0; u < n_utts; ++u) {
+        if (pcm16) {
+            uds[u].wave_f32 = reinterpret_cast<float*>(reinterpret_cast<char*>(d_f32) + off);
+            off += ((size_t)uds[u].out_len * 4 + 255) & ~(size_t)255;
+        } else {
+            uds[u].wave_f32 = static_cast<float*>(wave[u]);
+        }
+    }
+    void *d_uds_v, *d_items_v, *d_idx_v = nullptr;
+    rc = upload(h, uds.data(), uds.size() * sizeof(UttDesc), s, &d_uds_v);
+    if (rc) return rc;
+    rc = upload(h, items.data(), items.size() * sizeof(WorkItem), s, &d_items_v);
+    if (rc) return rc;
+    if (weight_index) {
+        rc = upload(h, weight_index, (size_t)n_utts * sizeof(int), s, &d_idx_v);
+        if (rc) return rc;
+    }
+    const float* d_sets;
+    rc = stage_in(h, weights, (size_t)n_sets * kBins * C * 2, s, &d_sets);
+    if (rc) return rc;
+    float* d_w = static_cast<float*>(arena_alloc(h, (size_t)n_utts * C * kBinsPad * sizeof(float2)));
+    unsigned* d_norm = static_cast<unsigned*>(arena_alloc(h, (size_t)2 * n_utts * sizeof(unsigned)));
+    if (!d_w || !d_norm) return fail(h, SETK_ERR_NOMEM, "arena");
+    unsigned* d_omax = d_norm + n_utts;
+    HIP_TRY(h, hipMemsetAsync(d_norm, 0, (size_t)2 * n_utts * sizeof(unsigned), s));
+    const UttDesc* d_uds = static_cast<const UttDesc*>(d_uds_v);
+    HIP_TRY(h, launch_maxabs(d_uds, C, d_norm, n_utts, max_samples, s));
+    HIP_TRY(h, launch_pack_fixed_weights(d_sets, static_cast<const int*>(d_idx_v), n_utts, C, d_w, s));
+
+    Pass2Args p2;
+    memset(&p2, 0, sizeof(p2));
+    p2.utts = d_uds;
+    p2.items = static_cast<const WorkItem*>(d_items_v);
+    p2.weight = d_w;
+    p2.window = h->d_window;
+    p2.synwin = h->d_window;
+    p2.winsq = h->d_winsq;
+    p2.tw256 = h->d_tw256;
+    p2.tw512 = h->d_tw512;
+    p2.outmax_bits = d_omax;
+    p2.g = g;
+    p2.flags = 0;
+    HIP_TRY(h, launch_pass2(C, false, p2, (int)items.size(), s));
+    ScaleArgs sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.utts = d_uds;
+    sc.norm_bits = d_norm;
+    sc.outmax_bits = d_omax;
+    sc.pcm16 = pcm16 ? 1 : 0;
+    HIP_TRY(h, launch_scale(sc, n_utts, max_len, s));
+    // the uploaded descriptors live in the arena: the next call on this handle may
+    // reuse it, so this one must have drained
+    HIP_TRY(h, hipStreamSynchronize(s));
     return SETK_OK;
 }
 

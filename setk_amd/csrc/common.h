@@ -145,6 +145,12 @@ hipError_t launch_cgmm_batch(int C, const void* d_tbl, int n_utts, int F, int ma
 hipError_t launch_ban(const float* w, const float* Rn, int F, int C, float* out, hipStream_t s);
 hipError_t launch_rank1(const float* pv, const float* Rs, const float* Rn, int F, int C,
                         float* out, hipStream_t s);
+hipError_t launch_directional_feats(const float* spec, const float* sv, const int* pairs, int n_pairs,
+                                    int C, int T, int F, float* out, hipStream_t s);
+hipError_t launch_maxabs(const UttDesc* utts, int C, unsigned* norm_bits, int n_utts, int max_samples,
+                         hipStream_t s);
+hipError_t launch_pack_fixed_weights(const float* sets, const int* index, int n_utts, int C,
+                                     float* out, hipStream_t s);
 hipError_t launch_pcm16_to_float(const int16_t* pcm, int C, int N, float* out, hipStream_t s);
 hipError_t launch_beamform_spec(const float* w_fc, const float* spec, int C, int T, int F,
                                 float* out, hipStream_t s);

@@ -297,4 +297,81 @@ hipError_t launch_pcm16_to_float(const int16_t* pcm, int C, int N, float* out, h
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Helpers of the fixed-weight path (apply_fixed_beamformer.py:38-48):
+// max |audio| per utterance (SpectrogramReader.maxabs, the renorm target) and
+// the reference's F x M weight sets -> the planar [C][264] layout of pass 2.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxabs_kernel(const UttDesc* utts, int C,
+                                                     unsigned* norm_bits) {
+    const UttDesc ud = utts[blockIdx.y];
+    const size_t n = (size_t)C * ud.num_samples;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        m = fmaxf(m, fabsf(ud.audio[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(norm_bits + blockIdx.y, __float_as_uint(m));
+}
+
+hipError_t launch_maxabs(const UttDesc* utts, int C, unsigned* norm_bits, int n_utts, int max_samples,
+                         hipStream_t s) {
+    int bx = (int)(((size_t)C * max_samples + 256 * 16 - 1) / (256 * 16));
+    bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+    hipLaunchKernelGGL(maxabs_kernel, dim3(bx, n_utts), dim3(256), 0, s, utts, C, norm_bits);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void pack_fixed_weights_kernel(const float2* __restrict__ sets,
+                                                                 const int* __restrict__ index,
+                                                                 int C, float2* __restrict__ out) {
+    const int u = blockIdx.y;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= kBinsPad) return;
+    const float2* w = sets + (size_t)(index ? index[u] : 0) * kBins * C;
+    for (int c = 0; c < C; ++c)
+        out[((size_t)u * C + c) * kBinsPad + f] = (f < kBins) ? w[(size_t)f * C + c] : make_float2(0.f, 0.f);
+}
+
+hipError_t launch_pack_fixed_weights(const float* sets, const int* index, int n_utts, int C,
+                                     float* out, hipStream_t s) {
+    hipLaunchKernelGGL(pack_fixed_weights_kernel, dim3((kBinsPad + 255) / 256, n_utts), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(sets), index, C,
+                       reinterpret_cast<float2*>(out));
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// directional_feats (libs/spatial.py:184-208):
+//   out[t][f] = mean_p cos((arg X_i - arg X_j)[t][f] - (arg v_i - arg v_j)[f])
+// over the microphone pairs p = (i, j).  spec [C][T][F], sv [F][C] complex64.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void directional_feats_kernel(
+    const float2* __restrict__ spec, const float2* __restrict__ sv, const int* __restrict__ pairs,
+    int n_pairs, int C, int T, int F, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)T * F;
+    if (i >= n) return;
+    const int f = (int)(i % F);
+    float acc = 0.f;
+    for (int p = 0; p < n_pairs; ++p) {
+        const int a = pairs[2 * p], b = pairs[2 * p + 1];
+        const float2 xa = spec[(size_t)a * n + i], xb = spec[(size_t)b * n + i];
+        const float2 va = sv[(size_t)f * C + a], vb = sv[(size_t)f * C + b];
+        const float ds = atan2f(xa.y, xa.x) - atan2f(xb.y, xb.x);
+        const float dt = atan2f(va.y, va.x) - atan2f(vb.y, vb.x);
+        acc += cosf(ds - dt);
+    }
+    out[i] = acc / (float)n_pairs;
+}
+
+hipError_t launch_directional_feats(const float* spec, const float* sv, const int* pairs, int n_pairs,
+                                    int C, int T, int F, float* out, hipStream_t s) {
+    const size_t n = (size_t)T * F;
+    hipLaunchKernelGGL(directional_feats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(spec), reinterpret_cast<const float2*>(sv),
+                       pairs, n_pairs, C, T, F, out);
+    return hipGetLastError();
+}
+
 }  // namespace setk

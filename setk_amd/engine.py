@@ -34,7 +34,9 @@ class Pcm16Frames(object):
         frames = np.asarray(frames)
         if frames.dtype != np.int16 or frames.ndim != 2:
             raise ValueError("Pcm16Frames expects an int16 array of shape N x C")
-        self.frames = np.ascontiguousarray(frames)
+        # (a private, writable copy: np.frombuffer views of file bytes are read-only
+        # and torch.from_numpy wants to own writable memory)
+        self.frames = np.array(frames, dtype=np.int16, order="C", copy=True)
 
     @property
     def num_channels(self):
@@ -251,6 +253,120 @@ class BatchEnhancer(object):
                                    [t.data_ptr() for t in waves], want_status=True)
         for j, i in enumerate(batch):
             results[i] = (waves[j].cpu().numpy() if status[j] == 0 else None, status[j])
+
+
+class FixedBatchBeamformer(object):
+    """apply_fixed_beamformer.py:38-48 for a batch: FixedBeamformer.run +
+    inverse_stft with the renorm to max |audio|.  weights: B x F x M complex (the
+    reference's layout); run() takes [(samps C x N float32 | Pcm16Frames, beam)]
+    and returns the waveforms (int16 when pcm16 else float32) in input order."""
+
+    def __init__(self, weights, frame_len=512, frame_hop=256, center=True,
+                 round_power_of_two=True, window="hann", pcm16=False, device=None,
+                 max_batch_samples=1 << 29):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _ffi.SetkError("setk_amd needs an MI355X GPU (no CPU fallback)")
+        self.ctx = _ffi.default_context(device)
+        self.dev = torch.device("cuda", self.ctx.device)
+        weights = np.asarray(weights)
+        if weights.ndim == 2:
+            weights = weights[None]
+        self.weights = np.ascontiguousarray(weights, dtype=np.complex64)  # B x F x M
+        n_fft = nextpow2(frame_len) if round_power_of_two else frame_len
+        self.stft = dict(frame_len=frame_len, frame_hop=frame_hop, n_fft=n_fft, center=center,
+                         window=stft_window(window, frame_len))
+        self.n_fft = n_fft
+        if self.weights.shape[1] != n_fft // 2 + 1:
+            raise ValueError(f"weights have {self.weights.shape[1]} bins, the transform "
+                             f"{n_fft // 2 + 1}")
+        self.pcm16 = pcm16
+        self.max_batch_samples = max_batch_samples
+        self._d_weights = None
+
+    def _plan(self):
+        s = self.stft
+        self.ctx.stft_plan(s["frame_len"], s["frame_hop"], s["n_fft"], s["center"], s["window"])
+
+    def run(self, utts):
+        self._plan()
+        results = [None] * len(utts)
+        groups = {}
+        for i, (samps, _) in enumerate(utts):
+            groups.setdefault(_channels_and_size(samps)[0], []).append(i)
+        for C, idx in groups.items():
+            if C != self.weights.shape[2]:
+                raise ValueError(f"Input obs do not match with weight, {self.weights.shape[1:]} "
+                                 f"vs {C} channels")
+            batch, nsamp = [], 0
+            for i in idx:
+                n = _channels_and_size(utts[i][0])[1]
+                if batch and nsamp + n > self.max_batch_samples:
+                    self._run(utts, batch, C, results)
+                    batch, nsamp = [], 0
+                batch.append(i)
+                nsamp += n
+            if batch:
+                self._run(utts, batch, C, results)
+        return results
+
+    def _upload(self, samps, C):
+        torch, dev = self.torch, self.dev
+        if isinstance(samps, Pcm16Frames):
+            pcm = torch.from_numpy(samps.frames).to(dev)
+            N = samps.frames.shape[0]
+            a = torch.empty((C, N), dtype=torch.float32, device=dev)
+            self.ctx.pcm16_to_float(pcm, C, N, a)
+            return a, N
+        samps = np.ascontiguousarray(samps, dtype=np.float32)
+        if samps.ndim == 1:
+            samps = samps[None]
+        return torch.from_numpy(samps).to(dev), samps.shape[1]
+
+    def _run(self, utts, batch, C, results):
+        torch, ctx, dev = self.torch, self.ctx, self.dev
+        if self.n_fft != 512:
+            return self._run_unfused(utts, batch, C, results)
+        if self._d_weights is None:
+            self._d_weights = torch.from_numpy(self.weights).to(dev)
+        audio, waves, ns, beams = [], [], [], []
+        for i in batch:
+            samps, beam = utts[i]
+            a, N = self._upload(samps, C)
+            L = ctx.istft_num_samples(ctx.num_frames(N))
+            audio.append(a)
+            waves.append(torch.empty(L, dtype=torch.int16 if self.pcm16 else torch.float32,
+                                     device=dev))
+            ns.append(N)
+            beams.append(int(beam))
+        ctx.apply_weights_batch(C, [t.data_ptr() for t in audio], ns, self._d_weights,
+                                self.weights.shape[0], beams, [t.data_ptr() for t in waves],
+                                flags=_ffi.FLAG_OUT_PCM16 if self.pcm16 else 0)
+        for j, i in enumerate(batch):
+            results[i] = waves[j].cpu().numpy()
+
+    def _run_unfused(self, utts, batch, C, results):
+        """n_fft != 512: setk_stft -> setk_beamform -> setk_istft per utterance."""
+        torch, ctx, dev = self.torch, self.ctx, self.dev
+        F = self.n_fft // 2 + 1
+        for i in batch:
+            samps, beam = utts[i]
+            a, N = self._upload(samps, C)
+            T = ctx.num_frames(N)
+            spec = torch.empty((C, T, F), dtype=torch.complex64, device=dev)
+            ctx.stft(a, spec)
+            w = torch.from_numpy(self.weights[int(beam)]).to(dev)
+            enh = torch.empty((T, F), dtype=torch.complex64, device=dev)
+            ctx.beamform(w, spec, C, T, F, enh)
+            L = ctx.istft_num_samples(T)
+            wave = torch.empty((1, L), dtype=torch.float32, device=dev)
+            norm = a.abs().max().reshape(1).contiguous()
+            ctx.istft(enh.reshape(1, T, F), 1, T, None, norm, wave)
+            out = wave[0]
+            if self.pcm16:
+                out = torch.round(out * 32767.0).to(torch.int16)
+            results[i] = out.cpu().numpy()
 
 
 class CgmmEstimator(object):

@@ -332,3 +332,86 @@ def test_pcm16_device_ingest_is_bit_identical(tmp_path):
                                                       (host, mask, None)])
     assert st_dev == 0 and st_host == 0
     assert np.array_equal(w_dev, w_host)
+
+
+def _consumer_inputs(td, g):
+    from setk_amd.libs import wavio
+    with open(os.path.join(td, "wav.scp"), "w") as ws, open(os.path.join(td, "mask.scp"), "w") as ms, \
+            open(os.path.join(td, "beam.scp"), "w") as bs:
+        for k in ("u0", "u1"):
+            wavio.write_pcm16(os.path.join(td, f"{k}.wav"), g[f"{k}.pcm"], 16000)
+            np.save(os.path.join(td, f"{k}.npy"), g[f"{k}.mask"])
+            ws.write(f"{k} {td}/{k}.wav\n")
+            ms.write(f"{k} {td}/{k}.npy\n")
+            bs.write(f"{k} {int(g[f'{k}.beam'])}\n")
+    np.save(os.path.join(td, "w.npy"), g["weights"])
+
+
+def test_consumers_fixed_beamformer_and_directional_feats(tmp_path):
+    """the drop-in apply_fixed_beamformer.py / compute_df_on_mask.py
+    (and the library calls under them) against what the unmodified reference
+    CLIs produced for the same inputs (tests/golden/ref_consumers.npz)."""
+    from setk_amd.engine import FixedBatchBeamformer, Pcm16Frames
+    from setk_amd.libs import beamformer as B, spatial as S, utils as U, wavio
+    from setk_amd.libs.data_handler import ScriptReader
+    g = load_golden("ref_consumers.npz")
+    td = str(tmp_path)
+    _consumer_inputs(td, g)
+    kw = dict(frame_len=512, frame_hop=256, center=True, window="hann")
+    pairs = [(0, 1), (1, 3), (0, 2)]
+
+    # ---- library level ----
+    eng = FixedBatchBeamformer(g["weights"], pcm16=True)
+    outs = eng.run([(Pcm16Frames(g[f"{k}.pcm"]), int(g[f"{k}.beam"])) for k in ("u0", "u1")])
+    for k, pcm in zip(("u0", "u1"), outs):
+        ref = g[f"{k}.fixed"]
+        assert pcm.dtype == np.int16 and pcm.shape == ref.shape
+        assert rms(pcm.astype(np.float64), ref.astype(np.float64)) / rms(ref.astype(np.float64)) < 1e-3
+        samps = g[f"{k}.pcm"].T.astype(np.float32) / np.float32(32768)
+        obs = np.stack([U.forward_stft(c, round_power_of_two=True, transpose=False, **kw)
+                        for c in samps])                                    # M x F x T
+        sv = B.solve_pevd(B.compute_covar(obs, np.minimum(g[f"{k}.mask"], 1)))
+        df = S.directional_feats(obs, sv.T, df_pair=pairs)
+        assert df.shape == g[f"{k}.df"].shape and df.dtype == np.float32
+        assert np.max(np.abs(df - g[f"{k}.df"])) < 2e-3
+        assert np.max(np.abs(df - o.directional_feats(obs, sv.T, df_pair=pairs))) < 1e-4
+    with pytest.raises(ValueError):
+        S.directional_feats(obs, sv.T[:2], df_pair=pairs)
+
+    # ---- command line level ----
+    py = [sys.executable]
+    r = subprocess.run(py + [os.path.join(ROOT, "scripts", "sptk", "apply_fixed_beamformer.py"),
+                             "--beam", f"{td}/beam.scp", f"{td}/wav.scp", f"{td}/w.npy", f"{td}/fixed"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Processed 2 utterances" in r.stderr
+    r2 = subprocess.run(py + [os.path.join(ROOT, "scripts", "sptk", "compute_df_on_mask.py"),
+                              "--mask-format", "numpy", "--df-pair", "0,1;1,3;0,2", "--scp",
+                              f"{td}/df.scp", f"{td}/wav.scp", f"{td}/mask.scp", f"{td}/df.ark"],
+                        capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    feats = ScriptReader(f"{td}/df.scp")
+    for k in ("u0", "u1"):
+        y, sr = wavio.read(f"{td}/fixed/{k}.wav", dtype="int16")
+        ref = g[f"{k}.fixed"].astype(np.float64)
+        assert sr == 16000 and rms(y.astype(np.float64), ref) / rms(ref) < 1e-3
+        assert np.max(np.abs(feats[k] - g[f"{k}.df"])) < 2e-3
+    # a single F x M weight needs no beam table (the reference stumbles here)
+    np.save(f"{td}/w1.npy", g["weights"][1])
+    r3 = subprocess.run(py + [os.path.join(ROOT, "scripts", "sptk", "apply_fixed_beamformer.py"),
+                              f"{td}/wav.scp", f"{td}/w1.npy", f"{td}/fixed1"],
+                        capture_output=True, text=True, timeout=600)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    # other transform size: the stand-alone operator path of the same engine
+    rng = np.random.default_rng(9)
+    w1k = ((rng.standard_normal((2, 513, 4)) + 1j * rng.standard_normal((2, 513, 4))) / 4).astype(
+        np.complex64)
+    eng2 = FixedBatchBeamformer(w1k, frame_len=1024, frame_hop=256)
+    samps = g["u1.pcm"].T.astype(np.float32) / np.float32(32768)
+    (wav,) = eng2.run([(samps, 1)])
+    kw2 = dict(frame_len=1024, frame_hop=256, center=True, window="hann")
+    obs = np.stack([o.forward_stft(c, round_power_of_two=True, transpose=False, **kw2)
+                    for c in samps])
+    ref = o.inverse_stft(o.beamform(w1k[1], obs), norm=float(np.max(np.abs(samps))),
+                         transpose=False, **kw2)
+    assert wav.shape == ref.shape and rms(wav, ref) / rms(ref) < 1e-3

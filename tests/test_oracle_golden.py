@@ -212,3 +212,29 @@ def test_live_reference_enhance():
     ref = libs.beamformer.MvdrBeamformer(257).run(mask, obs)
     ours = o.supervised_run("mvdr", mask, obs)
     assert rel_rms(ours, ref) < 1e-5
+
+
+def test_consumer_cli_goldens():
+    """the oracle reproduces what the unmodified reference CLIs
+    apply_fixed_beamformer.py and compute_df_on_mask.py wrote for the stored
+    inputs (tests/golden/ref_consumers.npz, oracle/make_golden.py)."""
+    g = load_golden("ref_consumers.npz")
+    kw = dict(frame_len=512, frame_hop=256, center=True, window="hann")
+    for k in ("u0", "u1"):
+        samps = g[f"{k}.pcm"].T.astype(np.float32) / np.float32(32768)
+        obs = np.stack([o.forward_stft(c, round_power_of_two=True, transpose=False, **kw)
+                        for c in samps])                                   # M x F x T
+        # fixed beamformer: beamform + inverse_stft, renorm to max |audio|, PCM16
+        w = g["weights"][int(g[f"{k}.beam"])]
+        enh = o.beamform(w, obs)
+        wav = o.inverse_stft(enh, norm=float(np.max(np.abs(samps))), transpose=False, **kw)
+        ref = g[f"{k}.fixed"].astype(np.float64) / 32768
+        got = np.rint(wav.astype(np.float64) * 32767) / 32768
+        assert wav.shape == ref.shape
+        assert rms(got, ref) / rms(ref) < 2e-4
+        # directional features (gauge free)
+        mask = np.minimum(g[f"{k}.mask"], 1)
+        sv = o.solve_pevd(o.compute_covar(obs, mask))
+        df = o.directional_feats(obs, sv.T, df_pair=[(0, 1), (1, 3), (0, 2)])
+        assert df.shape == g[f"{k}.df"].shape
+        assert np.max(np.abs(df - g[f"{k}.df"])) < 2e-3
