@@ -96,6 +96,13 @@ SETK_DEV void store_half(float* P, int f, const float* ds, const float* dn, cons
         }
 }
 
+// max(m, |a|, |b|) in one VALU instruction
+SETK_DEV float max3_abs(float m, float a, float b) {
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+
 SETK_DEV void wg_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_barrier();
@@ -162,10 +169,11 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
 
         cf raw[16];
         float raw_ms = 0.f, raw_mn = 0.f;
-        bool raw_ok = false;
+        bool raw_ok = false, raw_last = false;
         auto fetch = [&](int tb_tile) {
             const int t = tb_tile + my_tt;
             raw_ok = t < wi.t1;
+            raw_last = t == T - 1;
 #ifdef SETK_NO_GLOAD
             load_raw(raw, my_audio, n_samp, t * a.g.hop - a.g.pad, la, raw_ok && n_samp < 0);
 #else
@@ -180,14 +188,22 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
                 }
             }
         };
+        // max |x|: with hop <= 256 the first halves of consecutive frames tile the
+        // signal, so only the last frame of the utterance needs its second half
+        const bool half_max = a.g.hop <= kNfft / 2;
         auto produce = [&](int b, int tb_next_own) {
             cf* slot = xt0 + (b * NF + my_i) * SL;
             cf v[16];
 #pragma unroll
+            for (int j = 0; j < 8; ++j) mx = max3_abs(mx, raw[j].x, raw[j].y);
+            if (!half_max || raw_last) {
+#pragma unroll
+                for (int j = 8; j < 16; ++j) mx = max3_abs(mx, raw[j].x, raw[j].y);
+            }
+#pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const float2 d = raw[j];
                 const float2 w = w2[la + 16 * j];
-                mx = fmaxf(mx, fmaxf(fabsf(d.x), fabsf(d.y)));
                 v[j] = make_float2(d.x * w.x, d.y * w.y);
             }
             if (ny_lane) {
