@@ -222,8 +222,12 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                     cf Xk, Xm;
                     rfft_split(Zk, Zm, t5[16 * m], Xk, Xm);
                     const cf wk = wlo[16 * m], wm = wmir[16 * (7 - m)];
-                    const cf yk1 = cadd(Yk[m], cmulc(Xk, wk));
-                    const cf ym1 = cadd(Ym[m], cmulc(Xm, wm));
+                    // y + x conj(w) as two FMA chains (4 instructions; cadd(cmulc())
+                    // compiles to 6 without reassociation)
+                    const cf yk1 = make_float2(fmaf(Xk.x, wk.x, fmaf(Xk.y, wk.y, Yk[m].x)),
+                                               fmaf(Xk.y, wk.x, fmaf(-Xk.x, wk.y, Yk[m].y)));
+                    const cf ym1 = make_float2(fmaf(Xm.x, wm.x, fmaf(Xm.y, wm.y, Ym[m].x)),
+                                               fmaf(Xm.y, wm.x, fmaf(-Xm.x, wm.y, Ym[m].y)));
                     if (m == 0) {
                         // lane 0: X[0], X[256] are real and only Re Y[0], Re Y[256]
                         // reach the inverse (numpy irfft drops their imag); the
