@@ -194,3 +194,16 @@ def test_enhance_edge_geometries(N, hop, center):
             assert np.all(np.isfinite(wav))
     finally:
         c2.close()
+
+
+def test_randomised_geometry_sweep():
+    """tools/stress.py: 30 random draws of channels (1-8), ragged batch, hop
+    (64..512), centring and beamformer against the oracle."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    import os
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress.py"), "30", "7"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "CHECK" not in r.stdout

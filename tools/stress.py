@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Randomised parity sweep of the fused path against the CPU oracle (run on a
+GPU box): channels 1-8, ragged batches, hops 64..512, centred or not, the
+gauge-free PMWF-0 and gauge-fixed MVDR.  Prints the worst relative RMS.
+    python tools/stress.py [n_cases] [seed]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+from oracle import np_oracle as o  # noqa: E402
+from setk_amd import _ffi  # noqa: E402
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    dev = torch.device("cuda:0")
+    worst = 0.0
+    for case in range(n_cases):
+        C = int(rng.integers(1, 9))
+        hop = int(rng.choice([64, 128, 160, 200, 256, 256, 256, 384, 512]))
+        center = bool(rng.integers(0, 2)) or hop == 256
+        n_utts = int(rng.integers(1, 6))
+        kind = "pmwf-0" if rng.integers(0, 2) else "mvdr"
+        lens = [int(rng.integers(max(600, (C + 4) * hop), 30000)) for _ in range(n_utts)]
+        ctx = _ffi.Context(0)
+        ctx.stft_plan(512, hop, 512, center)
+        kw = dict(frame_len=512, frame_hop=hop, center=center, window="hann")
+        utts, masks, refs = [], [], []
+        for u, N in enumerate(lens):
+            mix, sp, nz = o.synth_utterance(1000 * case + u, C, N, return_parts=True)
+            mask = (0.1 + 0.8 * o.irm_mask(sp, nz, frame_len=512, frame_hop=hop, center=center)).astype(
+                np.float32)
+            utts.append(mix)
+            masks.append(mask)
+            refs.append(o.enhance_utterance(mix, mask, kind=kind, gauge=True, **kw))
+        a = [torch.from_numpy(u).to(dev) for u in utts]
+        m = [torch.from_numpy(x).to(dev) for x in masks]
+        outs = [torch.empty(ctx.istft_num_samples(ctx.num_frames(N)), dtype=torch.float32, device=dev)
+                for N in lens]
+        okw = dict(kind=0) if kind == "mvdr" else dict(kind=2, pmwf_beta=0.0, pmwf_ref=-1)
+        if C == 1:
+            okw = dict(kind=0)
+        opts = _ffi.BfOpts(flags=_ffi.FLAG_CLAMP_MASK, **okw)
+        st = ctx.enhance_batch(opts, C, [t.data_ptr() for t in a], lens, [t.data_ptr() for t in m], None,
+                               [t.data_ptr() for t in outs])
+        torch.cuda.synchronize()
+        errs = []
+        for w, r, s in zip(outs, refs, st):
+            w = w.cpu().numpy()
+            assert w.shape == r.shape, (w.shape, r.shape)
+            e = float(np.sqrt(np.mean((w - r) ** 2)) / max(np.sqrt(np.mean(r ** 2)), 1e-12))
+            errs.append(e)
+        worst = max(worst, max(errs))
+        flag = "" if max(errs) < 2e-3 and not any(st) else "   <-- CHECK"
+        print(f"case {case:3d} C={C} hop={hop} center={int(center)} {kind:6s} lens={lens} "
+              f"status={st} max rel rms {max(errs):.2e}{flag}")
+        ctx.close()
+    print(f"worst relative rms over {n_cases} cases: {worst:.3e}")
+    return 0 if worst < 2e-3 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
