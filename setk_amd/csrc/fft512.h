@@ -121,36 +121,125 @@ SETK_DEV void fft256_stage_b(cf (&v)[16], const cf* slot, int la, int ls) {
     dft16<DIR>(v);
 }
 
-// Padded-transpose variants: the 16x16 exchange uses row stride 17 instead of
-// the XOR swizzle, so every LDS address is one base register plus an immediate
-// (the swizzle costs ~30 loop-invariant address registers, which matters at a
-// 128-VGPR budget).  The slot must hold kSlotPad entries and consecutive slots
-// must be an odd multiple of 128 bytes apart for the two quad-rows of a
-// 32-lane LDS group to use complementary banks.
-constexpr int kSlotPad = 16 * 17;  // 272 complex entries
+// Padded-transpose variants: the 16x16 exchange uses a padded row stride instead
+// of the XOR swizzle, so every LDS address is one base register plus an
+// immediate (the swizzle costs ~30 loop-invariant address registers, which
+// matters at a 128-VGPR budget).  The stride is 18 entries = 144 bytes: rows
+// stay 16-byte aligned, so a lane fetches its 16 row entries with eight
+// ds_read_b128 (256 B/clk/CU; the compiler otherwise pairs 8-byte reads into
+// ds_read2_b64 at 128 B/clk), and the sixteen rows of a 16-lane LDS group start
+// 36 dwords apart = sixteen distinct multiples of 4 mod 64: conflict free.  The
+// per-lane tables (window, twiddles) use the same row form.
+// ROW = 18 where the register budget allows the 4-aligned quads of b128 loads
+// (pass 2, 256 VGPRs: 0.92 -> 0.84 ms); ROW = 17 (8-byte reads, nothing for the
+// compiler to widen) at the 128-VGPR budget of pass 1, where the wide form
+// spills (0.90 -> 1.14 ms).
+constexpr int kRow5 = 10;             // row stride of the 8-entry split-twiddle rows
+__host__ __device__ constexpr int slot_entries(int row) { return 16 * row; }  // per transform slot
+// Tables: for even ROW a lane's values form a contiguous 16-byte aligned row
+// (entry stride 1, rows ROW / kRow5 apart); for odd ROW they keep the natural
+// order (entry stride 16, lane la starts at entry la), 256 + 256 + 128 entries.
+__host__ __device__ constexpr int table_entries(int row) {
+    return (row % 2 == 0) ? 2 * 16 * row + 16 * kRow5 : 640;
+}
+template <int ROW> struct LaneTab {
+    static constexpr bool rows = (ROW % 2 == 0);
+    static constexpr int estride = rows ? 1 : 16;       // between a lane's consecutive entries
+    static constexpr int lstride = rows ? ROW : 1;      // between lanes (window, twiddle)
+    static constexpr int lstride5 = rows ? kRow5 : 1;   // between lanes (split twiddle)
+    static constexpr int size = rows ? 16 * ROW : 256;  // entries of the window / twiddle table
+};
 
-template <int DIR>
-SETK_DEV void fft256_stage_a_pad(cf (&v)[16], cf* slot, const cf* tw, int la) {
-    dft16<DIR>(v);
-    cf* dst = slot + la;
-    const cf* twl = tw + la;
+// 16 (or N) consecutive complex entries of a 16-byte aligned LDS row.  WIDE:
+// ds_read_b128 (needs 4-aligned register quads: fine at 256 VGPRs, measured
+// slower at the 128-VGPR budget of pass 1, which reads 8 bytes at a time).
+template <int N, bool WIDE = true>
+SETK_DEV void lds_row(const cf* row, cf (&out)[N]) {
+    if (WIDE) {
+        const float4* r4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(row, 16));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        cf t = v[dft16_pos(q)];
-        if (q) {
-            cf w = twl[q * 16];
-            if (DIR > 0) w.y = -w.y;
-            t = cmul(t, w);
+        for (int n = 0; n < N / 2; ++n) {
+            const float4 t = r4[n];
+            out[2 * n] = make_float2(t.x, t.y);
+            out[2 * n + 1] = make_float2(t.z, t.w);
         }
-        dst[q * 17] = t;
+    } else {
+#pragma unroll
+        for (int n = 0; n < N; ++n) out[n] = row[n];
     }
 }
 
-template <int DIR>
-SETK_DEV void fft256_stage_b_pad(cf (&v)[16], const cf* slot, int la) {
-    const cf* src = slot + la * 17;
+// Per-lane table rows in LDS (filled once per workgroup):
+//   win_l [16][ROW]   row la, entry j: (w[2n], w[2n+1]), n = la + 16 j
+//   tw_l  [16][ROW]   row la, entry q: exp(-2 pi i la q / 256)
+//   tw5_l [16][kRow5] row la, entry m: exp(-2 pi i (la + 16 m) / 512)
+template <int ROW>
+SETK_DEV void fill_lane_tables(cf* win_l, cf* tw_l, cf* tw5_l, const float* window,
+                               const float2* tw256, const float2* tw512, int tid, int nthreads) {
+    for (int i = tid; i < 256; i += nthreads) {
+        const int la = i & 15, j = i >> 4, n = la + 16 * j;
+        typedef LaneTab<ROW> L;
+        win_l[la * L::lstride + j * L::estride] = make_float2(window[2 * n], window[2 * n + 1]);
+        tw_l[la * L::lstride + j * L::estride] = tw256[j * 16 + la];
+    }
+    for (int i = tid; i < 128; i += nthreads) {
+        const int la = i & 15, m = i >> 4;
+        tw5_l[la * LaneTab<ROW>::lstride5 + m * LaneTab<ROW>::estride] = tw512[la + 16 * m];
+    }
+}
+
+// v[j] *= window row entry j (tw_row-style row pointer of this lane)
+template <int ROW>
+SETK_DEV void apply_window(cf (&v)[16], const cf* win_row) {
+    if (LaneTab<ROW>::rows) {
+        const float4* w4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(win_row, 16));
 #pragma unroll
-    for (int n = 0; n < 16; ++n) v[n] = src[n];
+        for (int j = 0; j < 16; j += 2) {
+            const float4 w = w4[j / 2];
+            v[j] = make_float2(v[j].x * w.x, v[j].y * w.y);
+            v[j + 1] = make_float2(v[j + 1].x * w.z, v[j + 1].y * w.w);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const cf w = win_row[j * 16];
+            v[j] = make_float2(v[j].x * w.x, v[j].y * w.y);
+        }
+    }
+}
+
+template <int DIR, int ROW, bool WIDE = (ROW % 2 == 0)>
+SETK_DEV void fft256_stage_a_pad(cf (&v)[16], cf* slot, const cf* tw_row, int la) {
+    dft16<DIR>(v);
+    cf* dst = slot + la;
+    if (WIDE) {
+        const float4* w4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(tw_row, 16));
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            const float4 w = w4[q / 2];  // entries q, q + 1
+            cf t0 = v[dft16_pos(q)], t1 = v[dft16_pos(q + 1)];
+            if (q) t0 = cmul(t0, make_float2(w.x, DIR > 0 ? -w.y : w.y));
+            t1 = cmul(t1, make_float2(w.z, DIR > 0 ? -w.w : w.w));
+            dst[q * ROW] = t0;
+            dst[(q + 1) * ROW] = t1;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            cf t = v[dft16_pos(q)];
+            if (q) {
+                cf w = tw_row[q * 16];
+                if (DIR > 0) w.y = -w.y;
+                t = cmul(t, w);
+            }
+            dst[q * ROW] = t;
+        }
+    }
+}
+
+template <int DIR, int ROW, bool WIDE = (ROW % 2 == 0)>
+SETK_DEV void fft256_stage_b_pad(cf (&v)[16], const cf* slot, int la) {
+    lds_row<16, WIDE>(slot + la * ROW, v);
     dft16<DIR>(v);
 }
 
@@ -229,15 +318,17 @@ SETK_DEV float qr_partner(float x) {
 // (16 - la) & 15, register 15 - m (lane 0: its own register 16 - m), fetched with
 // two DPP moves instead of an LDS round trip.  Writes X[k], X[256-k] (m < 8) into
 // the slot and X[256] to *nyq.
-SETK_DEV void qr_stage23(cf* slot, float* nyq, const cf* tw5, int la) {
+template <int ROW, bool WIDE = (ROW % 2 == 0)>
+SETK_DEV void qr_stage23(cf* slot, float* nyq, const cf* tw5_row, int la) {
     cf v[16];
-    fft256_stage_b_pad<-1>(v, slot, la);
+    fft256_stage_b_pad<-1, ROW, WIDE>(v, slot, la);
     const bool lane0 = (la == 0);
     // bins k = la + 16 m and 256 - k as ONE base register each plus an immediate
     // (written as slot[256 - k] the compiler keeps eight address registers)
     cf* lo = slot + la;
     cf* mir = slot + (256 - 16 * 7) - la;
-    const cf* t5 = tw5 + la;
+    cf t5[8];
+    if (WIDE) lds_row<8, true>(tw5_row, t5);  // else read where used (register budget)
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const cf Zk = v[dft16_pos(m)];
@@ -247,7 +338,7 @@ SETK_DEV void qr_stage23(cf* slot, float* nyq, const cf* tw5, int la) {
         Zm.x = lane0 ? own.x : Zm.x;
         Zm.y = lane0 ? own.y : Zm.y;
         cf Xk, Xm;
-        rfft_split(Zk, Zm, t5[16 * m], Xk, Xm);
+        rfft_split(Zk, Zm, WIDE ? t5[m] : tw5_row[16 * m], Xk, Xm);
         if (m == 0) {
             // lane 0: k = 0 pairs with itself (Z[256] == Z[0]): X[0], X[256]; and
             // the self-paired bin 128 = conj(Z[128])

@@ -118,14 +118,15 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
     constexpr int ND = PairSplit<C>::ND, NO = PairSplit<C>::NO;
     constexpr int NS = 32 / NF;           // transform sets (small C: tiles alternate sets)
     constexpr int F = kBins, FP = kBinsPad;
-    constexpr int SL = kSlotPad;          // slot stride (padded 16x16 transpose)
+    constexpr int ROW = 17;               // transpose / table row stride (fft512.h)
+    constexpr int SL = slot_entries(ROW); // slot stride (padded 16x16 transpose)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* xt0 = reinterpret_cast<cf*>(smem);            // [2][NF][SL]
-    cf* tw = xt0 + 2 * NF * SL;                       // [16][16]
-    cf* tw5 = tw + 256;                               // [128]
-    float* win = reinterpret_cast<float*>(tw5 + 128);  // [512]
-    float* xn0 = win + kNfft;                         // [2][32] nyquist bins (real)
+    cf* win_l = xt0 + 2 * NF * SL;                    // per-lane table rows, see fft512.h
+    cf* tw_l = win_l + LaneTab<ROW>::size;
+    cf* tw5_l = tw_l + LaneTab<ROW>::size;
+    float* xn0 = reinterpret_cast<float*>(win_l + table_entries(ROW));  // [2][32] nyquist bins (real)
     float* nym = xn0 + 64;                            // [2][2][8] bin-256 weights (speech|noise)
     float* red = nym + 32;                            // [16]
 
@@ -138,9 +139,7 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
     const bool clamp = (a.flags & 0x2) != 0;
     const bool has_mn = ud.mask_n != nullptr;
 
-    if (tid < 256) tw[tid] = a.tw256[tid];
-    if (tid < 128) tw5[tid] = a.tw512[tid];
-    if (tid < kNfft) win[tid] = a.window[tid];
+    fill_lane_tables<ROW>(win_l, tw_l, tw5_l, a.window, a.tw256, a.tw512, tid, NT);
 
     float mx = 0.f;
     // covariance-role state (declared here: the epilogue stores it)
@@ -164,7 +163,9 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
         const int my_tt = my_i / C, my_c = my_i - my_tt * C;
         const bool producer = my_set < NS;
         gcfloat_p my_audio = gptr(ud.audio) + (size_t)my_c * n_samp;
-        const float2* w2 = reinterpret_cast<const float2*>(win);
+        const cf* win_row = win_l + la * LaneTab<ROW>::lstride;
+        const cf* tw_row = tw_l + la * LaneTab<ROW>::lstride;
+        const cf* tw5_row = tw5_l + la * LaneTab<ROW>::lstride5;
         const bool ny_lane = !DUMP && producer && my_c == 0 && la == 0;
 
         cf raw[16];
@@ -201,19 +202,16 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
                 for (int j = 8; j < 16; ++j) mx = max3_abs(mx, raw[j].x, raw[j].y);
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float2 d = raw[j];
-                const float2 w = w2[la + 16 * j];
-                v[j] = make_float2(d.x * w.x, d.y * w.y);
-            }
+            for (int j = 0; j < 16; ++j) v[j] = raw[j];
+            apply_window<ROW>(v, win_row);
             if (ny_lane) {
                 const float s = clamp ? fminf(raw_ms, 1.f) : raw_ms;
                 nym[(b * 2 + 0) * 8 + my_tt] = s;
                 nym[(b * 2 + 1) * 8 + my_tt] = raw_ok ? (has_mn ? raw_mn : 1.f - s) : 0.f;
             }
-            fft256_stage_a_pad<-1>(v, slot, tw, la);
+            fft256_stage_a_pad<-1, ROW>(v, slot, tw_row, la);
             __builtin_amdgcn_wave_barrier();
-            qr_stage23(slot, xn0 + b * 32 + my_i, tw5, la);
+            qr_stage23<ROW>(slot, xn0 + b * 32 + my_i, tw5_row, la);
             // the next frame is requested only now: held across the transform it
             // would push the role past 128 VGPRs (the spill reloads then serialise
             // behind the very loads they make room for: measured 1.7 ms vs 1.0)
@@ -373,8 +371,8 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
 template <int C, bool DUMP>
 static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s) {
     constexpr int NF = pass1_tile_frames(C) * C;
-    const size_t lds = (size_t)2 * NF * kSlotPad * sizeof(cf) + 256 * sizeof(cf) + 128 * sizeof(cf) +
-                       kNfft * sizeof(float) + (64 + 32 + 16) * sizeof(float);
+    const size_t lds = (size_t)2 * NF * slot_entries(17) * sizeof(cf) + table_entries(17) * sizeof(cf) +
+                       (64 + 32 + 16) * sizeof(float);
     auto k = stft_covar_kernel<C, DUMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -20,48 +20,20 @@
 
 namespace setk {
 
+constexpr int kRow2 = 18;  // LDS row stride of this pass: 16-byte aligned rows, b128 reads (fft512.h)
+
 SETK_DEV int reflect_index2(int i, int n) {
     if (i < 0) i = -i;
     if (i >= n) i = 2 * (n - 1) - i;
     return i;
 }
 
-SETK_DEV void load_frame2(cf (&v)[16], const float* __restrict__ x, int n_samp, int s, int la,
-                          const float* win, bool valid) {
-    const float2* w2 = reinterpret_cast<const float2*>(win);
-    if (!valid) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = make_float2(0.f, 0.f);
-        return;
-    }
-    const bool interior = (s >= 0) && (s + kNfft <= n_samp) &&
-                          ((reinterpret_cast<uintptr_t>(x + s) & 7) == 0);
-    if (interior) {
-        const float2* p = reinterpret_cast<const float2*>(x + s);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int n = la + 16 * j;
-            const float2 d = p[n];
-            const float2 w = w2[n];
-            v[j] = make_float2(d.x * w.x, d.y * w.y);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int n = la + 16 * j;
-            const float d0 = x[reflect_index2(s + 2 * n, n_samp)];
-            const float d1 = x[reflect_index2(s + 2 * n + 1, n_samp)];
-            const float2 w = w2[n];
-            v[j] = make_float2(d0 * w.x, d1 * w.y);
-        }
-    }
-}
-
-// LDS plan (bytes): slots (16+keep)*2176 (padded 16x16 transpose) | wtab C*257*8 (BF mode) | tw 2048 |
-// win 2048 | synwin 2048 | winsq 2048 | red 16
+// LDS plan (bytes): slots (16+keep)*2304 (padded 16x16 transpose) | wtab C*257*8 (BF mode) |
+// per-lane table rows (window, twiddles; fft512.h) | winsq 2048 | red 16
 size_t pass2_lds_bytes(int C, int keep) {
     size_t wt = ((size_t)C * kBins * sizeof(cf) + 15) & ~(size_t)15;
-    return (size_t)(kSuperTile + keep) * kSlotPad * sizeof(cf) + wt + 4 * 2048 + 64;
+    return (size_t)(kSuperTile + keep) * slot_entries(kRow2) * sizeof(cf) + wt + table_entries(kRow2) * sizeof(cf) + 2048 +
+           64;
 }
 
 // raw (un-windowed) frame points of one quad-row lane: v[j] = (x[s+2n], x[s+2n+1])
@@ -112,22 +84,18 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int keep = a.g.keep;
-    constexpr int SL = kSlotPad;              // slot stride in complex entries
+    constexpr int SL = slot_entries(kRow2);              // slot stride in complex entries
     cf* slots = reinterpret_cast<cf*>(smem);  // [(keep + 16)][SL]
     char* p = smem + (size_t)(ST + keep) * SL * sizeof(cf);
     cf* wtab = reinterpret_cast<cf*>(p);  // [C][257]
     p += ((size_t)C * F * sizeof(cf) + 15) & ~(size_t)15;
-    cf* tw = reinterpret_cast<cf*>(p);
-    p += 2048;
-    float* win = reinterpret_cast<float*>(p);
-    p += 2048;
-    float* synwin = reinterpret_cast<float*>(p);
-    p += 2048;
+    cf* win_l = reinterpret_cast<cf*>(p);  // per-lane table rows (synthesis window ==
+    cf* tw_l = win_l + 16 * kRow2;          // analysis window)
+    cf* tw5_l = tw_l + 16 * kRow2;
+    p += table_entries(kRow2) * sizeof(cf);
     float* winsq = reinterpret_cast<float*>(p);
     p += 2048;
     float* red = reinterpret_cast<float*>(p);
-    cf* tw5 = reinterpret_cast<cf*>(synwin);  // synthesis window == analysis window:
-                                              // the synwin region holds the split twiddles
 
     const int tid = threadIdx.x;
     const int la = tid & 15, grp = tid >> 4;
@@ -140,12 +108,11 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
     const bool post_mask = (a.flags & 0x4) != 0;
     const bool clamp = (a.flags & 0x2) != 0;
 
-    tw[tid] = a.tw256[tid];
-    if (tid < 128) tw5[tid] = a.tw512[tid];
-    for (int i = tid; i < kNfft; i += 256) {
-        win[i] = a.window[i];
-        winsq[i] = a.winsq[i];
-    }
+    fill_lane_tables<kRow2>(win_l, tw_l, tw5_l, a.window, a.tw256, a.tw512, tid, 256);
+    for (int i = tid; i < kNfft; i += 256) winsq[i] = a.winsq[i];
+    const cf* win_row = win_l + la * kRow2;
+    const cf* tw_row = tw_l + la * kRow2;
+    const cf* tw5_row = tw5_l + la * kRow5;
     if (!ISTFT_ONLY) {
         const cf* wsrc = reinterpret_cast<const cf*>(a.weight) + (size_t)wi.utt * C * kBinsPad;
         for (int i = tid; i < C * F; i += 256) {
@@ -158,7 +125,6 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
     // frames needed to complete the first output position of this range
     const int t_first = max(wi.t0 - keep, 0);
     for (int i = tid; i < keep * SL; i += 256) slots[i] = make_float2(0.f, 0.f);
-    const float2* w2 = reinterpret_cast<const float2*>(win);
 
     for (int ts = t_first; ts < wi.t1; ts += ST) {
         cf* slot = slots + (keep + grp) * SL;  // this quad-row's frame slot
@@ -193,21 +159,20 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
             for (int c = 0; c < C; ++c) {
                 cf v[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const float2 w = w2[la + 16 * j];
-                    v[j] = make_float2(nxt[j].x * w.x, nxt[j].y * w.y);
-                }
+                for (int j = 0; j < 16; ++j) v[j] = nxt[j];
+                apply_window<kRow2>(v, win_row);
                 if (c + 1 < C)
                     load_raw(nxt, ud.audio + (size_t)(c + 1) * n_samp, n_samp, t * hop - a.g.pad,
                              la, tvalid);
-                fft256_stage_a_pad<-1>(v, slot, tw, la);
+                fft256_stage_a_pad<-1, kRow2>(v, slot, tw_row, la);
                 __builtin_amdgcn_wave_barrier();
-                fft256_stage_b_pad<-1>(v, slot, la);  // v[pos(kb)] = Z[la + 16 kb]
+                fft256_stage_b_pad<-1, kRow2>(v, slot, la);  // v[pos(kb)] = Z[la + 16 kb]
                 const cf* wc = wtab + c * F;
                 // bins k = la + 16 m and 256 - k: one base register each + immediates
                 const cf* wlo = wc + la;
                 const cf* wmir = wc + (256 - 16 * 7) - la;
-                const cf* t5 = tw5 + la;
+                cf t5[8];
+                lds_row<8>(tw5_row, t5);
                 // Hermitian split in registers: the mirror bin of k = la + 16 m is
                 // register 15 - m of lane (16 - la) & 15 (lane 0: own register 16 - m)
 #pragma unroll
@@ -220,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                     Zm.x = lane0 ? own.x : Zm.x;
                     Zm.y = lane0 ? own.y : Zm.y;
                     cf Xk, Xm;
-                    rfft_split(Zk, Zm, t5[16 * m], Xk, Xm);
+                    rfft_split(Zk, Zm, t5[m], Xk, Xm);
                     const cf wk = wlo[16 * m], wm = wmir[16 * (7 - m)];
                     // y + x conj(w) as two FMA chains (4 instructions; cadd(cmulc())
                     // compiles to 6 without reassociation)
@@ -248,6 +213,8 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
         }
         // ---- optional post-mask, merge into the packed inverse input (registers) ----
         cf Zlo[8], Zhi[8];  // 2 Z'[la + 16 m] and 2 Z'[256 - (la + 16 m)]
+        cf t5m[8];
+        lds_row<8>(tw5_row, t5m);
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int k = la + 16 * m;
@@ -264,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                 ym = cscale(ym, mc);
             }
             cf zk, zm;
-            irfft_merge(yk, ym, tw5[k], zk, zm);
+            irfft_merge(yk, ym, t5m[m], zk, zm);
             if (m == 0) {
                 const cf z0 = make_float2(yk.x + yk.y, yk.x - yk.y);
                 const cf z128 = make_float2(2.f * ym.x, -2.f * ym.y);
@@ -290,16 +257,17 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                 v[j].x = lane0 ? own.x : pv.x;
                 v[j].y = lane0 ? own.y : pv.y;
             }
-            fft256_stage_a_pad<+1>(v, slot, tw, la);
+            fft256_stage_a_pad<+1, kRow2>(v, slot, tw_row, la);
             __builtin_amdgcn_wave_barrier();
-            fft256_stage_b_pad<+1>(v, slot, la);
+            fft256_stage_b_pad<+1, kRow2>(v, slot, la);
             const float sc = tvalid ? (1.f / 256.f) : 0.f;
+            cf wsyn[16];
+            lds_row<16>(win_row, wsyn);
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) {
                 const int n = la + 16 * kb;
                 const cf z = v[dft16_pos(kb)];
-                const float2 w = w2[n];
-                slot[n] = make_float2(z.x * sc * w.x, z.y * sc * w.y);
+                slot[n] = make_float2(z.x * sc * wsyn[kb].x, z.y * sc * wsyn[kb].y);
             }
         }
         __syncthreads();
