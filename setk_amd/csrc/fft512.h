@@ -93,38 +93,14 @@ SETK_DEV void dft16(cf (&v)[16]) {
 
 // ---- 256-point complex transform on 16 lanes ------------------------------
 // Stage A: lane `la` holds v[j] = z[la + 16 j].  Radix-16 over j, twiddle by
-// W256^{la q}, store transposed into the 256-entry LDS slot (XOR swizzle).
-// tw: LDS table tw[q*16 + la] = exp(-2 pi i la q / 256).
-// `la` may carry a swizzle bit: callers pass la ^ (quad-row & 1) as `ls` so that
-// the two quad-rows sharing a 32-lane ds_read_b64 group hit complementary banks.
-template <int DIR>
-SETK_DEV void fft256_stage_a(cf (&v)[16], cf* slot, const cf* tw, int la, int ls) {
-    dft16<DIR>(v);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        cf t = v[dft16_pos(q)];
-        if (q) {
-            cf w = tw[q * 16 + la];
-            if (DIR > 0) w.y = -w.y;
-            t = cmul(t, w);
-        }
-        slot[q * 16 + (ls ^ q)] = t;
-    }
-}
-
-// Stage B (after a barrier): lane `la` gathers sub-transform `la`, radix-16,
-// leaves Z[la + 16 kb] in v[dft16_pos(kb)].
-template <int DIR>
-SETK_DEV void fft256_stage_b(cf (&v)[16], const cf* slot, int la, int ls) {
-#pragma unroll
-    for (int n = 0; n < 16; ++n) v[n] = slot[la * 16 + (n ^ ls)];
-    dft16<DIR>(v);
-}
-
-// Padded-transpose variants: the 16x16 exchange uses a padded row stride instead
-// of the XOR swizzle, so every LDS address is one base register plus an
-// immediate (the swizzle costs ~30 loop-invariant address registers, which
-// matters at a 128-VGPR budget).  The stride is 18 entries = 144 bytes: rows
+// W256^{la q}, store transposed into the LDS slot.  Stage B (no workgroup
+// barrier: a quad-row lives in one wavefront, whose LDS operations complete in
+// order): lane `la` gathers sub-transform `la`, radix-16, and holds
+// Z[la + 16 kb] in v[dft16_pos(kb)].
+//
+// The 16x16 exchange uses a padded row stride (an XOR swizzle was measured
+// first: it costs ~30 loop-invariant address registers), so every LDS address is
+// one base register plus an immediate.  The stride is 18 entries = 144 bytes: rows
 // stay 16-byte aligned, so a lane fetches its 16 row entries with eight
 // ds_read_b128 (256 B/clk/CU; the compiler otherwise pairs 8-byte reads into
 // ds_read2_b64 at 128 B/clk), and the sixteen rows of a 16-lane LDS group start

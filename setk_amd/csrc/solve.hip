@@ -62,7 +62,10 @@ SD int rr_partner(int r, int j) {
 // on sweep exhaustion.
 template <int C>
 SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
-    const double tol2 = 1e-20;  // |g_p^H g_q| <= 1e-10 |g_p||g_q| (outputs are float32)
+    // |g_p^H g_q| <= 1e-8 |g_p||g_q|: the outputs are float32 and the sweeps converge
+    // quadratically, so a tighter bound only adds a last, idle sweep (1e-20 measured
+    // 0.181 ms for the reduce+solve stage, 1e-16 0.174, 1e-14 0.170)
+    const double tol2 = 1e-16;
     bool done = false;
     for (int sweep = 0; sweep < 40 && !done; ++sweep) {
         bool rot = false;
