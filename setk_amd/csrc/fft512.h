@@ -200,11 +200,18 @@ SETK_DEV void fft256_stage_a_pad(cf (&v)[16], cf* slot, const cf* tw_row, int la
             dst[(q + 1) * ROW] = t1;
         }
     } else {
+        // twiddles fetched two steps ahead (at a tight register budget the compiler
+        // otherwise loads each one right before its use and waits out the LDS
+        // latency fifteen times)
+        cf wq[16];
+        wq[1] = tw_row[16];
+        wq[2] = tw_row[32];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
+            if (q + 3 < 16) wq[q + 3] = tw_row[(q + 3) * 16];
             cf t = v[dft16_pos(q)];
             if (q) {
-                cf w = tw_row[q * 16];
+                cf w = wq[q];
                 if (DIR > 0) w.y = -w.y;
                 t = cmul(t, w);
             }
@@ -304,9 +311,16 @@ SETK_DEV void qr_stage23(cf* slot, float* nyq, const cf* tw5_row, int la) {
     cf* lo = slot + la;
     cf* mir = slot + (256 - 16 * 7) - la;
     cf t5[8];
-    if (WIDE) lds_row<8, true>(tw5_row, t5);  // else read where used (register budget)
+    if (WIDE) {
+        lds_row<8, true>(tw5_row, t5);
+    } else {
+        // narrow path: fetched two steps ahead of their use (see fft256_stage_a_pad)
+        t5[0] = tw5_row[0];
+        t5[1] = tw5_row[16];
+    }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
+        if (!WIDE && m + 2 < 8) t5[m + 2] = tw5_row[16 * (m + 2)];
         const cf Zk = v[dft16_pos(m)];
         const cf src = v[dft16_pos(15 - m)];
         cf Zm = make_float2(qr_partner(src.x), qr_partner(src.y));
@@ -314,7 +328,7 @@ SETK_DEV void qr_stage23(cf* slot, float* nyq, const cf* tw5_row, int la) {
         Zm.x = lane0 ? own.x : Zm.x;
         Zm.y = lane0 ? own.y : Zm.y;
         cf Xk, Xm;
-        rfft_split(Zk, Zm, WIDE ? t5[m] : tw5_row[16 * m], Xk, Xm);
+        rfft_split(Zk, Zm, t5[m], Xk, Xm);
         if (m == 0) {
             // lane 0: k = 0 pairs with itself (Z[256] == Z[0]): X[0], X[256]; and
             // the self-paired bin 128 = conj(Z[128])

@@ -211,11 +211,12 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
             }
             fft256_stage_a_pad<-1, ROW>(v, slot, tw_row, la);
             __builtin_amdgcn_wave_barrier();
-            qr_stage23<ROW>(slot, xn0 + b * 32 + my_i, tw5_row, la);
-            // the next frame is requested only now: held across the transform it
-            // would push the role past 128 VGPRs (the spill reloads then serialise
-            // behind the very loads they make room for: measured 1.7 ms vs 1.0)
+            // the next frame is requested between the two radix-16 stages: the
+            // first stage's working set is dead, so the 32 registers in flight fit
+            // the 128-VGPR budget without spills (requested before stage one:
+            // 1.07 ms, here: 0.915, after the split: 0.935)
             if (tb_next_own < wi.t1) fetch(tb_next_own);
+            qr_stage23<ROW>(slot, xn0 + b * 32 + my_i, tw5_row, la);
         };
 
         wg_barrier();  // tables ready
