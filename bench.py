@@ -63,6 +63,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    from setk_amd import build as _build
+    _build.build_library(force=False)  # no-op when the in-tree library is current
     from setk_amd import _ffi, synth
 
     if not torch.cuda.is_available():

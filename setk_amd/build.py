@@ -35,6 +35,14 @@ def build_library(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link the shared
     library.  Returns the library path."""
     os.makedirs(OBJ, exist_ok=True)
+    # one builder at a time (the ranks of a torchrun launch all come through here)
+    import fcntl
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force, verbose):
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
              # SLP packing into v_pk_* costs more moves than it saves here (measured:

@@ -14,6 +14,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line(
         "markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # the in-tree library is git-ignored: (re)build it when a source is newer or it
+    # is absent (hipcc cross-compiles for gfx950 with or without a GPU)
+    from setk_amd import build
+    build.build_library(force=False)
 
 
 @pytest.fixture(scope="session")
