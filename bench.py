@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--beamformer", default="mvdr", choices=["mvdr", "gevd", "pmwf-0"])
     ap.add_argument("--distinct", type=int, default=16,
                     help="distinct synthetic utterances generated per rank (others are copies)")
-    ap.add_argument("--cpu-sample", type=int, default=16,
+    ap.add_argument("--cpu-sample", type=int, default=96,
                     help="utterances timed on the CPU oracle (0 = skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     return ap.parse_args()
