@@ -367,24 +367,45 @@ __global__ __launch_bounds__(256) void scale_kernel(ScaleArgs a) {
     const float sc = (norm > 0.f) ? norm / (omax + eps) : 1.f;
     const int n = ud.out_len;
     const float* src = ud.wave_f32;
+    const int stride = gridDim.x * 256;
+    const int i0 = blockIdx.x * 256 + threadIdx.x;
+    // 16 bytes per lane where the buffers allow it (they do for torch allocations)
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(ud.wave_out)) & 15) == 0;
+    const int n4 = vec ? (n >> 2) : 0;
     if (a.pcm16) {
         int16_t* dst = reinterpret_cast<int16_t*>(ud.wave_out);
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        short4* d4 = reinterpret_cast<short4*>(dst);
+        for (int i = i0; i < n4; i += stride) {
+            const float4 v = s4[i];
+            d4[i] = make_short4((short)(int)rintf(v.x * sc * 32767.f), (short)(int)rintf(v.y * sc * 32767.f),
+                                (short)(int)rintf(v.z * sc * 32767.f), (short)(int)rintf(v.w * sc * 32767.f));
+        }
+        for (int i = 4 * n4 + i0; i < n; i += stride) {
             const float v = rintf(src[i] * sc * 32767.f);
             dst[i] = (int16_t)(int)v;
         }
     } else {
         float* dst = reinterpret_cast<float*>(ud.wave_out);
         if (sc == 1.f && dst == src) return;
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-            dst[i] = src[i] * sc;
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int i = i0; i < n4; i += stride) {
+            float4 v = s4[i];
+            v.x *= sc;
+            v.y *= sc;
+            v.z *= sc;
+            v.w *= sc;
+            d4[i] = v;
+        }
+        for (int i = 4 * n4 + i0; i < n; i += stride) dst[i] = src[i] * sc;
     }
 }
 
 hipError_t launch_scale(const ScaleArgs& a, int n_utts, int max_len, hipStream_t s) {
-    int bx = (max_len + 256 * 8 - 1) / (256 * 8);
+    int bx = (max_len + 256 * 16 - 1) / (256 * 16);  // ~4 float4 per thread
     if (bx < 1) bx = 1;
-    if (bx > 64) bx = 64;
+    if (bx > 256) bx = 256;
     hipLaunchKernelGGL(scale_kernel, dim3(bx, n_utts), dim3(256), 0, s, a);
     return hipGetLastError();
 }
