@@ -45,12 +45,61 @@ SD cd zshfl(cd v, int src) { return make_double2(__shfl(v.x, src, 8), __shfl(v.y
 constexpr int kKindPevd = 100;  // internal: plain solve_pevd(Rs[, Rn])
 constexpr double kEpsF32 = 1.1920928955078125e-07;
 
-// round-robin partner of lane j in round r (8 players, 7 rounds)
-SD int rr_partner(int r, int j) {
-    if (j == 7) return r;
-    int k = (2 * r - j) % 7;
-    if (k < 0) k += 7;
-    return (k == j) ? 7 : k;
+// Exchange with lane j ^ M of the 8-lane group as DPP moves (VALU, a few cycles)
+// instead of ds_bpermute (LDS pipe, ~100 cycles): the 7 perfect matchings
+// j <-> j ^ M, M = 1..7, visit every column pair once per sweep.
+//   M = 1, 2, 3: quad_perm;  M = 7: row_half_mirror (j -> 7 - j = j ^ 7);
+//   M = 4, 5, 6: half_mirror followed by the quad_perm of M ^ 7.
+template <int M>
+SD int dpp_xor(int v) {
+    constexpr int qp[4] = {0, 0xB1, 0x4E, 0x1B};  // quad_perm of j ^ 1, j ^ 2, j ^ 3
+    if constexpr (M == 7) {
+        return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+    } else if constexpr (M < 4) {
+        return __builtin_amdgcn_update_dpp(0, v, qp[M], 0xf, 0xf, true);
+    } else {
+        const int h = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+        return __builtin_amdgcn_update_dpp(0, h, qp[M ^ 7], 0xf, 0xf, true);
+    }
+}
+template <int M>
+SD double dshfl_xor(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = dpp_xor<M>((int)(b & 0xffffffffll));
+    const int hi = dpp_xor<M>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// one rotation of column j against column j ^ M; returns true if it rotated
+template <int C, int M>
+SD bool jacobi_round(cd (&g)[C], int j) {
+    const double tol2 = 1e-16;  // see jacobi_pevd
+    const int p = j ^ M;
+    cd gp[C];
+    double m = 0.0, o = 0.0;
+    cd d = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        gp[i] = make_double2(dshfl_xor<M>(g[i].x), dshfl_xor<M>(g[i].y));
+        m += zabs2(g[i]);
+        o += zabs2(gp[i]);
+        d = zadd(d, zcmul(g[i], gp[i]));
+    }
+    const double dd = zabs2(d);
+    if (dd > tol2 * m * o && dd > 0.0) {
+        const double absd = sqrt(dd);
+        const double sigma = (j < p) ? 1.0 : -1.0;
+        const double zeta = sigma * (o - m) / (2.0 * absd);
+        const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + t * t);
+        const double sn = cs * t;
+        const double f = sigma * sn / absd;
+        const cd ph = make_double2(d.x * f, -d.y * f);  // sigma*sn*conj(d)/|d|
+#pragma unroll
+        for (int i = 0; i < C; ++i) g[i] = zsub(zscale(g[i], cs), zmul(ph, gp[i]));
+        return true;
+    }
+    return false;
 }
 
 // One-sided Jacobi on the columns of a Hermitian PSD matrix: lane j passes
@@ -59,43 +108,22 @@ SD int rr_partner(int r, int j) {
 // the principal eigenvector is that column normalised -- V itself is never
 // accumulated (half the shuffles and flops of the textbook form).  Returns the
 // vector replicated in `out` (unit 2-norm), its eigenvalue, and raises `noconv`
-// on sweep exhaustion.
+// on sweep exhaustion.  Stop: |g_p^H g_q| <= 1e-8 |g_p||g_q| -- the outputs are
+// float32 and the sweeps converge quadratically, so a tighter bound only adds a
+// last, idle sweep (1e-20 measured 0.181 ms for the reduce+solve stage, 1e-16
+// 0.174, 1e-14 0.170).
 template <int C>
 SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
-    // |g_p^H g_q| <= 1e-8 |g_p||g_q|: the outputs are float32 and the sweeps converge
-    // quadratically, so a tighter bound only adds a last, idle sweep (1e-20 measured
-    // 0.181 ms for the reduce+solve stage, 1e-16 0.174, 1e-14 0.170)
-    const double tol2 = 1e-16;
     bool done = false;
     for (int sweep = 0; sweep < 40 && !done; ++sweep) {
         bool rot = false;
-        for (int r = 0; r < 7; ++r) {
-            const int p = rr_partner(r, j);
-            cd gp[C];
-            double m = 0.0, o = 0.0;
-            cd d = make_double2(0.0, 0.0);
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                gp[i] = zshfl(g[i], p);
-                m += zabs2(g[i]);
-                o += zabs2(gp[i]);
-                d = zadd(d, zcmul(g[i], gp[i]));
-            }
-            const double dd = zabs2(d);
-            if (dd > tol2 * m * o && dd > 0.0) {
-                const double absd = sqrt(dd);
-                const double sigma = (j < p) ? 1.0 : -1.0;
-                const double zeta = sigma * (o - m) / (2.0 * absd);
-                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / sqrt(1.0 + t * t);
-                const double sn = cs * t;
-                const double f = sigma * sn / absd;
-                const cd ph = make_double2(d.x * f, -d.y * f);  // sigma*sn*conj(d)/|d|
-#pragma unroll
-                for (int i = 0; i < C; ++i) g[i] = zsub(zscale(g[i], cs), zmul(ph, gp[i]));
-                rot = true;
-            }
-        }
+        rot |= jacobi_round<C, 1>(g, j);
+        rot |= jacobi_round<C, 2>(g, j);
+        rot |= jacobi_round<C, 3>(g, j);
+        rot |= jacobi_round<C, 4>(g, j);
+        rot |= jacobi_round<C, 5>(g, j);
+        rot |= jacobi_round<C, 6>(g, j);
+        rot |= jacobi_round<C, 7>(g, j);
         done = !__any(rot);
     }
     if (!done) noconv = 1;
