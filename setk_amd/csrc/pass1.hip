@@ -406,8 +406,8 @@ hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipSt
 // max(sum_t m, 1e-6) (libs/beamformer.py:99-102).  Output planes per utterance:
 //   [Rs.re NP | Rs.im NP | Rn.re NP | Rn.im NP | (Ry.re NP | Ry.im NP)]
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void covar_finalize_kernel(FinalizeArgs a) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(320) void covar_finalize_kernel(FinalizeArgs a) {
+    const int f = threadIdx.x;  // one workgroup = one (plane, utterance) row of 264 bins
     const int u = blockIdx.z;
     const int C = a.num_channels;
     const int NP = npairs(C);
@@ -445,8 +445,8 @@ __global__ __launch_bounds__(256) void covar_finalize_kernel(FinalizeArgs a) {
 hipError_t launch_finalize(const FinalizeArgs& a, int n_utts, hipStream_t s) {
     const int NP = npairs(a.num_channels);
     const int planes_out = a.with_ry ? 6 * NP : 4 * NP;
-    dim3 grid((kBinsPad + 255) / 256, planes_out, n_utts);
-    hipLaunchKernelGGL(covar_finalize_kernel, grid, dim3(256), 0, s, a);
+    dim3 grid(1, planes_out, n_utts);
+    hipLaunchKernelGGL(covar_finalize_kernel, grid, dim3(320), 0, s, a);
     return hipGetLastError();
 }
 
