@@ -9,7 +9,7 @@
 // One problem = one (utterance, bin).  8 lanes cooperate on a problem (lane j
 // owns column j), 8 problems per wavefront, one wavefront per workgroup:
 //   * principal eigenvectors: one-sided (Hestenes) Jacobi on the columns, the
-//     7 round-robin rounds of a sweep exchange columns with __shfl (width 8);
+//     7 rounds of a sweep pair column j with j ^ m and exchange them with DPP moves;
 //   * Cholesky of the (noise) covariance cooperatively in LDS (row per lane),
 //     triangular solves per lane (each lane its own right-hand side);
 //   * the generalised problem is reduced with the Cholesky factor
