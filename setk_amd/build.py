@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsetk_hip.so")
 SOURCES = ["pass1.hip", "pass2.hip", "solve.hip", "modular.hip", "cgmm.hip", "capi.hip"]
-HEADERS = ["common.h", "fft512.h", os.path.join("..", "..", "include", "setk_hip.h")]
+HEADERS = ["common.h", "fft512.h", "dpp.h", os.path.join("..", "..", "include", "setk_hip.h")]
 ARCH = "gfx950"
 
 

@@ -17,6 +17,7 @@
 // (lanes 0-31 class 0, lanes 32-63 class 1), classes meet through __shfl_xor.
 #include <cstring>
 #include "common.h"
+#include "dpp.h"
 #include "fft512.h"
 #include "../../include/setk_hip.h"
 
@@ -139,11 +140,40 @@ __global__ void cgmm_finalize_kernel(const CgmmArgs* __restrict__ tbl, int em, i
 }
 
 // ---- eigendecomposition of R_k(f): one-sided Jacobi, 8 lanes per problem ----
-ZD int cg_partner(int r, int j) {
-    if (j == 7) return r;
-    int k = (2 * r - j) % 7;
-    if (k < 0) k += 7;
-    return (k == j) ? 7 : k;
+
+// one Jacobi rotation of column j against column j ^ M (the 7 XOR matchings of a
+// sweep, exchanged with DPP moves -- dpp.h), eigenvectors accumulated in v
+template <int C, int M>
+ZD bool cgmm_jacobi_round(zd (&g)[C], zd (&v)[C], int j) {
+    const int p = j ^ M;
+    zd gp[C], vp[C];
+    double m = 0.0, o = 0.0;
+    zd d = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        gp[i] = make_double2(dshfl_xor<M>(g[i].x), dshfl_xor<M>(g[i].y));
+        vp[i] = make_double2(dshfl_xor<M>(v[i].x), dshfl_xor<M>(v[i].y));
+        m += zd_abs2(g[i]);
+        o += zd_abs2(gp[i]);
+        d = zd_add(d, zd_cmul(g[i], gp[i]));
+    }
+    const double dd = zd_abs2(d);
+    if (dd > 1e-26 * m * o && dd > 0.0) {
+        const double absd = sqrt(dd);
+        const double sigma = (j < p) ? 1.0 : -1.0;
+        const double zeta = sigma * (o - m) / (2.0 * absd);
+        const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + t * t);
+        const double fsc = sigma * cs * t / absd;
+        const zd ph = make_double2(d.x * fsc, -d.y * fsc);
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            g[i] = zd_sub(zd_scale(g[i], cs), zd_mul(ph, gp[i]));
+            v[i] = zd_sub(zd_scale(v[i], cs), zd_mul(ph, vp[i]));
+        }
+        return true;
+    }
+    return false;
 }
 
 template <int C>
@@ -176,36 +206,13 @@ __global__ __launch_bounds__(64) void cgmm_eig_kernel(const CgmmArgs* __restrict
     bool done = false;
     for (int sweep = 0; sweep < 40 && !done; ++sweep) {
         bool rot = false;
-        for (int r = 0; r < 7; ++r) {
-            const int p = cg_partner(r, j);
-            zd gp[C], vp[C];
-            double m = 0.0, o = 0.0;
-            zd d = make_double2(0.0, 0.0);
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                gp[i] = zd_shfl(g[i], p);
-                vp[i] = zd_shfl(v[i], p);
-                m += zd_abs2(g[i]);
-                o += zd_abs2(gp[i]);
-                d = zd_add(d, zd_cmul(g[i], gp[i]));
-            }
-            const double dd = zd_abs2(d);
-            if (dd > 1e-26 * m * o && dd > 0.0) {
-                const double absd = sqrt(dd);
-                const double sigma = (j < p) ? 1.0 : -1.0;
-                const double zeta = sigma * (o - m) / (2.0 * absd);
-                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / sqrt(1.0 + t * t);
-                const double fsc = sigma * cs * t / absd;
-                const zd ph = make_double2(d.x * fsc, -d.y * fsc);
-#pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    g[i] = zd_sub(zd_scale(g[i], cs), zd_mul(ph, gp[i]));
-                    v[i] = zd_sub(zd_scale(v[i], cs), zd_mul(ph, vp[i]));
-                }
-                rot = true;
-            }
-        }
+        rot |= cgmm_jacobi_round<C, 1>(g, v, j);
+        rot |= cgmm_jacobi_round<C, 2>(g, v, j);
+        rot |= cgmm_jacobi_round<C, 3>(g, v, j);
+        rot |= cgmm_jacobi_round<C, 4>(g, v, j);
+        rot |= cgmm_jacobi_round<C, 5>(g, v, j);
+        rot |= cgmm_jacobi_round<C, 6>(g, v, j);
+        rot |= cgmm_jacobi_round<C, 7>(g, v, j);
         done = !__any(rot);
     }
     double lam2 = 0.0;

@@ -18,6 +18,7 @@
 // streaming passes; fp64 keeps it at least as accurate as the reference's
 // LAPACK c64/c128 calls.
 #include "common.h"
+#include "dpp.h"
 #include <hip/hip_runtime.h>
 #include "../../include/setk_hip.h"
 
@@ -44,31 +45,6 @@ SD cd zshfl(cd v, int src) { return make_double2(__shfl(v.x, src, 8), __shfl(v.y
 
 constexpr int kKindPevd = 100;  // internal: plain solve_pevd(Rs[, Rn])
 constexpr double kEpsF32 = 1.1920928955078125e-07;
-
-// Exchange with lane j ^ M of the 8-lane group as DPP moves (VALU, a few cycles)
-// instead of ds_bpermute (LDS pipe, ~100 cycles): the 7 perfect matchings
-// j <-> j ^ M, M = 1..7, visit every column pair once per sweep.
-//   M = 1, 2, 3: quad_perm;  M = 7: row_half_mirror (j -> 7 - j = j ^ 7);
-//   M = 4, 5, 6: half_mirror followed by the quad_perm of M ^ 7.
-template <int M>
-SD int dpp_xor(int v) {
-    constexpr int qp[4] = {0, 0xB1, 0x4E, 0x1B};  // quad_perm of j ^ 1, j ^ 2, j ^ 3
-    if constexpr (M == 7) {
-        return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
-    } else if constexpr (M < 4) {
-        return __builtin_amdgcn_update_dpp(0, v, qp[M], 0xf, 0xf, true);
-    } else {
-        const int h = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
-        return __builtin_amdgcn_update_dpp(0, h, qp[M ^ 7], 0xf, 0xf, true);
-    }
-}
-template <int M>
-SD double dshfl_xor(double x) {
-    const long long b = __builtin_bit_cast(long long, x);
-    const int lo = dpp_xor<M>((int)(b & 0xffffffffll));
-    const int hi = dpp_xor<M>((int)(b >> 32));
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
 
 // one rotation of column j against column j ^ M; returns true if it rotated
 template <int C, int M>
