@@ -238,8 +238,14 @@ __global__ __launch_bounds__(64) void cgmm_eig_kernel(const CgmmArgs* __restrict
 }
 
 // ---- E-step: phi, posterior gamma (cluster.py:207-212, 214-235, 261-287) ----
-template <int C>
+// ACCUM: also fold this E-step's gamma M / phi x x^H into the next M-step's
+// partial sums (what cgmm_accum_kernel does in EM mode) -- the spectrogram is
+// then streamed once per EM iteration instead of twice and gamma / phi never
+// leave the registers; the stand-alone E-step (ACCUM = false) only closes the
+// last iteration and writes the outputs.
+template <int C, bool ACCUM>
 __global__ __launch_bounds__(64) void cgmm_estep_kernel(const CgmmArgs* __restrict__ tbl, int last) {
+    constexpr int NP = npairs(C);
     CgmmArgs a = tbl[blockIdx.z];
     if (!last) a.mask_out = nullptr;
     if ((int)blockIdx.y >= a.nchunks) return;
@@ -261,6 +267,10 @@ __global__ __launch_bounds__(64) void cgmm_estep_kernel(const CgmmArgs* __restri
         for (int i = 0; i < C; ++i) Vr[j][i] = Vd[j * C + i];
     }
     const float ld = a.logdet[(size_t)k * F + fc];
+    cf acc[ACCUM ? NP : 1];
+#pragma unroll
+    for (int e = 0; e < (ACCUM ? NP : 1); ++e) acc[e] = make_float2(0.f, 0.f);
+    float sumg = 0.f;
     for (int t = t0; t < t1; ++t) {
         cf x[C];
 #pragma unroll
@@ -282,11 +292,33 @@ __global__ __launch_bounds__(64) void cgmm_estep_kernel(const CgmmArgs* __restri
         const float mx = fmaxf(lp, lo);
         const float mine = 0.5f * expf(lp - mx), other = 0.5f * expf(lo - mx);
         const float g = mine / fmaxf(mine + other, kEps32);
-        if (ok) {
+        if (ACCUM) {
+            const float w = g * (float)C / ph;
+            sumg += g;
+            int e = 0;
+#pragma unroll
+            for (int i = 0; i < C; ++i)
+#pragma unroll
+                for (int j = i; j < C; ++j) {
+                    const cf p = cmulc(x[i], x[j]);
+                    acc[e].x = fmaf(w, p.x, acc[e].x);
+                    if (i != j) acc[e].y = fmaf(w, p.y, acc[e].y);
+                    ++e;
+                }
+        } else if (ok) {
             a.phi[((size_t)k * T + t) * F + f] = ph;
             a.gamma[((size_t)k * T + t) * F + f] = g;
             if (a.mask_out && k == 0) a.mask_out[(size_t)t * F + f] = g;
         }
+    }
+    if (ACCUM && ok) {
+        float* P = a.partials + ((size_t)chunk * 2 + k) * (2 * NP + 1) * a.pitch;
+#pragma unroll
+        for (int e = 0; e < NP; ++e) {
+            P[(size_t)e * a.pitch + f] = acc[e].x;
+            P[(size_t)(NP + e) * a.pitch + f] = acc[e].y;
+        }
+        P[(size_t)(2 * NP) * a.pitch + f] = sumg;
     }
 }
 
@@ -297,14 +329,19 @@ static hipError_t cgmm_run_t(const CgmmArgs* d_tbl, int n_utts, int F, int max_c
     dim3 g_tf((F + 31) / 32, max_chunks, n_utts);
     dim3 g_fin((F + 255) / 256, 2 * NP * 2, n_utts);
     dim3 g_eig((2 * F + 7) / 8, 1, n_utts);
+    // M-step from the initialisation, then per EM iteration ONE pass over the
+    // spectrogram (E-step fused with the next M-step's accumulation), and a closing
+    // E-step that writes the masks
     for (int it = 0; it <= num_iters; ++it) {
         const int em = it > 0;
-        hipLaunchKernelGGL(cgmm_accum_kernel<C>, g_tf, dim3(64), 0, s, d_tbl, em);
+        if (!em)
+            hipLaunchKernelGGL(cgmm_accum_kernel<C>, g_tf, dim3(64), 0, s, d_tbl, 0);
+        else
+            hipLaunchKernelGGL((cgmm_estep_kernel<C, true>), g_tf, dim3(64), 0, s, d_tbl, 0);
         hipLaunchKernelGGL(cgmm_finalize_kernel, g_fin, dim3(256), 0, s, d_tbl, em, C);
         hipLaunchKernelGGL(cgmm_eig_kernel<C>, g_eig, dim3(64), 0, s, d_tbl);
-        hipLaunchKernelGGL(cgmm_estep_kernel<C>, g_tf, dim3(64), 0, s, d_tbl,
-                           (int)(it == num_iters));
     }
+    hipLaunchKernelGGL((cgmm_estep_kernel<C, false>), g_tf, dim3(64), 0, s, d_tbl, 1);
     return hipGetLastError();
 }
 
