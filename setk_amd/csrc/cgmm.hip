@@ -271,10 +271,18 @@ __global__ __launch_bounds__(64) void cgmm_estep_kernel(const CgmmArgs* __restri
 #pragma unroll
     for (int e = 0; e < (ACCUM ? NP : 1); ++e) acc[e] = make_float2(0.f, 0.f);
     float sumg = 0.f;
+    // the next frame's bins are requested one iteration ahead
+    cf xn[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) xn[c] = a.spec[((size_t)c * T + min(t0, T - 1)) * F + fc];
     for (int t = t0; t < t1; ++t) {
         cf x[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) x[c] = a.spec[((size_t)c * T + t) * F + fc];
+        for (int c = 0; c < C; ++c) x[c] = xn[c];
+        if (t + 1 < t1) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) xn[c] = a.spec[((size_t)c * T + t + 1) * F + fc];
+        }
         float q = 0.f;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
