@@ -226,3 +226,48 @@ def test_batch_is_deterministic(ctx):
         assert st_a == [0, 0, 0] and st_b == [0, 0, 0]
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+def test_full_size_properties(ctx):
+    """BASELINE configs[2] utterance size (8 ch x 30 s), where the oracle is too slow
+    to run per test: size-independent properties of the fused path --
+    scale equivariance, channel-permutation invariance of PMWF with a fixed physical
+    reference microphone, independence of the batch an utterance travels in, and
+    the single-channel identity."""
+    from setk_amd import _ffi
+    N = 480000
+    mix, sp, nz = o.synth_utterance(5, 8, N, return_parts=True)
+    c2 = ctx
+    T = c2.num_frames(N)
+    rng = np.random.default_rng(3)
+    mask = rng.uniform(0.05, 0.95, size=(T, 257)).astype(np.float32)
+    opts = lambda: _ffi.BfOpts(flags=_ffi.FLAG_CLAMP_MASK, **KINDS["mvdr"])  # noqa: E731
+    (y,), st = run_batch(c2, opts(), [mix], [mask])
+    assert st == [0] and y.shape == (N,) and np.all(np.isfinite(y))
+    # output is renormalised to max |input|
+    assert abs(np.max(np.abs(y)) - np.max(np.abs(mix))) < 1e-4 * np.max(np.abs(mix))
+    # scale equivariance
+    (y2,), _ = run_batch(c2, opts(), [0.5 * mix], [mask])
+    assert rms(y2, 0.5 * y) / rms(y) < 1e-4
+    # channel permutation: PMWF referenced to the same physical microphone (MVDR's
+    # output is referenced to the gauge channel 0, so it is not permutation invariant)
+    perm = np.array([3, 0, 7, 1, 6, 2, 5, 4])
+    pm = lambda ref: _ffi.BfOpts(flags=_ffi.FLAG_CLAMP_MASK, kind=2, pmwf_beta=0.0,  # noqa: E731
+                                 pmwf_ref=ref)
+    (ya,), sa = run_batch(c2, pm(2), [mix], [mask])
+    (yb,), sb = run_batch(c2, pm(int(np.where(perm == 2)[0][0])),
+                          [np.ascontiguousarray(mix[perm])], [mask])
+    assert sa == [0] and sb == [0]
+    assert rms(yb, ya) / rms(ya) < 1e-4
+    # same utterance inside a ragged batch (different work split)
+    others = [o.synth_utterance(6, 8, 200000), o.synth_utterance(7, 8, 333333)]
+    masks = [rng.uniform(0.05, 0.95, size=(c2.num_frames(u.shape[1]), 257)).astype(np.float32)
+             for u in others]
+    ys, st = run_batch(c2, opts(), [others[0], mix, others[1]], [masks[0], mask, masks[1]])
+    assert st == [0, 0, 0]
+    assert rms(ys[1], y) / rms(y) < 1e-5
+    # one channel: the beamformer is the identity up to the renorm
+    (y1,), st = run_batch(c2, opts(), [mix[:1]], [mask])
+    assert st == [0]
+    x = mix[0, :y1.shape[0]]
+    assert rms(y1, x * (np.max(np.abs(mix[0])) / np.max(np.abs(x)))) / rms(x) < 1e-4
