@@ -236,6 +236,27 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts,
                        const float* const* mask_n, void* const* wave,
                        int* status, void* stream);
 
+/* The same call with taps on the intermediate results of the fused kernels
+ * (parity tests compare them with compute_covar / the weight classes directly;
+ * a caller may also keep the weights).  Every member may be NULL; device or
+ * host memory:
+ *   Rs, Rn   [n_utts][F][C][C] complex64  normalised covariances out of the fused
+ *            STFT+covariance kernel and its reduction (libs/beamformer.py:87-103)
+ *   weight   [n_utts][F][C]    complex64  beamformer weights (libs/beamformer.py
+ *            weight() of the selected class, after BAN when requested)
+ *   maxabs   [n_utts] float32  max |audio| (WaveReader.maxabs, the renorm target) */
+typedef struct setk_batch_taps {
+    float* Rs;
+    float* Rn;
+    float* weight;
+    float* maxabs;
+} setk_batch_taps;
+int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utts,
+                            int num_channels, const float* const* audio,
+                            const int* num_samples, const float* const* mask_s,
+                            const float* const* mask_n, void* const* wave,
+                            int* status, const setk_batch_taps* taps, void* stream);
+
 /* Stage timings (ms, hipEvent on `stream`) of the most recent
  * setk_enhance_batch when profiling was enabled with setk_set_profiling(h,1):
  * out[0] = the fused STFT+covariance kernel alone, out[1] = partial reduction +

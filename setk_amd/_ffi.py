@@ -29,6 +29,10 @@ class BfOpts(ctypes.Structure):
                 ("pmwf_ref", c_int), ("rank1", c_int)]
 
 
+class BatchTaps(ctypes.Structure):
+    _fields_ = [("Rs", c_void_p), ("Rn", c_void_p), ("weight", c_void_p), ("maxabs", c_void_p)]
+
+
 class SetkError(RuntimeError):
     pass
 
@@ -47,7 +51,8 @@ def exported_symbols():
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
         "setk_pcm16_to_float", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
-        "setk_cgmm_masks_batch", "setk_enhance_batch", "setk_apply_weights_batch",
+        "setk_cgmm_masks_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
+        "setk_apply_weights_batch",
         "setk_directional_feats", "setk_set_profiling",
         "setk_last_stage_ms"
     ]
@@ -97,6 +102,8 @@ def load_library():
         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int),
         c_void_p
     ]
+    lib.setk_enhance_batch_taps.argtypes = lib.setk_enhance_batch.argtypes[:-1] + [
+        POINTER(BatchTaps), c_void_p]
     lib.setk_directional_feats.argtypes = [H, fp, fp, POINTER(c_int), c_int, c_int, c_int, c_int,
                                            fp, c_void_p]
     lib.setk_apply_weights_batch.argtypes = [
@@ -279,7 +286,10 @@ class Context:
 
     # -- fused hot path ---------------------------------------------------------
     def enhance_batch(self, opts, num_channels, audio_ptrs, num_samples, mask_ptrs,
-                      itf_ptrs, wave_ptrs, want_status=True, stream=None):
+                      itf_ptrs, wave_ptrs, want_status=True, stream=None, taps=None):
+        """taps: dict with any of Rs, Rn ([n][F][C][C] complex64), weight ([n][F][C]
+        complex64), maxabs ([n] float32) -> numpy arrays / device tensors filled by
+        setk_enhance_batch_taps."""
         n = len(audio_ptrs)
         A = (c_void_p * n)(*audio_ptrs)
         M = (c_void_p * n)(*mask_ptrs)
@@ -287,10 +297,17 @@ class Context:
         I = (c_void_p * n)(*itf_ptrs) if itf_ptrs is not None else None
         NS = (c_int * n)(*[int(v) for v in num_samples])
         ST = (c_int * n)() if want_status else None
-        self.check(
-            self._lib.setk_enhance_batch(
-                self._h, ctypes.byref(opts), n, int(num_channels), A, NS, M, I, W, ST,
-                current_stream_ptr() if stream is None else stream))
+        st = current_stream_ptr() if stream is None else stream
+        if taps:
+            tp = BatchTaps(*[_ptr(taps.get(k)) for k in ("Rs", "Rn", "weight", "maxabs")])
+            self.check(
+                self._lib.setk_enhance_batch_taps(
+                    self._h, ctypes.byref(opts), n, int(num_channels), A, NS, M, I, W, ST,
+                    ctypes.byref(tp), st))
+        else:
+            self.check(
+                self._lib.setk_enhance_batch(
+                    self._h, ctypes.byref(opts), n, int(num_channels), A, NS, M, I, W, ST, st))
         return list(ST) if want_status else None
 
     def directional_feats(self, spec, sv, pairs, C, T, F, out, stream=None):

@@ -52,6 +52,9 @@ struct setk_context {
     std::vector<hipEvent_t> ev_pool;   // free events
     std::vector<hipEvent_t> ev_used;   // 5 per profiled call, in call order
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // stream of the most recent call (arena_reset)
+    hipStream_t last_stream = nullptr;
+    bool have_last_stream = false;
     // tunables
     int p1_items = 1024;
     int p2_items = 1024;
@@ -83,7 +86,14 @@ bool is_device_ptr(const void* p) {
     return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
 }
 
-void arena_reset(setk_handle_t h) {
+// Every entry point starts by recycling the per-handle arena (and may rewrite
+// the cached descriptor block).  Work of the previous call may still be in
+// flight on ITS stream: calls on the same stream are ordered behind it, a call
+// on a different stream first drains the previous one.
+void arena_reset(setk_handle_t h, hipStream_t s) {
+    if (h->have_last_stream && h->last_stream != s) (void)hipStreamSynchronize(h->last_stream);
+    h->last_stream = s;
+    h->have_last_stream = true;
     for (auto& b : h->blocks) b.off = 0;
 }
 
@@ -374,7 +384,7 @@ static int stft_generic(setk_handle_t h, const float* audio, int C, int N, float
     const int T = setk_stft_num_frames(h, N);
     if (T < 0) return T;
     const int F = h->n_fft / 2 + 1;
-    arena_reset(h);
+    arena_reset(h, s);
     const float* d_audio;
     int rc = stage_in(h, audio, (size_t)C * N, s, &d_audio);
     if (rc) return rc;
@@ -399,7 +409,7 @@ static int istft_generic(setk_handle_t h, const float* spec, int B, int T, int n
         const long padded = (long)nsamps + (h->center ? h->n_fft : 0);
         T_eff = (int)std::max<long>(1, std::min<long>(T, (padded + h->hop - 1) / h->hop));
     }
-    arena_reset(h);
+    arena_reset(h, s);
     const float* d_spec;
     int rc = stage_in(h, spec, (size_t)B * T * F * 2, s, &d_spec);
     if (rc) return rc;
@@ -408,9 +418,10 @@ static int istft_generic(setk_handle_t h, const float* spec, int B, int T, int n
     if (rc) return rc;
     std::vector<float> hn(B, -1.f);
     if (norm) {
-        if (is_device_ptr(norm))
-            HIP_TRY(h, hipMemcpy(hn.data(), norm, B * sizeof(float), hipMemcpyDeviceToHost));
-        else
+        if (is_device_ptr(norm)) {
+            HIP_TRY(h, hipMemcpyAsync(hn.data(), norm, B * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+        } else
             memcpy(hn.data(), norm, B * sizeof(float));
     }
     void* d_norm;
@@ -446,7 +457,7 @@ int setk_stft(setk_handle_t h, const float* audio, int num_channels, int num_sam
     if (T < 0) return T;
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    arena_reset(h);
+    arena_reset(h, s);
     const float* d_audio;
     rc = stage_in(h, audio, (size_t)num_channels * num_samples, s, &d_audio);
     if (rc) return rc;
@@ -499,7 +510,7 @@ int setk_istft(setk_handle_t h, const float* spec, int batch, int num_frames, in
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    arena_reset(h);
+    arena_reset(h, s);
     const int T = num_frames, F = kBins;
     const int L = setk_istft_num_samples(h, T, nsamps);
     int T_eff = T;
@@ -517,9 +528,11 @@ int setk_istft(setk_handle_t h, const float* spec, int batch, int num_frames, in
     if (L > 0) HIP_TRY(h, hipMemsetAsync(ob.dev, 0, (size_t)batch * L * sizeof(float), s));
     std::vector<float> hn(batch, -1.f);
     if (norm) {
-        if (is_device_ptr(norm))
-            HIP_TRY(h, hipMemcpy(hn.data(), norm, batch * sizeof(float), hipMemcpyDeviceToHost));
-        else
+        if (is_device_ptr(norm)) {
+            HIP_TRY(h, hipMemcpyAsync(hn.data(), norm, batch * sizeof(float), hipMemcpyDeviceToHost,
+                                      s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+        } else
             memcpy(hn.data(), norm, batch * sizeof(float));
     }
     void* d_norm;
@@ -581,7 +594,7 @@ int setk_covar(setk_handle_t h, const float* spec, const float* mask, int num_ch
         return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    arena_reset(h);
+    arena_reset(h, s);
     const int C = num_channels, T = num_frames, F = num_bins;
     const float *d_spec, *d_mask;
     int rc = stage_in(h, spec, (size_t)C * T * F * 2, s, &d_spec);
@@ -613,7 +626,7 @@ static int run_weights(setk_handle_t h, const setk_bf_opts& o, int kind, const f
     const int pitch = pitch_of(F);
     const bool mpdr = (kind == SETK_BF_MPDR || kind == SETK_BF_MPDR_WHITEN);
     const int planes = mpdr ? 6 * NP : (Rn ? 4 * NP : 2 * NP);
-    arena_reset(h);
+    arena_reset(h, s);
     const float *d_Rs, *d_Rn = nullptr, *d_Ry = nullptr;
     const size_t nmat = (size_t)F * C * C * 2;
     int rc = stage_in(h, Rs, nmat, s, &d_Rs);
@@ -722,7 +735,7 @@ int setk_ban(setk_handle_t h, const float* weight, const float* Rn, int num_bins
         return fail(h, SETK_ERR_INVALID, "bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    arena_reset(h);
+    arena_reset(h, s);
     const int F = num_bins, C = num_channels;
     const float *d_w, *d_Rn;
     int rc = stage_in(h, weight, (size_t)F * C * 2, s, &d_w);
@@ -745,7 +758,7 @@ int setk_pcm16_to_float(setk_handle_t h, const int16_t* pcm, int num_channels, i
         return fail(h, SETK_ERR_INVALID, "bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    arena_reset(h);
+    arena_reset(h, s);
     const size_t n16 = (size_t)num_channels * num_samples;
     const int16_t* d_pcm;
     int rc = stage_in(h, pcm, n16, s, &d_pcm);
@@ -777,7 +790,7 @@ int setk_rank1(setk_handle_t h, const float* Rs, const float* Rn, int num_bins,
     o.flags = SETK_FLAG_NO_GAUGE;
     int rc = run_weights(h, o, kKindPevd, Rs, Rn, nullptr, F, C, d_pv, status, nullptr, s);
     if (rc == SETK_OK) {
-        arena_reset(h);
+        arena_reset(h, s);
         const float *d_Rs, *d_Rn = nullptr;
         rc = stage_in(h, Rs, (size_t)F * C * C * 2, s, &d_Rs);
         if (rc == SETK_OK && Rn) rc = stage_in(h, Rn, (size_t)F * C * C * 2, s, &d_Rn);
@@ -800,7 +813,7 @@ int setk_beamform(setk_handle_t h, const float* weight, const float* spec, int n
         return fail(h, SETK_ERR_INVALID, "bad args");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    arena_reset(h);
+    arena_reset(h, s);
     const int C = num_channels, T = num_frames, F = num_bins;
     const float *d_w, *d_spec;
     int rc = stage_in(h, weight, (size_t)F * C * 2, s, &d_w);
@@ -827,7 +840,7 @@ int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
         return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    arena_reset(h);
+    arena_reset(h, s);
     const int C = num_channels, F = num_bins;
     const size_t ab = cgmm_args_bytes();
     std::vector<char> tbl((size_t)n_utts * ab);
@@ -863,7 +876,7 @@ int setk_directional_feats(setk_handle_t h, const float* spec, const float* stee
             return fail(h, SETK_ERR_INVALID, "microphone pair out of range");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    arena_reset(h);
+    arena_reset(h, s);
     const int C = num_channels, T = num_frames, F = num_bins;
     const float *d_spec, *d_sv;
     int rc = stage_in(h, spec, (size_t)C * T * F * 2, s, &d_spec);
@@ -894,7 +907,7 @@ int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int nu
         return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    arena_reset(h);
+    arena_reset(h, s);
     const int C = num_channels, T = num_frames, F = num_bins;
     const float *d_spec, *d_init = nullptr;
     int rc = stage_in(h, spec, (size_t)C * T * F * 2, s, &d_spec);
@@ -946,7 +959,7 @@ int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
                 return fail(h, SETK_ERR_INVALID, "weight index out of range");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    arena_reset(h);
+    arena_reset(h, s);
     const bool pcm16 = (flags & SETK_FLAG_OUT_PCM16) != 0;
     const StftGeom g = geom_of(h);
 
@@ -1042,6 +1055,15 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
                        const float* const* audio, const int* num_samples,
                        const float* const* mask_s, const float* const* mask_n,
                        void* const* wave, int* status, void* stream) {
+    return setk_enhance_batch_taps(h, opts, n_utts, num_channels, audio, num_samples, mask_s,
+                                   mask_n, wave, status, nullptr, stream);
+}
+
+int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utts,
+                            int num_channels, const float* const* audio, const int* num_samples,
+                            const float* const* mask_s, const float* const* mask_n,
+                            void* const* wave, int* status, const setk_batch_taps* taps,
+                            void* stream) {
     if (!h || !opts || n_utts <= 0 || !audio || !num_samples || !mask_s || !wave)
         return fail(h, SETK_ERR_INVALID, "bad args");
     int rc = require_plan512(h);
@@ -1062,7 +1084,7 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
         return fail(h, SETK_ERR_INVALID, "Reference channel ID exceeds total channels");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    arena_reset(h);
+    arena_reset(h, s);
     const bool pcm16 = (opts->flags & SETK_FLAG_OUT_PCM16) != 0;
     const int NP = npairs(C);
     const StftGeom g = geom_of(h);
@@ -1198,6 +1220,23 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
     fa.num_channels = C;
     fa.with_ry = mpdr ? 1 : 0;
     HIP_TRY(h, launch_finalize(fa, n_utts, s));
+    OutBuf tap_rs, tap_rn, tap_w;
+    if (taps && taps->Rs) {
+        rc = stage_out(h, taps->Rs, (size_t)n_utts * kBins * C * C * sizeof(float2), &tap_rs);
+        if (rc) return rc;
+        HIP_TRY(h, launch_unpack_covar(d_covar, n_utts, planes_out, 0, kBins, C,
+                                       static_cast<float*>(tap_rs.dev), s));
+        rc = copy_back(h, tap_rs, s);
+        if (rc) return rc;
+    }
+    if (taps && taps->Rn) {
+        rc = stage_out(h, taps->Rn, (size_t)n_utts * kBins * C * C * sizeof(float2), &tap_rn);
+        if (rc) return rc;
+        HIP_TRY(h, launch_unpack_covar(d_covar, n_utts, planes_out, 2 * NP, kBins, C,
+                                       static_cast<float*>(tap_rn.dev), s));
+        rc = copy_back(h, tap_rn, s);
+        if (rc) return rc;
+    }
 
     // ---- stage 2: weights ----
     SolveArgs sa;
@@ -1223,6 +1262,14 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
     HIP_TRY(h, launch_solve(sa, s));
     if (kind == SETK_BF_PMWF && opts->pmwf_ref < 0) HIP_TRY(h, launch_pmwf_select(sa, nullptr, s));
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[2], s));
+    if (taps && taps->weight) {
+        rc = stage_out(h, taps->weight, (size_t)n_utts * kBins * C * sizeof(float2), &tap_w);
+        if (rc) return rc;
+        HIP_TRY(h, launch_unpack_weight_batch(d_w, n_utts, kBins, C,
+                                              static_cast<float*>(tap_w.dev), s));
+        rc = copy_back(h, tap_w, s);
+        if (rc) return rc;
+    }
 
     // ---- stage 3: beamform + iSTFT ----
     Pass2Args p2;
@@ -1250,10 +1297,20 @@ int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, in
     sc.pcm16 = pcm16 ? 1 : 0;
     HIP_TRY(h, launch_scale(sc, n_utts, max_len, s));
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[4], s));
-    if (status) {
-        HIP_TRY(h, hipMemcpyAsync(status, d_status, (size_t)n_utts * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipStreamSynchronize(s));
+    if (taps && taps->maxabs) {
+        // max |audio| per utterance (WaveReader.maxabs): the float bit patterns
+        if (is_device_ptr(taps->maxabs))
+            HIP_TRY(h, hipMemcpyAsync(taps->maxabs, d_norm, (size_t)n_utts * 4,
+                                      hipMemcpyDeviceToDevice, s));
+        else
+            HIP_TRY(h, hipMemcpyAsync(taps->maxabs, d_norm, (size_t)n_utts * 4,
+                                      hipMemcpyDeviceToHost, s));
     }
+    if (status)
+        HIP_TRY(h, hipMemcpyAsync(status, d_status, (size_t)n_utts * 4, hipMemcpyDeviceToHost, s));
+    if (status || tap_rs.host || tap_rn.host || tap_w.host ||
+        (taps && taps->maxabs && !is_device_ptr(taps->maxabs)))
+        HIP_TRY(h, hipStreamSynchronize(s));
     return SETK_OK;
 }
 

@@ -129,6 +129,10 @@ hipError_t launch_covar_spec_finalize(int C, const float* partials, int nparts, 
 hipError_t launch_pack_covar(const float* fcc, int F, int C, float* planes, int plane0,
                              hipStream_t s);
 hipError_t launch_unpack_weight(const float* wplanes, int F, int C, float* w_fc, hipStream_t s);
+hipError_t launch_unpack_covar(const float* planes, int n_utts, int n_planes, int plane0, int F,
+                               int C, float* out, hipStream_t s);
+hipError_t launch_unpack_weight_batch(const float* wplanes, int n_utts, int F, int C, float* w,
+                                      hipStream_t s);
 hipError_t launch_stft_generic(const float* audio, int C, int n_samp, int T, int n_fft, int hop,
                                int pad, const float* window, const float* tw, float* spec,
                                hipStream_t s);

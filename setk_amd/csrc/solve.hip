@@ -651,6 +651,51 @@ hipError_t launch_pack_covar(const float* fcc, int F, int C, float* planes, int 
     return hipGetLastError();
 }
 
+// packed planes of a batch -> covar[u][F][C][C] complex64 (Hermitian completion),
+// pair set starting at plane0 of each utterance's `planes` planes
+__global__ void unpack_covar_kernel(const float* planes, int n_planes, int plane0, int F, int C,
+                                    int pitch, float2* out) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int u = blockIdx.y;
+    if (f >= F) return;
+    const int NP = npairs(C);
+    const float* base = planes + ((size_t)u * n_planes + plane0) * pitch + f;
+    float2* o = out + ((size_t)u * F + f) * C * C;
+    for (int i = 0; i < C; ++i)
+        for (int j = i; j < C; ++j) {
+            const int e = pair_index(i, j, C);
+            const float re = base[(size_t)e * pitch], im = base[(size_t)(NP + e) * pitch];
+            o[i * C + j] = make_float2(re, i == j ? 0.f : im);
+            if (i != j) o[j * C + i] = make_float2(re, -im);
+        }
+}
+
+hipError_t launch_unpack_covar(const float* planes, int n_utts, int n_planes, int plane0, int F,
+                               int C, float* out, hipStream_t s) {
+    const int pitch = (F == kBins) ? kBinsPad : ((F + 7) / 8) * 8;
+    hipLaunchKernelGGL(unpack_covar_kernel, dim3((F + 255) / 256, n_utts), dim3(256), 0, s, planes,
+                       n_planes, plane0, F, C, pitch, reinterpret_cast<float2*>(out));
+    return hipGetLastError();
+}
+
+// weight planes of a batch [u][C][pitch] float2 -> w[u][F][C] complex64
+__global__ void unpack_weight_batch_kernel(const float2* wp, int F, int C, int pitch, float2* w) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int u = blockIdx.y;
+    if (f >= F) return;
+    for (int c = 0; c < C; ++c)
+        w[((size_t)u * F + f) * C + c] = wp[((size_t)u * C + c) * pitch + f];
+}
+
+hipError_t launch_unpack_weight_batch(const float* wplanes, int n_utts, int F, int C, float* w,
+                                      hipStream_t s) {
+    const int pitch = (F == kBins) ? kBinsPad : ((F + 7) / 8) * 8;
+    hipLaunchKernelGGL(unpack_weight_batch_kernel, dim3((F + 255) / 256, n_utts), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(wplanes), F, C, pitch,
+                       reinterpret_cast<float2*>(w));
+    return hipGetLastError();
+}
+
 // weight planes [C][pitch] float2 -> w[F][C] complex64
 __global__ void unpack_weight_kernel(const float2* wp, int F, int C, int pitch, float2* w_fc) {
     const int f = blockIdx.x * 256 + threadIdx.x;

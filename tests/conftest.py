@@ -35,5 +35,13 @@ def rms(a, b=None):
     return float(np.sqrt(np.mean(np.abs(d)**2)))
 
 
+def pcm16_rel_rms(pcm, ref_float):
+    """int16 samples (a wav the product wrote) against a float reference quantised
+    the way libsndfile does (lrint(x * 32767)): both sides carry the same PCM16
+    floor, so north_star's 1e-3 applies to what is left."""
+    q = np.rint(np.asarray(ref_float, dtype=np.float64) * 32767.0)
+    return rms(np.asarray(pcm, dtype=np.float64), q) / max(rms(q), 1e-30)
+
+
 def rel_rms(a, ref):
     return rms(a, ref) / max(rms(ref), 1e-30)

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, load_golden, rms, rel_rms
+from conftest import ROOT, load_golden, rms, rel_rms, pcm16_rel_rms
 from oracle import np_oracle as o
 from oracle import make_golden as mg
 
@@ -227,8 +227,7 @@ def test_cli_options_vad_postmask_itf_online(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         sr, y = scipy.io.wavfile.read(os.path.join(dst, "u0.wav"))
         ref = o.enhance_utterance(samps, mask, kind="mvdr", gauge=True, **okw)
-        a = y.astype(np.float64) / 32767
-        assert rms(a, ref) / rms(ref) < 2e-3, name
+        assert pcm16_rel_rms(y, ref) < 1e-3, (name, pcm16_rel_rms(y, ref))
     # block-online mode runs (the reference's raises TypeError) and is sane
     dst = os.path.join(td, "online")
     r = subprocess.run(base + ["--online.chunk-size", "16", os.path.join(td, "wav.scp"),

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, load_golden, rms
+from conftest import ROOT, load_golden, rms, pcm16_rel_rms
 from oracle import np_oracle as o
 
 pytestmark = pytest.mark.gpu
@@ -36,7 +36,7 @@ def test_doc_pipeline_mask_and_pmwf_golden():
     (wav, st), = BatchEnhancer(beamformer="pmwf-0", pcm16=True).enhance([(samps, mask, None)])
     assert st == 0
     stored = doc["pmwf_0"].astype(np.float64)
-    assert rms(wav.astype(np.float64), stored) / rms(stored) < 2e-3
+    assert rms(wav.astype(np.float64), stored) / rms(stored) < 1e-3
 
 
 @pytest.mark.parametrize("C,N,iters", [(6, 20000, 20), (4, 9000, 5), (8, 12000, 10), (2, 6000, 3)])
@@ -94,7 +94,7 @@ def test_cgmm_cli_then_mvdr_cli(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     sr, y = scipy.io.wavfile.read(os.path.join(td, "enh", "u.wav"))
     ref = o.enhance_utterance(samps, mask, kind="mvdr", gauge=True)
-    assert rms(y.astype(np.float64) / 32767, ref) / rms(ref) < 2e-3
+    assert pcm16_rel_rms(y, ref) < 1e-3, pcm16_rel_rms(y, ref)
 
 
 def test_cgmm_batched_ragged_equals_single():

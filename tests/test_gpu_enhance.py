@@ -186,7 +186,8 @@ def test_enhance_edge_geometries(N, hop, center):
         assert wav.shape == ref.shape
         if T >= 3:
             assert st == [0]
-            assert rms(wav, ref) / max(rms(ref), 1e-12) < 2e-3, (N, hop, center)
+            err = rms(wav, ref) / max(rms(ref), 1e-12)
+            assert err < 1e-3, (N, hop, center, err)
         else:
             # 1-2 frames: rank-deficient covariances (and, without centring, samples
             # divided by window^2 ~ 1e-9): nothing meaningful to compare, but the
@@ -229,8 +230,9 @@ def test_batch_is_deterministic(ctx):
 
 
 def test_full_size_properties(ctx):
-    """BASELINE configs[2] utterance size (8 ch x 30 s), where the oracle is too slow
-    to run per test: size-independent properties of the fused path --
+    """BASELINE configs[2] utterance size (8 ch x 30 s): size-independent properties
+    of the fused path on top of the direct oracle comparison at this size
+    (tests/test_gpu_baseline_sizes.py) --
     scale equivariance, channel-permutation invariance of PMWF with a fixed physical
     reference microphone, independence of the batch an utterance travels in, and
     the single-channel identity."""
