@@ -348,14 +348,19 @@ _default_ctx = {}
 def default_context(device=None):
     """Process-wide context for the python API mirror (one per device)."""
     if device is None:
-        device = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get(
-            "SETK_DEVICE") is None else int(os.environ["SETK_DEVICE"])
-        try:
-            import torch
-            if torch.cuda.is_available():
-                device = torch.cuda.current_device()
-        except Exception:
-            pass
+        # SETK_DEVICE, then LOCAL_RANK (torchrun), then torch's current device
+        if os.environ.get("SETK_DEVICE") is not None:
+            device = int(os.environ["SETK_DEVICE"])
+        elif os.environ.get("LOCAL_RANK") is not None:
+            device = int(os.environ["LOCAL_RANK"])
+        else:
+            device = 0
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    device = torch.cuda.current_device()
+            except Exception:
+                pass
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
     return _default_ctx[device]

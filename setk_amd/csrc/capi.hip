@@ -666,11 +666,10 @@ static int run_weights(setk_handle_t h, const setk_bf_opts& o, int kind, const f
     a.pmwf_beta = o.pmwf_beta;
     int* d_ref = nullptr;
     if (kind == SETK_BF_PMWF && o.pmwf_ref < 0) {
-        a.snr_acc = static_cast<double*>(arena_alloc(h, (size_t)C * 2 * sizeof(double)));
+        a.snr_acc = static_cast<double*>(arena_alloc(h, (size_t)F * C * 2 * sizeof(double)));
         a.wmat = static_cast<float*>(arena_alloc(h, (size_t)F * C * C * 8));
         d_ref = static_cast<int*>(arena_alloc(h, sizeof(int)));
         if (!a.snr_acc || !a.wmat || !d_ref) return fail(h, SETK_ERR_NOMEM, "arena");
-        HIP_TRY(h, hipMemsetAsync(a.snr_acc, 0, (size_t)C * 2 * sizeof(double), s));
     }
     HIP_TRY(h, launch_solve(a, s));
     if (kind == SETK_BF_PMWF && o.pmwf_ref < 0) HIP_TRY(h, launch_pmwf_select(a, d_ref, s));
@@ -1254,10 +1253,10 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     sa.pmwf_ref = opts->pmwf_ref;
     sa.pmwf_beta = opts->pmwf_beta;
     if (kind == SETK_BF_PMWF && opts->pmwf_ref < 0) {
-        sa.snr_acc = static_cast<double*>(arena_alloc(h, (size_t)n_utts * C * 2 * sizeof(double)));
+        sa.snr_acc =
+            static_cast<double*>(arena_alloc(h, (size_t)n_utts * kBins * C * 2 * sizeof(double)));
         sa.wmat = static_cast<float*>(arena_alloc(h, (size_t)n_utts * kBins * C * C * 8));
         if (!sa.snr_acc || !sa.wmat) return fail(h, SETK_ERR_NOMEM, "arena");
-        HIP_TRY(h, hipMemsetAsync(sa.snr_acc, 0, (size_t)n_utts * C * 2 * sizeof(double), s));
     }
     HIP_TRY(h, launch_solve(sa, s));
     if (kind == SETK_BF_PMWF && opts->pmwf_ref < 0) HIP_TRY(h, launch_pmwf_select(sa, nullptr, s));

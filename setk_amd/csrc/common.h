@@ -10,6 +10,7 @@ constexpr int kNfft = 512;        // fused kernels are specialised for n_fft = 5
 constexpr int kBins = 257;        // n_fft / 2 + 1
 constexpr int kBinsPad = 264;     // row pitch of per-bin planes (multiple of 8)
 constexpr int kMaxChannels = 8;   // register-resident covariance accumulators
+constexpr int kMaxChannels16 = 16; // modular (unfused) operators: covariance, solve, beamform
 constexpr int kSuperTile = 16;    // frames per inverse-transform batch (pass 2)
 constexpr int kMaxKeep = 7;       // ceil(512 / hop) - 1 for hop >= 64
 
@@ -79,7 +80,7 @@ struct SolveArgs {
     float* weight;        // [n_utts][C][kBinsPad] float2
     int* status;          // [n_utts] (atomicMax) or per-bin when per_bin != 0
     int* bin_status;      // [n_problems] or null
-    double* snr_acc;      // PMWF ref<0: [n_utts][C][2] (ps, pn)
+    double* snr_acc;      // PMWF ref<0: [n_problems][C][2] per-bin (ps, pn)
     float* wmat;          // PMWF ref<0: [n_problems][C][C] float2 (column major)
     int n_utts;
     int num_bins;

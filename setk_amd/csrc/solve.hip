@@ -469,8 +469,10 @@ __global__ __launch_bounds__(64, SETK_SOLVE_WAVES) void solve_kernel(SolveArgs a
                 pn += zcmul(x[i], s2).x;
             }
             if (live && j < C) {
-                atomicAdd(&a.snr_acc[((size_t)u * C + j) * 2 + 0], ps);
-                atomicAdd(&a.snr_acc[((size_t)u * C + j) * 2 + 1], pn);
+                // per-bin terms; pmwf_select_kernel sums them in bin order (an atomic
+                // accumulation would make the argmax depend on the arrival order)
+                a.snr_acc[((size_t)prob * C + j) * 2 + 0] = ps;
+                a.snr_acc[((size_t)prob * C + j) * 2 + 1] = pn;
                 float2* wm = reinterpret_cast<float2*>(a.wmat) + ((size_t)prob * C + j) * C;
 #pragma unroll
                 for (int i = 0; i < C; ++i) wm[i] = make_float2((float)x[i].x, (float)x[i].y);
@@ -571,11 +573,23 @@ __global__ __launch_bounds__(256) void pmwf_select_kernel(SolveArgs a, int pitch
     const int f = blockIdx.x * 256 + threadIdx.x;
     const int C = a.num_channels, F = a.num_bins;
     const int NP = npairs(C);
+    // sum_f of the per-bin (ps, pn) terms in a fixed order: thread c sums channel c
+    __shared__ double s_snr[kMaxChannels16][2];
+    if (threadIdx.x < C) {
+        double ps = 0.0, pn = 0.0;
+        for (int b = 0; b < F; ++b) {
+            ps += a.snr_acc[(((size_t)u * F + b) * C + threadIdx.x) * 2 + 0];
+            pn += a.snr_acc[(((size_t)u * F + b) * C + threadIdx.x) * 2 + 1];
+        }
+        s_snr[threadIdx.x][0] = ps;
+        s_snr[threadIdx.x][1] = pn;
+    }
+    __syncthreads();
     int ref = 0;
     double best = -1e300;
     for (int c = 0; c < C; ++c) {
-        const double ps = a.snr_acc[((size_t)u * C + c) * 2 + 0];
-        const double pn = a.snr_acc[((size_t)u * C + c) * 2 + 1];
+        const double ps = s_snr[c][0];
+        const double pn = s_snr[c][1];
         const double r = ps / fmax(kEpsF32, pn);
         if (r > best) {
             best = r;

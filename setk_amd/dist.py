@@ -4,7 +4,8 @@ Utterance sharding over the GPUs of one node.
 The reference parallelises this path with ``split_scp.pl`` + ``run.pl JOB=1:nj``
 (scripts/run_adapt_beamformer.sh:69-92): contiguous scp shards, one process
 each, no communication.  Here: one process per GPU (torchrun), utterances are
-independent units dealt to ranks by duration (longest first, round robin) and
+independent units dealt to ranks by duration (longest first, each to the least
+loaded rank) and
 RCCL (torch.distributed backend "nccl") carries only the start/finish barrier
 and the three counters of the final "Processed N utterances" line.  There is no
 data-path collective because the path has no exchange step.
@@ -20,6 +21,7 @@ class Shard:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self._dist = None
+        self.assigned_weight = 0.0
         if self.world > 1:
             import torch
             import torch.distributed as dist
@@ -42,9 +44,25 @@ class Shard:
 
     def assign(self, keys, weights=None):
         """Keys owned by this rank.  With weights (e.g. durations) the keys are
-        dealt longest-first round robin, which balances the sum of weights;
-        without, plain round robin in table order."""
+        dealt longest first, each to the least loaded rank, which balances the sum
+        of weights; without, plain round robin in table order."""
         return assign_keys(keys, self.rank, self.world, weights)
+
+    def assign_by_duration(self, wav_reader, keys=None):
+        """Keys of this rank, dealt longest-first / least-loaded on the sample counts
+        in the wave headers (utterances whose length cannot be read from a header --
+        pipes, per-channel globs -- count as the mean of the others)."""
+        keys = list(wav_reader.index_keys if keys is None else keys)
+        if self.world <= 1:
+            return keys
+        lens = [wav_reader.peek_nsamps(k) for k in keys]
+        known = [n for n in lens if n]
+        mean = (sum(known) / len(known)) if known else 1.0
+        weights = [n if n else mean for n in lens]
+        mine = assign_keys(keys, self.rank, self.world, weights)
+        wsum = dict(zip(keys, weights))
+        self.assigned_weight = sum(wsum[k] for k in mine)
+        return mine
 
     def barrier(self):
         if self._dist is not None:
@@ -72,6 +90,14 @@ def assign_keys(keys, rank, world, weights=None):
         return keys
     if weights is None:
         return keys[rank::world]
+    # longest first, each to the least loaded rank so far (LPT; ties -> lowest
+    # rank): every rank evaluates the same deterministic deal
     order = sorted(range(len(keys)), key=lambda i: (-float(weights[i]), i))
-    mine = sorted(order[rank::world])  # keep table order inside a rank
+    load = [0.0] * world
+    owner = {}
+    for i in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[i] = r
+        load[r] += float(weights[i])
+    mine = sorted(i for i, r in owner.items() if r == rank)  # table order inside a rank
     return [keys[i] for i in mine]

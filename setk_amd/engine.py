@@ -207,6 +207,12 @@ class BatchEnhancer(object):
     def _run(self, utts, batch, C, has_itf, results):
         if self.stft["n_fft"] != 512:
             return self._run_unfused(utts, batch, C, has_itf, results)
+        kind = self.opts_kw["kind"]
+        if has_itf and kind == _ffi.BF_MPDR_WHITEN:
+            # the fused kernel forms Ry from mask_s + (1 - mask_s); with a separate
+            # interferer mask Rn and Ry are independent (libs/beamformer.py:573-590)
+            return self._run_unfused(utts, batch, C, has_itf, results)
+        drop_itf = has_itf and kind == _ffi.BF_MPDR  # plain MPDR never reads mask_n
         torch, ctx, dev = self.torch, self.ctx, self.dev
         audio, masks, itfs, waves, ns = [], [], [], [], []
         flags = self.base_flags | (0 if has_itf else _ffi.FLAG_CLAMP_MASK)
@@ -240,7 +246,7 @@ class BatchEnhancer(object):
                     itf = np.where(vad, 1.0e-4, itf)
             audio.append(a)
             masks.append(torch.from_numpy(np.ascontiguousarray(mask, dtype=np.float32)).to(dev))
-            if has_itf:
+            if has_itf and not drop_itf:
                 itfs.append(torch.from_numpy(np.ascontiguousarray(itf, dtype=np.float32)).to(dev))
             L = ctx.istft_num_samples(T)
             waves.append(torch.empty(L, dtype=torch.int16 if self.pcm16 else torch.float32,
@@ -249,7 +255,7 @@ class BatchEnhancer(object):
         opts = _ffi.BfOpts(flags=flags, **self.opts_kw)
         status = ctx.enhance_batch(opts, C, [t.data_ptr() for t in audio], ns,
                                    [t.data_ptr() for t in masks],
-                                   [t.data_ptr() for t in itfs] if has_itf else None,
+                                   [t.data_ptr() for t in itfs] if itfs else None,
                                    [t.data_ptr() for t in waves], want_status=True)
         for j, i in enumerate(batch):
             results[i] = (waves[j].cpu().numpy() if status[j] == 0 else None, status[j])

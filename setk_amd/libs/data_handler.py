@@ -70,42 +70,53 @@ def _pipe_open(command, mode, background=True):
     return proc.stdout
 
 
-def _fopen(fname, mode):
-    """open() extended with '-' (stdin/stdout) and 'cmd |' (pipe)."""
-    if mode not in ("w", "r", "wb", "rb"):
-        raise ValueError(f"Unknown open mode: {mode}")
-    if not fname:
-        return None
-    fname = fname.strip()
-    if fname == "-":
-        if mode in ("w", "wb"):
-            return sys.stdout.buffer if mode == "wb" else sys.stdout
-        return sys.stdin.buffer if mode == "rb" else sys.stdin
-    if fname[-1] == "|":
-        pin = _pipe_open(fname[:-1], mode, background=(mode == "rb"))
-        return pin if mode == "rb" else TextIOWrapper(pin)
-    if mode in ("r", "rb") and not os.path.exists(fname):
-        raise FileNotFoundError(f'Could not find common file: "{fname}"')
-    if mode in ("r", "w"):
-        return codecs.open(fname, mode, encoding="utf-8")
-    return open(fname, mode)
-
-
-def _fclose(fname, fd):
-    if fname != "-" and fd and fname[-1] != "|":
-        fd.close()
+_MODES = ("r", "w", "rb", "wb")
 
 
 class ext_open(object):
-    def __init__(self, fname, mode):
-        self.fname, self.mode = fname, mode
+    """``with ext_open(spec, mode) as fd``: `spec` is a path, ``-`` (the process's
+    stdin/stdout) or ``command |`` (read side of a shell pipe).  Ordinary files
+    are closed on exit, the standard streams and pipes are left alone
+    (reference behaviour: data_handler.py:76-138)."""
 
-    def __enter__(self):
-        self.fd = _fopen(self.fname, self.mode)
+    def __init__(self, fname, mode):
+        if mode not in _MODES:
+            raise ValueError(f"Unknown open mode: {mode}")
+        self.spec = fname.strip() if fname else fname
+        self.mode = mode
+        self.fd = None
+        self._owned = False
+
+    def _open(self):
+        spec, mode = self.spec, self.mode
+        binary, writing = mode.endswith("b"), mode.startswith("w")
+        if not spec:
+            return None
+        if spec == "-":
+            std = sys.stdout if writing else sys.stdin
+            return std.buffer if binary else std
+        if spec.endswith("|"):
+            pipe = _pipe_open(spec[:-1], mode, background=binary)
+            return pipe if binary else TextIOWrapper(pipe)
+        if not writing and not os.path.exists(spec):
+            raise FileNotFoundError(f'Could not find common file: "{spec}"')
+        self._owned = True
+        return open(spec, mode) if binary else codecs.open(spec, mode, encoding="utf-8")
+
+    def open(self):
+        self.fd = self._open()
         return self.fd
 
-    def __exit__(self, *args):
-        _fclose(self.fname, self.fd)
+    def close(self):
+        if self._owned and self.fd is not None:
+            self.fd.close()
+        self.fd, self._owned = None, False
+
+    def __enter__(self):
+        return self.open()
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def parse_scps(scp_path, value_processor=lambda x: x, num_tokens=2, restrict=True):
@@ -155,7 +166,7 @@ class Reader(object):
         if type(index) == int:
             n = len(self.index_keys)
             if index >= n or index < 0:
-                raise KeyError(f"Interger index out of range, {index:d} vs {n:d}")
+                raise KeyError(f"position {index:d} outside the table of {n:d} entries")
             index = self.index_keys[index]
         if index not in self.index_dict:
             raise KeyError(f"Missing utterance {index}!")
@@ -174,30 +185,50 @@ class ScpReader(Reader):
 
 
 class Writer(object):
+    """Sink of (key, ndarray) pairs: either one archive stream (path, ``-`` or
+    nothing) or a directory that receives one file per key; optionally a Kaldi
+    script file with one ``key<TAB>location`` line per object
+    (reference: data_handler.py:275-323)."""
+
     def __init__(self, obj_path_or_dir, scp_path=None, is_dir=False):
-        self.scp_path = scp_path
+        self.is_dir = bool(is_dir)
         if obj_path_or_dir == "-" and scp_path:
-            warnings.warn("Ignore script output discriptor cause dump archives to stdout")
-            self.scp_path = None
-        self.dump_out_dir = is_dir
-        if is_dir:
-            self.path_or_dir = Path(obj_path_or_dir).absolute()
-            self.path_or_dir.mkdir(exist_ok=True, parents=True)
+            warnings.warn("archives go to stdout: the script file would hold no usable offsets, "
+                          "not writing it")
+            scp_path = None
+        if self.is_dir:
+            self.target = Path(obj_path_or_dir).absolute()
+            self.target.mkdir(parents=True, exist_ok=True)
         else:
-            self.path_or_dir = os.path.abspath(obj_path_or_dir)
+            self.target = obj_path_or_dir if obj_path_or_dir == "-" else os.path.abspath(
+                obj_path_or_dir)
+        self._ark = None if self.is_dir else ext_open(self.target, "wb")
+        self._scp = ext_open(scp_path, "w")
+        self.ark_fd = None
+        self.scp_fd = None
 
     def __enter__(self):
-        if not self.dump_out_dir:
-            self.ark_file = _fopen(self.path_or_dir, "wb")
-        self.scp_file = _fopen(self.scp_path, "w")
+        if self._ark is not None:
+            self.ark_fd = self._ark.open()
+        self.scp_fd = self._scp.open()
         return self
 
-    def __exit__(self, *args):
-        if not self.dump_out_dir:
-            _fclose(self.path_or_dir, self.ark_file)
-        _fclose(self.scp_path, self.scp_file)
+    def __exit__(self, *exc):
+        if self._ark is not None:
+            self._ark.close()
+        self._scp.close()
+        self.ark_fd = self.scp_fd = None
 
-    def check_args(self, data):
+    def record(self, key, location):
+        """One line of the output script file (if any)."""
+        if self.scp_fd is not None:
+            self.scp_fd.write(f"{key}\t{location}\n")
+
+    def file_for(self, key, suffix):
+        return self.target / f"{key}{suffix}"
+
+    @staticmethod
+    def check_args(data):
         if not isinstance(data, np.ndarray):
             raise RuntimeError("Instance of Writer accepts np.ndarray object, " +
                                f"but got {type(data)}")
@@ -297,6 +328,33 @@ class WaveReader(ScpReader):
     def _load(self, key):
         return self.read(key)
 
+    def peek_nsamps(self, key):
+        """Samples per channel from the wave header alone (no decode), or None when
+        the entry is a pipe / a glob of several files.  Feeds the duration-balanced
+        sharding (the reference balances with split_scp.pl on utterance counts)."""
+        fname = self.index_dict[key].rstrip()
+        if fname[-1] == "|":
+            return None
+        wav_list = glob.glob(fname)
+        if ":" in fname and not wav_list:
+            wav_list = [fname]
+        if len(wav_list) != 1:
+            return None
+        addr = wav_list[0]
+        try:
+            if ":" in addr and not os.path.exists(addr):
+                path, offset = addr.rsplit(":", 1)
+                with open(path, "rb") as fd:
+                    fd.seek(int(offset))
+                    info = wavio.read_header(fd)
+            else:
+                with open(addr, "rb") as fd:
+                    info = wavio.read_header(fd)
+        except (OSError, ValueError, wavio.WaveFormatError):
+            return None
+        frame = info["channels"] * (info["bits"] // 8)
+        return info["data_bytes"] // frame if frame else None
+
     def maxabs(self, key):
         return np.max(np.abs(self.read(key)))
 
@@ -342,32 +400,41 @@ class SpectrogramReader(WaveReader):
         return spec if kw["transpose"] else np.ascontiguousarray(np.transpose(spec, (0, 2, 1)))
 
 
+def _split_ark_address(addr):
+    """'path/to.ark:1234' -> ('path/to.ark', 1234) (the path may contain ':')."""
+    path, sep, offset = addr.rpartition(":")
+    if not sep:
+        raise ValueError("Unsupported scripts address format")
+    return path, int(offset)
+
+
 class ScriptReader(ScpReader):
-    """Kaldi scp of 'ark_path:offset' values -> float matrix/vector."""
+    """Kaldi scp of 'ark_path:offset' values -> float matrix/vector.  Archives
+    stay open for the life of the reader (reference: data_handler.py:506-535)."""
 
     def __init__(self, ark_scp):
-        def addr_processor(addr):
-            tok = addr.split(":")
-            if len(tok) == 1:
-                raise ValueError("Unsupported scripts address format")
-            return (":".join(tok[0:-1]), int(tok[-1]))
+        super().__init__(ark_scp, value_processor=_split_ark_address)
+        self._arks = {}
 
-        super().__init__(ark_scp, value_processor=addr_processor)
-        self.fmgr = dict()
-
-    def _open(self, obj, addr):
-        if obj not in self.fmgr:
-            self.fmgr[obj] = open(obj, "rb")
-        arkf = self.fmgr[obj]
-        arkf.seek(addr)
-        return arkf
+    def _seek(self, path, offset):
+        fd = self._arks.get(path)
+        if fd is None:
+            fd = self._arks[path] = open(path, "rb")
+        fd.seek(offset)
+        return fd
 
     def _load(self, key):
-        path, addr = self.index_dict[key]
-        return kaldi_io.read_float_mat_vec(self._open(path, addr), direct_access=True)
+        path, offset = self.index_dict[key]
+        return kaldi_io.read_float_mat_vec(self._seek(path, offset), direct_access=True)
+
+    def locate(self, key):
+        """(archive path, byte offset of the binary marker) of an entry."""
+        return self.index_dict[key]
 
 
 class ArchiveWriter(Writer):
+    """Kaldi binary archive (+ scp with byte offsets of the '\\0B' markers)."""
+
     def __init__(self, ark_path, scp_path=None, dtype=np.float32):
         if not ark_path:
             raise RuntimeError("Seem configure path of archives as None")
@@ -376,16 +443,18 @@ class ArchiveWriter(Writer):
 
     def write(self, key, obj):
         self.check_args(obj)
-        kaldi_io.write_token(self.ark_file, key)
-        if self.path_or_dir != "-":
-            offset = self.ark_file.tell()
-        kaldi_io.write_binary_symbol(self.ark_file)
-        kaldi_io.write_float_mat_vec(self.ark_file, obj.astype(self.dtype))
-        if self.scp_file:
-            self.scp_file.write(f"{key}\t{self.path_or_dir}:{offset:d}\n")
+        fd = self.ark_fd
+        kaldi_io.write_token(fd, key)
+        offset = fd.tell() if self.target != "-" else None
+        kaldi_io.write_binary_symbol(fd)
+        kaldi_io.write_float_mat_vec(fd, obj.astype(self.dtype))
+        if offset is not None:
+            self.record(key, f"{self.target}:{offset:d}")
 
 
 class WaveWriter(Writer):
+    """{dir}/{key}.wav, PCM_16 (reference: data_handler.py:590-605)."""
+
     def __init__(self, dump_dir, scp_path=None, sr=16000, normalize=True):
         super().__init__(dump_dir, scp_path, is_dir=True)
         self.sr = sr
@@ -393,10 +462,16 @@ class WaveWriter(Writer):
 
     def write(self, key, obj):
         self.check_args(obj)
-        obj_path = self.path_or_dir / f"{key}.wav"
-        write_wav(str(obj_path), obj, sr=self.sr, normalize=self.normalize)
-        if self.scp_file:
-            self.scp_file.write(f"{key}\t{obj_path}\n")
+        dst = self.file_for(key, ".wav")
+        write_wav(str(dst), obj, sr=self.sr, normalize=self.normalize)
+        self.record(key, dst)
+
+    def write_pcm16(self, key, pcm):
+        """Samples that already are 16-bit PCM (the device quantises with
+        libsndfile's rule): no host conversion."""
+        dst = self.file_for(key, ".wav")
+        wavio.write_pcm16(str(dst), pcm, self.sr)
+        self.record(key, dst)
 
 
 class NumpyWriter(Writer):
@@ -405,7 +480,6 @@ class NumpyWriter(Writer):
 
     def write(self, key, obj):
         self.check_args(obj)
-        obj_path = self.path_or_dir / f"{key}.npy"
-        np.save(obj_path, obj)
-        if self.scp_file:
-            self.scp_file.write(f"{key}\t{obj_path}\n")
+        dst = self.file_for(key, ".npy")
+        np.save(dst, obj)
+        self.record(key, dst)

@@ -70,17 +70,8 @@ def write_int32(fd, value):
     fd.write(b"\x04" + struct.pack("<i", int(value)))
 
 
-def _peek(fd, n):
-    if hasattr(fd, "peek"):
-        return fd.peek(n)[:n]
-    pos = fd.tell()
-    data = fd.read(n)
-    fd.seek(pos)
-    return data
-
-
-def read_common_mat(fd):
-    kind = read_token(fd)
+def read_common_mat(fd, kind=None):
+    kind = kind or read_token(fd)
     _need(kind in ("FM", "DM"), f"Unknown matrix type: {kind}")
     dt = np.dtype(_FLOAT_TYPES[kind])
     rows, cols = read_int32(fd), read_int32(fd)
@@ -89,10 +80,10 @@ def read_common_mat(fd):
     return np.frombuffer(payload, dtype=dt).reshape(rows, cols)
 
 
-def read_float_vec(fd, direct_access=False):
+def read_float_vec(fd, direct_access=False, kind=None):
     if direct_access:
         expect_binary(fd)
-    kind = read_token(fd)
+    kind = kind or read_token(fd)
     _need(kind in ("FV", "DV"), f"Unknown vector type: {kind}")
     dt = np.dtype(_FLOAT_TYPES[kind])
     dim = read_int32(fd)
@@ -124,8 +115,8 @@ def uncompress(payload, kind, head):
     return vmin + q.reshape(rows, cols) * step
 
 
-def read_compress_mat(fd):
-    kind = read_token(fd)
+def read_compress_mat(fd, kind=None):
+    kind = kind or read_token(fd)
     head = struct.unpack("<ffii", fd.read(16))
     rows, cols = head[2], head[3]
     nbytes = {"CM": cols * (8 + rows), "CM2": 2 * rows * cols, "CM3": rows * cols}.get(kind)
@@ -133,24 +124,31 @@ def read_compress_mat(fd):
     return uncompress(fd.read(nbytes), kind, head)
 
 
+def _read_typed(fd, kind, allow_vec):
+    """Dispatch on the type token that precedes every Kaldi object (the token is
+    read, never peeked: BufferedReader.peek may return a single byte at a buffer
+    boundary)."""
+    _need(kind is not None, "unexpected end of archive")
+    if kind[0] == "C":
+        return read_compress_mat(fd, kind)
+    _need(kind[0] != "S", "sparse matrices are not supported on the mask path")
+    if kind in ("FV", "DV"):
+        _need(allow_vec, f"Unknown matrix type: {kind}")
+        return read_float_vec(fd, kind=kind)
+    return read_common_mat(fd, kind)
+
+
 def read_general_mat(fd, direct_access=False):
     if direct_access:
         expect_binary(fd)
-    first = _peek(fd, 1)
-    if first == b"C":
-        return read_compress_mat(fd)
-    _need(first != b"S", "sparse matrices are not supported on the mask path")
-    return read_common_mat(fd)
+    return _read_typed(fd, read_token(fd), allow_vec=False)
 
 
 def read_float_mat_vec(fd, direct_access=False):
     """Matrix or vector at the current position (scp offsets point at '\\0B')."""
     if direct_access:
         expect_binary(fd)
-    tag = _peek(fd, 2)
-    if tag[-1:] == b"V":
-        return read_float_vec(fd)
-    return read_general_mat(fd)
+    return _read_typed(fd, read_token(fd), allow_vec=True)
 
 
 def write_common_mat(fd, mat):

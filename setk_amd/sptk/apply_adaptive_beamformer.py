@@ -113,7 +113,7 @@ def run_online(args, shard):
     beamformer = cls(num_bins, args.channels, args.alpha)
     logger.info(f"Using online {args.beamformer} beamformer, chunk size = {args.chunk_size:d}")
     num_done = 0
-    keys = shard.assign(reader.index_keys)
+    keys = shard.assign_by_duration(reader)
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
         for key in keys:
             if key not in tgt:
@@ -169,7 +169,7 @@ def run_offline(args, shard):
                            ban=bool(args.ban), pmwf_ref=args.pmwf_ref,
                            rank1_appro=args.rank1_appro, post_mask=bool(args.mask),
                            vad_proportion=args.vad_proportion, pcm16=True, device=device)
-    keys = shard.assign(wav_reader.index_keys)
+    keys = shard.assign_by_duration(wav_reader)
     num_done = 0
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
 
@@ -183,9 +183,7 @@ def run_offline(args, shard):
                     # the reference's np.linalg.LinAlgError branch (:170-172)
                     logger.error(f"Raise linalg error: {key}")
                     continue
-                wavio.write_pcm16(str(writer.path_or_dir / f"{key}.wav"), pcm, args.sr)
-                if writer.scp_file:
-                    writer.scp_file.write(f"{key}\t{writer.path_or_dir / (key + '.wav')}\n")
+                writer.write_pcm16(key, pcm)
                 done += 1
             return done
 

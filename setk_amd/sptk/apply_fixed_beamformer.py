@@ -44,7 +44,7 @@ def run(args):
                                   round_power_of_two=bool(args.round_power_of_two),
                                   window=args.window, pcm16=True, device=device)
     wav_reader = WaveReader(args.wav_scp)
-    keys = shard.assign(wav_reader.index_keys)
+    keys = shard.assign_by_duration(wav_reader)
     num_done = 0
     with WaveWriter(args.dst_dir) as writer:
 
@@ -53,9 +53,7 @@ def run(args):
                 return 0
             outs = engine.run([(s, b) for (_, s, b) in pending])
             for (key, _, _), pcm in zip(pending, outs):
-                wavio.write_pcm16(str(writer.path_or_dir / f"{key}.wav"), pcm, writer.sr)
-                if writer.scp_file:
-                    writer.scp_file.write(f"{key}\t{writer.path_or_dir / (key + '.wav')}\n")
+                writer.write_pcm16(key, pcm)
             return len(pending)
 
         pending = []

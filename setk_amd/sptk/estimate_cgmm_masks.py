@@ -62,7 +62,7 @@ def run(args):
     num_done = 0
     with NumpyWriter(args.dst_dir) as writer:
         dst_dir = Path(args.dst_dir)
-        for key in shard.assign(reader.index_keys):
+        for key in shard.assign_by_duration(reader):
             if (dst_dir / f"{key}.npy").exists():
                 logger.info(f"Training utterance {key} ... Skip")
                 continue
@@ -110,7 +110,7 @@ def run_batched(args, shard):
                 num_done += 1
             pending.clear()
 
-        for key in shard.assign(reader.index_keys):
+        for key in shard.assign_by_duration(reader):
             if (dst_dir / f"{key}.npy").exists():
                 logger.info(f"Training utterance {key} ... Skip")
                 continue

@@ -345,3 +345,101 @@ def test_shard_world_size_two_gloo(tmp_path):
     for o in outs:
         assert o["world"] == 2
         assert o["tot"][0] == 11 and o["tot"][1] == sum(((i * 13) % 7) + 1 for i in range(11))
+
+
+_WORKER_RAGGED = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+from setk_amd.dist import Shard
+from setk_amd.libs.data_handler import WaveReader
+sh = Shard(backend="gloo")
+reader = WaveReader({scp!r})
+mine = sh.assign_by_duration(reader)
+sec = sum(reader.peek_nsamps(k) for k in mine) / 16000.0
+sh.barrier()
+tot = sh.sum_counts([len(mine), sec])
+print(json.dumps(dict(rank=sh.rank, mine=mine, sec=sec, tot=tot, w=sh.assigned_weight)))
+sh.close()
+"""
+
+
+def test_duration_balanced_sharding_world_size_two_gloo(tmp_path):
+    """What the CLIs do under torchrun: keys dealt by the lengths in the wave
+    headers (no decode); ragged lengths must balance in SECONDS, not in counts
+    (the reference's split_scp.pl balances counts, run_adapt_beamformer.sh:69-70)."""
+    from setk_amd.libs import wavio
+    lens = [160000, 8000, 8000, 8000, 480000, 16000, 16000, 240000, 32000, 8000, 100000]
+    with open(tmp_path / "wav.scp", "w") as f:
+        for i, n in enumerate(lens):
+            wavio.write_pcm16(str(tmp_path / f"u{i}.wav"), np.zeros((n, 2), np.int16), 16000)
+            f.write(f"u{i} {tmp_path}/u{i}.wav\n")
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER_RAGGED.format(root=ROOT, scp=str(tmp_path / "wav.scp")))
+    port = 29950 + (os.getpid() % 40)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(__import__("json").loads(o.strip().splitlines()[-1]))
+    assert sorted(outs[0]["mine"] + outs[1]["mine"]) == sorted(f"u{i}" for i in range(len(lens)))
+    total = sum(lens) / 16000.0
+    for o in outs:
+        assert abs(o["tot"][1] - total) < 1e-6 and o["tot"][0] == len(lens)
+        assert abs(o["w"] / 16000.0 - o["sec"]) < 1e-9
+    # seconds are balanced to within the longest utterance's share of a greedy deal;
+    # a plain round robin on counts would put 480000 + 240000 + ... on one rank
+    assert abs(outs[0]["sec"] - outs[1]["sec"]) <= max(lens) / 16000.0 * 0.5
+    rr = [sum(lens[r::2]) / 16000.0 for r in range(2)]
+    assert abs(outs[0]["sec"] - outs[1]["sec"]) < abs(rr[0] - rr[1])
+
+
+def test_kaldi_sequential_vectors_across_buffer_boundaries(tmp_path):
+    """Vector entries whose type token straddles an 8 KiB BufferedReader boundary
+    (a peek-based dispatch saw one byte there and took the vector for a matrix)."""
+    from setk_amd.libs import kaldi_io
+    from setk_amd.libs.data_handler import ArchiveReader, ArchiveWriter
+    rng = np.random.default_rng(0)
+    path = str(tmp_path / "v.ark")
+    items = []
+    with ArchiveWriter(path) as w:
+        for i in range(40):
+            # payload sizes walk the header of the next entry across offset 8192 * k
+            v = rng.standard_normal(2040 + i).astype(np.float32)
+            items.append((f"k{i}", v))
+            w.write(f"k{i}", v)
+            m = rng.standard_normal((3, 5 + i)).astype(np.float32)
+            items.append((f"m{i}", m))
+            w.write(f"m{i}", m)
+    got = list(ArchiveReader(path))
+    assert [k for k, _ in got] == [k for k, _ in items]
+    for (_, a), (_, b) in zip(got, items):
+        assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_writer_family(tmp_path):
+    from setk_amd.libs.data_handler import (ArchiveWriter, NumpyWriter, ScriptReader, WaveWriter,
+                                            WaveReader)
+    m = np.arange(12, dtype=np.float32).reshape(3, 4)
+    with ArchiveWriter(str(tmp_path / "a.ark"), str(tmp_path / "a.scp")) as w:
+        w.write("x", m)
+        w.write("y", m[0])
+        with pytest.raises(RuntimeError):
+            w.write("z", [1, 2, 3])
+    r = ScriptReader(str(tmp_path / "a.scp"))
+    assert np.array_equal(r["x"], m) and np.array_equal(r["y"], m[0])
+    with NumpyWriter(str(tmp_path / "npy"), str(tmp_path / "n.scp")) as w:
+        w.write("x", m)
+    assert np.array_equal(np.load(tmp_path / "npy" / "x.npy"), m)
+    assert (tmp_path / "n.scp").read_text().split()[0] == "x"
+    with WaveWriter(str(tmp_path / "wav" / "deep"), str(tmp_path / "w.scp")) as w:
+        w.write("s", np.linspace(-0.5, 0.5, 100).astype(np.float32))
+        w.write_pcm16("p", np.arange(-50, 50, dtype=np.int16))
+    rd = WaveReader(str(tmp_path / "w.scp"))
+    assert rd.peek_nsamps("s") == 100 and rd.peek_nsamps("p") == 100
+    assert np.array_equal(rd.read_pcm16("p")[:, 0], np.arange(-50, 50, dtype=np.int16))
