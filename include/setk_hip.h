@@ -158,6 +158,15 @@ int setk_weights(setk_handle_t h, const setk_bf_opts* opts, const float* Rs,
 int setk_pcm16_to_float(setk_handle_t h, const int16_t* pcm, int num_channels,
                         int num_samples, float* audio, void* stream);
 
+/* The same for a batch in ONE launch (device pointers; the tables are host
+ * arrays): what the streaming host pipeline runs on a staging slab of wav
+ * payloads.  power0 (device double[n_utts], may be NULL) receives sum(x0^2) of
+ * channel 0 -- SpectrogramReader.power * N (data_handler.py:398-403), which the
+ * CLI only logs.  Asynchronous on `stream`. */
+int setk_pcm16_to_float_batch(setk_handle_t h, int n_utts, int num_channels,
+                              const int16_t* const* pcm, const int* num_samples,
+                              float* const* audio, double* power0, void* stream);
+
 /* do_ban (libs/beamformer.py:14-28) on an arbitrary weight:
  * out[f] = w[f] * sqrt(|w^H Rn Rn w|) / max(Re w^H Rn w, eps_f32). */
 int setk_ban(setk_handle_t h, const float* weight, const float* Rn, int num_bins,
@@ -227,7 +236,8 @@ int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
  * mask_n     NULL, or per-utterance interferer masks (--itf-mask)
  * wave[u]    device float32 (or int16) [hop*(T_u-1)] when center, see
  *            setk_istft_num_samples
- * status[u]  host int, SETK_NUM_* (worst bin of the utterance)
+ * status[u]  int, SETK_NUM_* (worst bin of the utterance); host memory (the call
+ *            then synchronises the stream), device memory (asynchronous) or NULL
  * The pointer tables and num_samples are HOST arrays of n_utts entries.
  * Requires the n_fft = 512 plan and 1 <= C <= 8. */
 int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts,

@@ -50,7 +50,7 @@ def exported_symbols():
         "setk_abi_version", "setk_create", "setk_destroy", "setk_last_error",
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
-        "setk_pcm16_to_float", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
+        "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
         "setk_cgmm_masks_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
         "setk_directional_feats", "setk_set_profiling",
@@ -92,6 +92,8 @@ def load_library():
                                  fp, fp, POINTER(c_int), c_void_p]
     lib.setk_ban.argtypes = [H, fp, fp, c_int, c_int, fp, c_void_p]
     lib.setk_pcm16_to_float.argtypes = [H, c_void_p, c_int, c_int, fp, c_void_p]
+    lib.setk_pcm16_to_float_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int),
+                                              POINTER(c_void_p), c_void_p, c_void_p]
     lib.setk_rank1.argtypes = [H, fp, fp, c_int, c_int, fp, fp, c_void_p]
     lib.setk_beamform.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, c_void_p]
     lib.setk_cgmm_masks.argtypes = [H, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_void_p]
@@ -122,6 +124,8 @@ def _ptr(x):
     """Raw address of a numpy array (host) or torch tensor (host/device)."""
     if x is None:
         return None
+    if isinstance(x, int):  # a raw (device) address
+        return x
     if isinstance(x, np.ndarray):
         if not x.flags["C_CONTIGUOUS"]:
             raise ValueError("array must be C-contiguous")
@@ -251,6 +255,17 @@ class Context:
             self._lib.setk_pcm16_to_float(self._h, _ptr(pcm), C, N, _ptr(out),
                                           current_stream_ptr() if stream is None else stream))
 
+    def pcm16_to_float_batch(self, C, pcm_ptrs, num_samples, out_ptrs, power0=None, stream=None):
+        """One launch for a batch of interleaved int16 payloads (device addresses)."""
+        n = len(pcm_ptrs)
+        P = (c_void_p * n)(*pcm_ptrs)
+        O = (c_void_p * n)(*out_ptrs)
+        NS = (c_int * n)(*[int(v) for v in num_samples])
+        self.check(
+            self._lib.setk_pcm16_to_float_batch(
+                self._h, n, int(C), P, NS, O, _ptr(power0),
+                current_stream_ptr() if stream is None else stream))
+
     def ban(self, weight, Rn, F, C, out, stream=None):
         self.check(
             self._lib.setk_ban(self._h, _ptr(weight), _ptr(Rn), F, C, _ptr(out),
@@ -286,7 +301,8 @@ class Context:
 
     # -- fused hot path ---------------------------------------------------------
     def enhance_batch(self, opts, num_channels, audio_ptrs, num_samples, mask_ptrs,
-                      itf_ptrs, wave_ptrs, want_status=True, stream=None, taps=None):
+                      itf_ptrs, wave_ptrs, want_status=True, stream=None, taps=None,
+                      status_ptr=None):
         """taps: dict with any of Rs, Rn ([n][F][C][C] complex64), weight ([n][F][C]
         complex64), maxabs ([n] float32) -> numpy arrays / device tensors filled by
         setk_enhance_batch_taps."""
@@ -297,6 +313,10 @@ class Context:
         I = (c_void_p * n)(*itf_ptrs) if itf_ptrs is not None else None
         NS = (c_int * n)(*[int(v) for v in num_samples])
         ST = (c_int * n)() if want_status else None
+        if status_ptr is not None:
+            # device int32[n]: filled asynchronously on the stream, nothing returned
+            ST = ctypes.cast(c_void_p(int(status_ptr)), POINTER(c_int))
+            want_status = False
         st = current_stream_ptr() if stream is None else stream
         if taps:
             tp = BatchTaps(*[_ptr(taps.get(k)) for k in ("Rs", "Rn", "weight", "maxabs")])

@@ -773,6 +773,30 @@ int setk_pcm16_to_float(setk_handle_t h, const int16_t* pcm, int num_channels, i
     return SETK_OK;
 }
 
+int setk_pcm16_to_float_batch(setk_handle_t h, int n_utts, int num_channels,
+                              const int16_t* const* pcm, const int* num_samples,
+                              float* const* audio, double* power0, void* stream) {
+    if (!h || n_utts <= 0 || num_channels <= 0 || !pcm || !num_samples || !audio)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h, s);
+    std::vector<char> tbl(pcm_item_bytes() * n_utts);
+    int max_n = 0;
+    for (int u = 0; u < n_utts; ++u) {
+        if (!pcm[u] || !audio[u] || num_samples[u] <= 0)
+            return fail(h, SETK_ERR_INVALID, "null utterance pointer");
+        pcm_item_fill(tbl.data(), u, pcm[u], audio[u], num_samples[u]);
+        max_n = std::max(max_n, num_samples[u]);
+    }
+    void* d_tbl;
+    int rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
+    if (rc) return rc;
+    if (power0) HIP_TRY(h, hipMemsetAsync(power0, 0, (size_t)n_utts * sizeof(double), s));
+    HIP_TRY(h, launch_pcm16_to_float_batch(d_tbl, n_utts, num_channels, max_n, power0, s));
+    return SETK_OK;
+}
+
 int setk_rank1(setk_handle_t h, const float* Rs, const float* Rn, int num_bins,
                int num_channels, float* out, int* status, void* stream) {
     if (!h || !Rs || !out || num_bins <= 0) return fail(h, SETK_ERR_INVALID, "bad args");
@@ -1305,9 +1329,11 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
             HIP_TRY(h, hipMemcpyAsync(taps->maxabs, d_norm, (size_t)n_utts * 4,
                                       hipMemcpyDeviceToHost, s));
     }
+    const bool status_dev = status && is_device_ptr(status);
     if (status)
-        HIP_TRY(h, hipMemcpyAsync(status, d_status, (size_t)n_utts * 4, hipMemcpyDeviceToHost, s));
-    if (status || tap_rs.host || tap_rn.host || tap_w.host ||
+        HIP_TRY(h, hipMemcpyAsync(status, d_status, (size_t)n_utts * 4,
+                                  status_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    if ((status && !status_dev) || tap_rs.host || tap_rn.host || tap_w.host ||
         (taps && taps->maxabs && !is_device_ptr(taps->maxabs)))
         HIP_TRY(h, hipStreamSynchronize(s));
     return SETK_OK;

@@ -157,6 +157,10 @@ hipError_t launch_maxabs(const UttDesc* utts, int C, unsigned* norm_bits, int n_
 hipError_t launch_pack_fixed_weights(const float* sets, const int* index, int n_utts, int C,
                                      float* out, hipStream_t s);
 hipError_t launch_pcm16_to_float(const int16_t* pcm, int C, int N, float* out, hipStream_t s);
+size_t pcm_item_bytes();
+void pcm_item_fill(void* dst, int i, const int16_t* pcm, float* out, int n);
+hipError_t launch_pcm16_to_float_batch(const void* d_items, int n_utts, int C, int max_n,
+                                       double* power0, hipStream_t s);
 hipError_t launch_beamform_spec(const float* w_fc, const float* spec, int C, int T, int F,
                                 float* out, hipStream_t s);
 

@@ -297,6 +297,53 @@ hipError_t launch_pcm16_to_float(const int16_t* pcm, int C, int N, float* out, h
     return hipGetLastError();
 }
 
+// Batched form: one launch for a whole staging slab (blockIdx.y = utterance).
+// Optionally sums x^2 of channel 0 (SpectrogramReader.power, only used for the
+// CLI's log line) into power0[u] (double, atomics: log precision only).
+struct PcmItem {
+    const int16_t* pcm;
+    float* out;
+    int n;
+    int pad_;
+};
+
+__global__ __launch_bounds__(256) void pcm16_to_float_batch_kernel(const PcmItem* __restrict__ items,
+                                                                   int C, double* power0) {
+    const PcmItem it = items[blockIdx.y];
+    float acc = 0.f;
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < it.n; n += gridDim.x * 256) {
+        const int16_t* src = it.pcm + (size_t)n * C;
+        for (int c = 0; c < C; ++c) {
+            const float v = (float)src[c] * (1.0f / 32768.0f);
+            it.out[(size_t)c * it.n + n] = v;
+            if (c == 0) acc = fmaf(v, v, acc);
+        }
+    }
+    if (power0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if ((threadIdx.x & 63) == 0) atomicAdd(power0 + blockIdx.y, (double)acc);
+    }
+}
+
+size_t pcm_item_bytes() { return sizeof(PcmItem); }
+void pcm_item_fill(void* dst, int i, const int16_t* pcm, float* out, int n) {
+    PcmItem* it = static_cast<PcmItem*>(dst) + i;
+    it->pcm = pcm;
+    it->out = out;
+    it->n = n;
+    it->pad_ = 0;
+}
+
+hipError_t launch_pcm16_to_float_batch(const void* d_items, int n_utts, int C, int max_n,
+                                       double* power0, hipStream_t s) {
+    int bx = (max_n + 256 * 8 - 1) / (256 * 8);
+    bx = bx < 1 ? 1 : bx;
+    hipLaunchKernelGGL(pcm16_to_float_batch_kernel, dim3(bx, n_utts), dim3(256), 0, s,
+                       static_cast<const PcmItem*>(d_items), C, power0);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // Helpers of the fixed-weight path (apply_fixed_beamformer.py:38-48):
 // max |audio| per utterance (SpectrogramReader.maxabs, the renorm target) and

@@ -107,6 +107,21 @@ class BatchEnhancer(object):
         s = self.stft
         self.ctx.stft_plan(s["frame_len"], s["frame_hop"], s["n_fft"], s["center"], s["window"])
 
+    def frames_and_length(self, num_samples):
+        """(T, L) of the planned transform for a signal of num_samples, evaluated on
+        the host (librosa's framing: SURVEY appendix A)."""
+        s = self.stft
+        hop, n_fft = s["frame_hop"], s["n_fft"]
+        if s["center"]:
+            if num_samples < n_fft // 2 + 1:
+                raise ValueError("signal shorter than n_fft/2+1 (reflect padding)")
+            T = 1 + num_samples // hop
+            return T, hop * (T - 1)
+        if num_samples < n_fft:
+            raise ValueError("signal shorter than n_fft")
+        T = 1 + (num_samples - n_fft) // hop
+        return T, n_fft + hop * (T - 1)
+
     def condition_mask(self, mask, num_frames):
         """apply_adaptive_beamformer.py:146-151: masks arrive T x F or F x T."""
         F = self.num_bins

@@ -1,0 +1,548 @@
+"""
+Streaming host pipeline of the beamformer CLI: disk -> pinned staging slab ->
+H2D -> fused kernels -> D2H -> wav files, several batches in flight.
+
+This replaces the reference's per-utterance loop
+(scripts/sptk/apply_adaptive_beamformer.py:130-178 on top of
+libs/data_handler.py:345-413: decode, compute, encode, one utterance at a time on
+one core).  The kernels need ~16 us per 8-ch / 30-s utterance; reading its
+7.7 MB of PCM and 1.9 MB of mask and crossing PCIe costs 20x that, so the host
+side is organised as a pipeline with every stage overlapped:
+
+  plan      (caller's thread)  wave / mask headers only: channels, samples, frames,
+                               payload offsets -> byte offsets inside a slab
+  read      (thread pool)      file.readinto(pinned slab) -- the wav's 16-bit frames
+                               and the float32 mask rows land in page-locked memory
+                               exactly as stored, no host conversion
+  H2D       (copy-in stream)   ONE hipMemcpyAsync per batch
+  compute   (compute stream)   setk_pcm16_to_float_batch + setk_enhance_batch, status
+                               and PCM16 output written into the device out-slab
+  D2H       (copy-out stream)  ONE hipMemcpyAsync per batch
+  write     (thread pool)      RIFF header + the slab's int16 samples -> {key}.wav
+
+A slab slot (pinned host in/out + device in/out + device float audio) is owned
+by one batch from `read` to `write`; `depth` slots bound the memory and give the
+overlap.  Inputs the fast path cannot take as stored (non-PCM16 wavs, pipes,
+per-channel globs, compressed / transposed / float64 masks) are decoded on the
+host by the ordinary readers and copied into the slab as float32.
+
+PyTorch is plumbing here: pinned / device buffers, streams and events.
+"""
+import os
+import queue
+import struct
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import _ffi
+from .libs import wavio
+
+ALIGN = 256
+
+
+def _align(n):
+    return (n + ALIGN - 1) // ALIGN * ALIGN
+
+
+# ----------------------------------------------------------------------------
+# sources: what can be read straight into a slab
+# ----------------------------------------------------------------------------
+class Payload(object):
+    """A contiguous byte range of an open file that IS the data wanted (int16 wav
+    frames [N][C] or float32 mask rows [T][F]), or a host array to copy."""
+
+    __slots__ = ("fd", "offset", "nbytes", "array")
+
+    def __init__(self, fd=None, offset=0, nbytes=0, array=None):
+        self.fd, self.offset, self.nbytes, self.array = fd, offset, nbytes, array
+
+    def load_into(self, dst):
+        """dst: writable uint8 numpy view of exactly nbytes."""
+        if self.array is not None:
+            dst[:] = np.frombuffer(self.array, dtype=np.uint8)
+            return
+        got = 0
+        mv = memoryview(dst)
+        while got < self.nbytes:  # os.preadv releases the GIL, no seek state
+            n = os.preadv(self.fd, [mv[got:]], self.offset + got)
+            if n <= 0:
+                raise IOError("truncated payload")
+            got += n
+
+
+class OpenFiles(object):
+    """Process-lifetime cache of read-only descriptors (the reference's readers
+    also keep archives open, data_handler.py:343, 522-529)."""
+
+    def __init__(self, limit=512):
+        self.fds = {}
+        self.limit = limit
+        self.lock = threading.Lock()
+
+    def get(self, path):
+        with self.lock:
+            fd = self.fds.get(path)
+            if fd is None:
+                if len(self.fds) >= self.limit:
+                    for p in list(self.fds)[:self.limit // 2]:
+                        os.close(self.fds.pop(p))
+                fd = self.fds[path] = os.open(path, os.O_RDONLY)
+            return fd
+
+    def close(self):
+        with self.lock:
+            for fd in self.fds.values():
+                os.close(fd)
+            self.fds.clear()
+
+
+def probe_wav(files, path, offset=0):
+    """Header of a wave file (or of a wave inside an archive at `offset`) ->
+    (info dict, absolute payload offset)."""
+    fd = files.get(path)
+
+    class _Buf(object):  # minimal file interface over the header bytes for wavio
+        def __init__(self, b):
+            self.b, self.p = b, 0
+
+        def read(self, n):
+            out = self.b[self.p:self.p + n]
+            self.p += len(out)
+            return out
+
+        def seekable(self):
+            return True
+
+        def seek(self, n, whence=0):
+            self.p = self.p + n if whence == 1 else n
+
+    for window in (4096, 1 << 20):  # headers with long LIST chunks need the second try
+        buf = _Buf(os.pread(fd, window, offset))
+        try:
+            info = wavio.read_header(buf)
+            return info, offset + buf.p
+        except wavio.WaveFormatError:
+            if window != 4096:
+                raise
+
+
+def probe_npy(files, path):
+    """-> (shape, dtype, fortran, payload offset) of a .npy file."""
+    fd = files.get(path)
+    head = os.pread(fd, 4096, 0)
+    if head[:6] != b"\x93NUMPY":
+        raise ValueError(f"{path}: not a .npy file")
+    major = head[6]
+    if major == 1:
+        hlen = struct.unpack("<H", head[8:10])[0]
+        start = 10
+    else:
+        hlen = struct.unpack("<I", head[8:12])[0]
+        start = 12
+    if start + hlen > len(head):
+        head = os.pread(fd, start + hlen, 0)
+    import ast
+    d = ast.literal_eval(head[start:start + hlen].decode("latin1"))
+    return tuple(d["shape"]), np.dtype(d["descr"]), bool(d["fortran_order"]), start + hlen
+
+
+def probe_kaldi_matrix(files, path, offset):
+    """Binary Kaldi float matrix at `offset` (the scp offset points at '\\0B') ->
+    (rows, cols, dtype, payload offset), or None for compressed / vector entries."""
+    fd = files.get(path)
+    head = os.pread(fd, 32, offset)
+    p = 0
+    if head[:2] == b"\x00B":
+        p = 2
+    tok = head[p:p + 3]
+    if tok not in (b"FM ", b"DM "):
+        return None
+    p += 3
+    if head[p] != 4 or head[p + 5] != 4:
+        return None
+    rows = struct.unpack("<i", head[p + 1:p + 5])[0]
+    cols = struct.unpack("<i", head[p + 6:p + 10])[0]
+    return rows, cols, np.dtype("<f4" if tok == b"FM " else "<f8"), offset + p + 10
+
+
+# ----------------------------------------------------------------------------
+# one utterance of a batch
+# ----------------------------------------------------------------------------
+class Job(object):
+    __slots__ = ("key", "C", "N", "T", "L", "pcm16", "audio", "mask", "itf", "off_audio",
+                 "off_mask", "off_itf", "off_f32", "off_out", "error", "power", "pw_idx")
+
+    def __init__(self, key):
+        self.key = key
+        self.error = None
+
+
+class _Slot(object):
+    """Buffers of one in-flight batch."""
+
+    def __init__(self, torch, dev, in_cap, f32_cap, out_cap):
+        self.torch, self.dev = torch, dev
+        self.in_cap = self.f32_cap = self.out_cap = 0
+        self.h_in = self.d_in = self.d_f32 = self.h_out = self.d_out = None
+        self.ensure(in_cap, f32_cap, out_cap)
+        self.e_in = torch.cuda.Event()
+        self.e_compute = torch.cuda.Event()
+        self.e_out = torch.cuda.Event()
+
+    def ensure(self, in_cap, f32_cap, out_cap):
+        torch, dev = self.torch, self.dev
+        if in_cap > self.in_cap:
+            self.h_in = torch.empty(in_cap, dtype=torch.uint8, pin_memory=True)
+            self.d_in = torch.empty(in_cap, dtype=torch.uint8, device=dev)
+            self.np_in = self.h_in.numpy()
+            self.in_cap = in_cap
+        if f32_cap > self.f32_cap:
+            self.d_f32 = torch.empty(f32_cap, dtype=torch.uint8, device=dev)
+            self.f32_cap = f32_cap
+        if out_cap > self.out_cap:
+            self.h_out = torch.empty(out_cap, dtype=torch.uint8, pin_memory=True)
+            self.d_out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
+            self.np_out = self.h_out.numpy()
+            self.out_cap = out_cap
+
+
+class StreamPipeline(object):
+    """
+    pipe = StreamPipeline(engine, sink, ...)      engine: a BatchEnhancer (n_fft 512)
+    pipe.submit(key, wav_payload_or_array, mask_payload_or_array, itf_or_None)
+    ...
+    pipe.close()  -> (num_done, stats)
+
+    announce(key, power) is called in submission order when a batch has come back
+    (the CLI's "Processing utterance ..." line); sink(key, pcm_int16_view, status,
+    error) -> bool from writer threads, in no particular order (status != 0: the
+    reference's LinAlgError case; error: an exception raised while reading).
+    """
+
+    def __init__(self, engine, sink, announce=None, batch_utts=32, depth=3, read_threads=None,
+                 write_threads=4, slab_mb=0):
+        import torch
+        self.torch = torch
+        self.engine = engine
+        self.ctx = engine.ctx
+        self.dev = engine.dev
+        self.sink = sink
+        self.announce = announce
+        self.batch_utts = max(1, int(batch_utts))
+        self.F = engine.num_bins
+        ncpu = os.cpu_count() or 4
+        self.read_threads = read_threads or max(4, min(32, ncpu // 2))
+        self.readers = ThreadPoolExecutor(self.read_threads, thread_name_prefix="setk-read")
+        self.writers = ThreadPoolExecutor(write_threads, thread_name_prefix="setk-write")
+        self.depth = depth
+        self.free_slots = queue.Queue()
+        self.slots_made = 0
+        self.min_in = slab_mb << 20
+        self.launch_q = queue.Queue(maxsize=depth)
+        self.done_q = queue.Queue(maxsize=depth)
+        self.pending = []
+        self.group = None
+        self.num_done = 0
+        self.num_failed = 0
+        self.exc = None
+        self.stats = dict(batches=0, utts=0, bytes_in=0, bytes_out=0, t_read=0.0, t_h2d_wait=0.0,
+                          t_launch=0.0, t_d2h_wait=0.0, t_write=0.0, t_plan=0.0)
+        self.lock = threading.Lock()
+        engine._plan()
+        self.s_in = torch.cuda.Stream(device=self.dev)
+        self.s_compute = torch.cuda.Stream(device=self.dev)
+        self.s_out = torch.cuda.Stream(device=self.dev)
+        self.t_first = None
+        self.launcher = threading.Thread(target=self._launch_loop, name="setk-launch", daemon=True)
+        self.completer = threading.Thread(target=self._complete_loop, name="setk-done", daemon=True)
+        self.launcher.start()
+        self.completer.start()
+
+    # ---- planning (caller's thread) ---------------------------------------------
+    def submit(self, key, audio, mask, itf=None):
+        """audio: Payload of int16 frames + (C, N) via .meta, or a C x N float32 array;
+        mask / itf: Payload of float32 [T][F] rows or a T x F array.  See make_*()."""
+        if self.exc:
+            raise self.exc
+        if self.t_first is None:
+            self.t_first = time.perf_counter()
+        t0 = time.perf_counter()
+        job = Job(key)
+        if isinstance(audio, tuple):          # (Payload, C, N): PCM16 as stored
+            job.audio, job.C, job.N = audio
+            job.pcm16 = True
+        else:
+            a = np.ascontiguousarray(audio, dtype=np.float32)
+            if a.ndim == 1:
+                a = a[None]
+            job.C, job.N = a.shape
+            job.audio = Payload(array=a, nbytes=a.nbytes)
+            job.pcm16 = False
+            job.power = float(np.dot(a[0].astype(np.float64), a[0])) / max(a.shape[1], 1)
+        job.T, job.L = self.engine.frames_and_length(job.N)
+        job.mask = self._mask_payload(mask, job.T)
+        job.itf = None if itf is None else self._mask_payload(itf, job.T)
+        g = (job.C, job.itf is not None)
+        if self.pending and (g != self.group or len(self.pending) >= self.batch_utts):
+            self._dispatch()
+        self.group = g
+        self.pending.append(job)
+        self.stats["t_plan"] += time.perf_counter() - t0
+        if len(self.pending) >= self.batch_utts:
+            self._dispatch()
+
+    def _mask_payload(self, m, T):
+        if isinstance(m, Payload):
+            if m.nbytes != T * self.F * 4:
+                raise ValueError("Shape of input obs do not match with mask matrix, " +
+                                 f"{T} frames vs {m.nbytes // (4 * self.F)} mask rows")
+            return m
+        m = self.engine.condition_mask(m, T)
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        return Payload(array=m, nbytes=m.nbytes)
+
+    def _get_slot(self, in_cap, f32_cap, out_cap):
+        if self.slots_made < self.depth and self.free_slots.empty():
+            self.slots_made += 1
+            grow = 1.25  # head room: later batches of ragged lengths reuse the buffers
+            slot = _Slot(self.torch, self.dev, max(int(in_cap * grow), self.min_in),
+                         int(f32_cap * grow), int(out_cap * grow))
+        else:
+            while True:
+                try:
+                    slot = self.free_slots.get(timeout=0.5)
+                    break
+                except queue.Empty:
+                    if self.exc:
+                        raise self.exc
+            slot.ensure(in_cap, f32_cap, out_cap)
+        return slot
+
+    def _dispatch(self):
+        batch, self.pending = self.pending, []
+        if not batch:
+            return
+        # slab layout: [audio payloads | masks | itf masks]; out: [pcm16 waves | status | power]
+        off = 0
+        f32 = 0
+        out = 0
+        for j in batch:
+            j.off_audio = off
+            off = _align(off + j.audio.nbytes)
+        for j in batch:
+            j.off_mask = off
+            off = _align(off + j.mask.nbytes)
+            if j.itf is not None:
+                j.off_itf = off
+                off = _align(off + j.itf.nbytes)
+        for j in batch:
+            j.off_f32 = f32
+            if j.pcm16:
+                f32 = _align(f32 + 4 * j.C * j.N)
+            j.off_out = out
+            out = _align(out + 2 * j.L)
+        n = len(batch)
+        off_status = out
+        off_power = _align(off_status + 4 * n)
+        out_total = _align(off_power + 8 * n)
+        slot = self._get_slot(max(off, ALIGN), max(f32, ALIGN), out_total)
+        t0 = time.perf_counter()
+        futs = [self.readers.submit(self._read_job, j, slot) for j in batch]
+        self.launch_q.put((batch, slot, futs, off, off_status, off_power, out_total, t0))
+
+    # ---- read stage (pool) --------------------------------------------------------
+    @staticmethod
+    def _read_job(job, slot):
+        try:
+            buf = slot.np_in
+            job.audio.load_into(buf[job.off_audio:job.off_audio + job.audio.nbytes])
+            job.mask.load_into(buf[job.off_mask:job.off_mask + job.mask.nbytes])
+            if job.itf is not None:
+                job.itf.load_into(buf[job.off_itf:job.off_itf + job.itf.nbytes])
+        except Exception as e:  # reported per utterance by the completer
+            job.error = e
+
+    # ---- H2D + kernels + D2H (one thread owns the handle) ---------------------------
+    def _launch_loop(self):
+        torch = self.torch
+        try:
+            torch.cuda.set_device(self.dev)
+            while True:
+                item = self.launch_q.get()
+                if item is None:
+                    self.done_q.put(None)
+                    return
+                batch, slot, futs, used_in, off_status, off_power, out_total, t0 = item
+                for f in futs:
+                    f.result()
+                t1 = time.perf_counter()
+                good = [j for j in batch if j.error is None]
+                if good:
+                    self._launch(good, len(batch), slot, used_in, off_status, off_power, out_total)
+                t2 = time.perf_counter()
+                with self.lock:
+                    self.stats["t_read"] += t1 - t0
+                    self.stats["t_launch"] += t2 - t1
+                    self.stats["bytes_in"] += used_in
+                    self.stats["bytes_out"] += out_total
+                self.done_q.put((batch, slot, off_status, off_power, bool(good)))
+        except BaseException as e:  # surfaces in submit()/close()
+            self.exc = e
+            self.done_q.put(None)
+
+    def _launch(self, jobs, n_all, slot, used_in, off_status, off_power, out_total):
+        torch, ctx, eng = self.torch, self.ctx, self.engine
+        with torch.cuda.stream(self.s_in):
+            slot.d_in[:used_in].copy_(slot.h_in[:used_in], non_blocking=True)
+            slot.e_in.record(self.s_in)
+        C = jobs[0].C
+        has_itf = jobs[0].itf is not None
+        base_in, base_f32, base_out = (slot.d_in.data_ptr(), slot.d_f32.data_ptr(),
+                                       slot.d_out.data_ptr())
+        with torch.cuda.stream(self.s_compute):
+            self.s_compute.wait_event(slot.e_in)
+            stream = self.s_compute.cuda_stream
+            pcm = [j for j in jobs if j.pcm16]
+            if pcm:
+                # int16 frames -> float32 C x N; sum(x0^2) of the k-th converted
+                # utterance lands at off_power + 8 k of the out-slab (log line only)
+                for k, j in enumerate(pcm):
+                    j.pw_idx = k
+                ctx.pcm16_to_float_batch(C, [base_in + j.off_audio for j in pcm],
+                                         [j.N for j in pcm], [base_f32 + j.off_f32 for j in pcm],
+                                         power0=base_out + off_power, stream=stream)
+            aptr = [(base_f32 + j.off_f32) if j.pcm16 else (base_in + j.off_audio) for j in jobs]
+            mptr = [base_in + j.off_mask for j in jobs]
+            iptr = [base_in + j.off_itf for j in jobs] if has_itf else None
+            wptr = [base_out + j.off_out for j in jobs]
+            kind = eng.opts_kw["kind"]
+            if has_itf and kind == _ffi.BF_MPDR:
+                iptr = None  # plain MPDR never reads the interferer mask
+            flags = eng.base_flags | _ffi.FLAG_OUT_PCM16 | (0 if has_itf else _ffi.FLAG_CLAMP_MASK)
+            opts = _ffi.BfOpts(flags=flags, **eng.opts_kw)
+            # status of job i at off_status + 4 * i (positions within `jobs`)
+            ctx.enhance_batch(opts, C, aptr, [j.N for j in jobs], mptr, iptr, wptr,
+                              stream=stream, status_ptr=base_out + off_status)
+            slot.e_compute.record(self.s_compute)
+        with torch.cuda.stream(self.s_out):
+            self.s_out.wait_event(slot.e_compute)
+            slot.h_out[:out_total].copy_(slot.d_out[:out_total], non_blocking=True)
+            slot.e_out.record(self.s_out)
+
+    # ---- completion: wait for D2H, hand the samples to the writers ------------------
+    def _complete_loop(self):
+        try:
+            self.torch.cuda.set_device(self.dev)
+            while True:
+                item = self.done_q.get()
+                if item is None:
+                    return
+                batch, slot, off_status, off_power, launched = item
+                t0 = time.perf_counter()
+                if launched:
+                    slot.e_out.synchronize()
+                t1 = time.perf_counter()
+                good = [j for j in batch if j.error is None]
+                status = np.frombuffer(slot.np_out[off_status:off_status + 4 * len(good)],
+                                       dtype=np.int32)
+                power = np.frombuffer(slot.np_out[off_power:off_power + 8 * len(good)],
+                                      dtype=np.float64)
+                futs = []
+                gi = 0
+                for j in batch:
+                    if j.error is not None:
+                        futs.append(self.writers.submit(self.sink, j.key, None, -1, j.error))
+                        continue
+                    if self.announce is not None:
+                        self.announce(j.key, float(power[j.pw_idx]) / max(j.N, 1)
+                                      if j.pcm16 else j.power)
+                    pcm = np.frombuffer(slot.np_out[j.off_out:j.off_out + 2 * j.L], dtype=np.int16)
+                    futs.append(self.writers.submit(self.sink, j.key, pcm, int(status[gi]), None))
+                    gi += 1
+                ok = 0
+                for f in futs:
+                    ok += 1 if f.result() else 0
+                t2 = time.perf_counter()
+                with self.lock:
+                    self.num_done += ok
+                    self.stats["batches"] += 1
+                    self.stats["utts"] += len(batch)
+                    self.stats["t_d2h_wait"] += t1 - t0
+                    self.stats["t_write"] += t2 - t1
+                self.free_slots.put(slot)
+        except BaseException as e:
+            self.exc = e
+
+    def close(self):
+        """Flush, wait for everything in flight, return (num_done, stats)."""
+        try:
+            if not self.exc:
+                self._dispatch()
+        finally:
+            self.launch_q.put(None)
+            self.launcher.join()
+            self.completer.join()
+            self.readers.shutdown()
+            self.writers.shutdown()
+        if self.exc:
+            raise self.exc
+        st = dict(self.stats)
+        st["wall_s"] = (time.perf_counter() - self.t_first) if self.t_first else 0.0
+        st["read_threads"] = self.read_threads
+        st["depth"] = self.depth
+        st["batch_utts"] = self.batch_utts
+        return self.num_done, st
+
+
+# ----------------------------------------------------------------------------
+# scp entries -> sources
+# ----------------------------------------------------------------------------
+def wav_source(wav_reader, key, files):
+    """What submit() takes as `audio` for an entry of a WaveReader table: the PCM16
+    payload as it lies in the file when the entry is ONE 16-bit PCM file (plain
+    path or path.ark:offset), else the decoded C x N float32 array."""
+    import glob
+    fname = wav_reader.index_dict[key].rstrip()
+    if wav_reader.normalize and fname and fname[-1] != "|":
+        hits = glob.glob(fname)
+        if ":" in fname and not hits:
+            hits = [fname]
+        if len(hits) == 1:
+            path, offset = hits[0], 0
+            if not os.path.exists(path) and ":" in path:
+                path, off = path.rsplit(":", 1)
+                offset = int(off)
+            info, data_off = probe_wav(files, path, offset)
+            if info["sr"] != wav_reader.sr:
+                raise RuntimeError(f"Expect sr={wav_reader.sr} of {path}, get {info['sr']} instead")
+            if info["fmt"] == wavio.WAVE_FORMAT_PCM and info["bits"] == 16:
+                ch = info["channels"]
+                n = info["data_bytes"] // (2 * ch)
+                size = os.fstat(files.get(path)).st_size
+                n = min(n, max(0, (size - data_off) // (2 * ch)))
+                return (Payload(fd=files.get(path), offset=data_off, nbytes=2 * ch * n), ch, n)
+    samps = wav_reader.read(key)
+    return samps[None] if samps.ndim == 1 else samps
+
+
+def mask_source(reader, key, files, num_bins):
+    """Payload of the float32 [T][F] rows when the mask is stored that way (a
+    C-ordered float32 .npy, or a Kaldi FM matrix), else the loaded array."""
+    from .libs.data_handler import NumpyReader, ScriptReader
+    try:
+        if isinstance(reader, NumpyReader):
+            path = reader.index_dict[key]
+            shape, dt, fortran, off = probe_npy(files, path)
+            if dt == np.dtype("<f4") and not fortran and len(shape) == 2 and shape[1] == num_bins:
+                return Payload(fd=files.get(path), offset=off, nbytes=4 * shape[0] * shape[1])
+        elif isinstance(reader, ScriptReader):
+            path, offset = reader.locate(key)
+            hit = probe_kaldi_matrix(files, path, offset)
+            if hit and hit[2] == np.dtype("<f4") and hit[1] == num_bins:
+                return Payload(fd=files.get(path), offset=hit[3], nbytes=4 * hit[0] * hit[1])
+    except (OSError, ValueError, KeyError, SyntaxError):
+        pass
+    return reader[key]

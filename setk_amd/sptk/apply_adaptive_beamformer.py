@@ -61,13 +61,24 @@ _OPTIONS = (
                                     help="If >= 64, using online beamformer instead")),
     (("--online.channels",), dict(default=4, type=int, dest="channels",
                                   help="Number of channels available")),
-    (("--batch-utts",), dict(default=64, type=int,
+    (("--batch-utts",), dict(default=32, type=int,
                              help="[setk_amd] utterances enhanced per GPU batch")),
     (("--device",), dict(default=-1, type=int,
                          help="[setk_amd] GPU ordinal (default: LOCAL_RANK or 0)")),
     (("--device-ingest",), dict(default=True, type=lambda v: str(v).lower() in ("true", "1", "yes"),
                                 help="[setk_amd] upload 16-bit PCM files as stored and "
                                      "convert on the GPU (same samples as the host decode)")),
+    (("--pipeline",), dict(default=True, type=lambda v: str(v).lower() in ("true", "1", "yes"),
+                           help="[setk_amd] streaming host pipeline (pinned staging, read / "
+                                "H2D / compute / D2H / write overlapped); false: one batch "
+                                "at a time")),
+    (("--pipeline-depth",), dict(default=3, type=int,
+                                 help="[setk_amd] batches in flight in the host pipeline")),
+    (("--read-threads",), dict(default=0, type=int,
+                               help="[setk_amd] file reader threads (0: half the cores, <= 32)")),
+    (("--profile",), dict(default="", type=str,
+                          help="[setk_amd] write a JSON run summary (wall clock from the first "
+                               "scp read to the last wav close, stage times, bytes) here")),
 )
 
 
@@ -152,7 +163,22 @@ def run_online(args, shard):
     return num_done, len(reader)
 
 
+def _fast_path_ok(args):
+    """The streaming pipeline drives the fused n_fft = 512 kernels; the other
+    configurations go through BatchEnhancer.enhance one batch at a time."""
+    n_fft = nextpow2(args.frame_len) if args.round_power_of_two else args.frame_len
+    if n_fft != 512 or not args.pipeline:
+        return False
+    if 0.5 < args.vad_proportion < 1:
+        return False  # the VAD threshold is a host-side sort over |X_0|
+    if args.itf_mask and args.beamformer == "mpdr-whiten":
+        return False
+    return True
+
+
 def run_offline(args, shard):
+    import time
+    t_start = time.perf_counter()
     wav_reader = WaveReader(args.wav_scp, sr=args.sr)
     MaskReader = {"numpy": NumpyReader, "kaldi": ScriptReader}[args.fmt]
     tgt = MaskReader(args.tgt_mask)
@@ -170,46 +196,110 @@ def run_offline(args, shard):
                            rank1_appro=args.rank1_appro, post_mask=bool(args.mask),
                            vad_proportion=args.vad_proportion, pcm16=True, device=device)
     keys = shard.assign_by_duration(wav_reader)
+    summary = dict(mode="batch", utts=0, rank=shard.rank, world=shard.world,
+                   assigned_samples=shard.assigned_weight)
     num_done = 0
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
+        if _fast_path_ok(args):
+            num_done, stats = _run_pipeline(args, engine, writer, wav_reader, tgt, itf, keys)
+            summary.update(mode="pipeline", stages=stats)
+        else:
+            num_done = _run_batches(args, engine, writer, wav_reader, tgt, itf, keys)
+    summary["wall_s"] = time.perf_counter() - t_start
+    summary["utts"] = num_done
+    logger.info(f"rank {shard.rank}: {num_done} utterances in {summary['wall_s']:.2f} s "
+                "(first scp read to last wav close)")
+    if args.profile:
+        import json
+        path = args.profile if shard.world == 1 else f"{args.profile}.rank{shard.rank}"
+        with open(path, "w") as f:
+            json.dump(summary, f, indent=1)
+    return num_done, len(wav_reader)
 
-        def flush(pending):
-            done = 0
-            if not pending:
-                return done
-            results = engine.enhance([(s, m, i) for (_, s, m, i) in pending])
-            for (key, _, _, _), (pcm, status) in zip(pending, results):
-                if status != 0:
-                    # the reference's np.linalg.LinAlgError branch (:170-172)
-                    logger.error(f"Raise linalg error: {key}")
-                    continue
-                writer.write_pcm16(key, pcm)
-                done += 1
-            return done
 
-        pending = []
+def _run_pipeline(args, engine, writer, wav_reader, tgt, itf, keys):
+    """Streaming path: setk_amd.pipeline.StreamPipeline."""
+    import threading
+    from setk_amd.pipeline import OpenFiles, StreamPipeline, mask_source, wav_source
+    files = OpenFiles()
+    lock = threading.Lock()
+
+    def announce(key, power):
+        logger.info(f"Processing utterance {key}, " +
+                    f"signal power {10 * np.log10(power + 1e-5):.2f}...")
+
+    def sink(key, pcm, status, error):
+        if error is not None:
+            raise error
+        if status != 0:
+            # the reference's np.linalg.LinAlgError branch (:170-172)
+            logger.error(f"Raise linalg error: {key}")
+            return False
+        dst = writer.file_for(key, ".wav")
+        wavio.write_pcm16(str(dst), pcm, writer.sr)
+        with lock:
+            writer.record(key, dst)
+        return True
+
+    pipe = StreamPipeline(engine, sink, announce=announce, batch_utts=args.batch_utts,
+                          depth=args.pipeline_depth, read_threads=args.read_threads or None)
+    try:
         for key in keys:
             if key not in tgt:
                 continue
-            pcm = wav_reader.read_pcm16(key) if args.device_ingest else None
-            if pcm is not None:
-                # 16-bit PCM file: upload the frames as stored, convert on the device
-                ch0 = pcm[:, 0].astype(np.float32) / np.float32(32768.0)
-                samps = Pcm16Frames(pcm)
-            else:
+            audio = wav_source(wav_reader, key, files) if args.device_ingest else None
+            if audio is None:
                 samps = wav_reader.read(key)
-                if samps.ndim == 1:
-                    samps = samps[None]
-                ch0 = samps[0]
-            power = np.linalg.norm(ch0, 2)**2 / ch0.size
-            logger.info(f"Processing utterance {key}, " +
-                        f"signal power {10 * np.log10(power + 1e-5):.2f}...")
-            pending.append((key, samps, tgt[key], None if itf is None else itf[key]))
-            if len(pending) >= args.batch_utts:
-                num_done += flush(pending)
-                pending = []
-        num_done += flush(pending)
-    return num_done, len(wav_reader)
+                audio = samps[None] if samps.ndim == 1 else samps
+            pipe.submit(key, audio, mask_source(tgt, key, files, engine.num_bins),
+                        None if itf is None else mask_source(itf, key, files, engine.num_bins))
+    finally:
+        out = pipe.close()
+        files.close()
+    return out
+
+
+def _run_batches(args, engine, writer, wav_reader, tgt, itf, keys):
+    """One batch at a time (n_fft != 512, VAD filtering, --pipeline false)."""
+    num_done = 0
+
+    def flush(pending):
+        done = 0
+        if not pending:
+            return done
+        results = engine.enhance([(s, m, i) for (_, s, m, i) in pending])
+        for (key, _, _, _), (pcm, status) in zip(pending, results):
+            if status != 0:
+                # the reference's np.linalg.LinAlgError branch (:170-172)
+                logger.error(f"Raise linalg error: {key}")
+                continue
+            writer.write_pcm16(key, pcm)
+            done += 1
+        return done
+
+    pending = []
+    for key in keys:
+        if key not in tgt:
+            continue
+        pcm = wav_reader.read_pcm16(key) if args.device_ingest else None
+        if pcm is not None:
+            # 16-bit PCM file: upload the frames as stored, convert on the device
+            ch0 = pcm[:, 0].astype(np.float32) / np.float32(32768.0)
+            samps = Pcm16Frames(pcm)
+        else:
+            samps = wav_reader.read(key)
+            if samps.ndim == 1:
+                samps = samps[None]
+            ch0 = samps[0]
+        power = np.linalg.norm(ch0, 2)**2 / ch0.size
+        logger.info(f"Processing utterance {key}, " +
+                    f"signal power {10 * np.log10(power + 1e-5):.2f}...")
+        pending.append((key, samps, tgt[key], None if itf is None else itf[key]))
+        if len(pending) >= args.batch_utts:
+            num_done += flush(pending)
+            pending = []
+    num_done += flush(pending)
+    return num_done
 
 
 def run(args):

@@ -414,3 +414,72 @@ def test_consumers_fixed_beamformer_and_directional_feats(tmp_path):
     ref = o.inverse_stft(o.beamform(w1k[1], obs), norm=float(np.max(np.abs(samps))),
                          transpose=False, **kw2)
     assert wav.shape == ref.shape and rms(wav, ref) / rms(ref) < 1e-3
+
+
+def test_streaming_pipeline_equals_batch_path(tmp_path):
+    """The streaming host pipeline (pinned slabs, payloads read as stored, batched
+    device ingest, several batches in flight) writes the same wavs as the
+    one-batch-at-a-time path, for every kind of scp entry: PCM16 wav + float32
+    npy (read straight into the slab), Kaldi FM archive masks, a transposed (F x T)
+    mask, a float64 mask, a 32-bit float wav, a per-channel glob, ragged lengths,
+    different channel counts, a missing mask (skipped)."""
+    import scipy.io.wavfile
+    from setk_amd.libs import wavio
+    from setk_amd.libs.data_handler import ArchiveWriter
+    td = str(tmp_path)
+    rng = np.random.default_rng(5)
+    lens = [16000, 9000, 23456, 16000, 5000, 12000, 8000, 30000, 7000]
+    chans = [4, 4, 4, 4, 4, 4, 2, 4, 4]
+    refs = {}
+    os.makedirs(f"{td}/m")
+    with open(f"{td}/wav.scp", "w") as ws, open(f"{td}/mask.scp", "w") as ms, \
+            ArchiveWriter(f"{td}/masks.ark", f"{td}/ark.scp") as aw:
+        for i, (n, c) in enumerate(zip(lens, chans)):
+            mix, sp, nz = o.synth_utterance(500 + i, c, n, return_parts=True)
+            mask = (0.1 + 0.8 * o.irm_mask(sp, nz)).astype(np.float32)
+            pcm = wavio.float_to_pcm16(mix.T)
+            key = f"utt{i}"
+            if i == 3:    # IEEE float wav: decoded on the host
+                scipy.io.wavfile.write(f"{td}/{key}.wav", 16000, mix.T.copy())
+                samps = mix
+            elif i == 5:  # per-channel files behind a glob
+                for ch in range(c):
+                    wavio.write_pcm16(f"{td}/{key}.CH{ch}.wav", pcm[:, ch], 16000)
+                samps = pcm.T.astype(np.float32) / 32768
+            else:
+                wavio.write_pcm16(f"{td}/{key}.wav", pcm, 16000)
+                samps = pcm.T.astype(np.float32) / 32768
+            ws.write(f"{key} {td}/{key}.CH*.wav\n" if i == 5 else f"{key} {td}/{key}.wav\n")
+            stored = mask
+            if i == 1:
+                stored = np.ascontiguousarray(mask.T)       # F x T
+            if i == 2:
+                stored = mask.astype(np.float64)
+            if i != 8:                                       # utt8 has no mask: skipped
+                np.save(f"{td}/m/{key}.npy", stored)
+                ms.write(f"{key} {td}/m/{key}.npy\n")
+                aw.write(key, stored.astype(np.float32))
+                refs[key] = o.enhance_utterance(samps.astype(np.float32), mask, kind="mvdr",
+                                                gauge=True)
+    script = os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py")
+
+    def run(dst, fmt, mask_scp, *extra):
+        r = subprocess.run([sys.executable, script, "--mask-format", fmt, "--batch-utts", "3",
+                            *extra, f"{td}/wav.scp", mask_scp, dst],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "Processed 8 utterances out of 9" in r.stderr
+        assert r.stderr.count("Processing utterance") == 8
+        return {k: scipy.io.wavfile.read(os.path.join(dst, k + ".wav"))[1] for k in refs}
+
+    a = run(f"{td}/pipe", "numpy", f"{td}/mask.scp", "--profile", f"{td}/prof.json")
+    b = run(f"{td}/batch", "numpy", f"{td}/mask.scp", "--pipeline", "false")
+    c = run(f"{td}/kaldi", "kaldi", f"{td}/ark.scp")
+    assert not os.path.exists(f"{td}/pipe/utt8.wav")
+    for k, ref in refs.items():
+        assert a[k].dtype == np.int16 and np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], c[k]), k
+        assert pcm16_rel_rms(a[k], ref) < 1e-3, (k, pcm16_rel_rms(a[k], ref))
+    import json
+    prof = json.load(open(f"{td}/prof.json"))
+    assert prof["mode"] == "pipeline" and prof["utts"] == 8 and prof["stages"]["batches"] >= 3
