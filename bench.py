@@ -59,7 +59,7 @@ def parse():
                     help="distinct synthetic utterances generated per rank (others are copies)")
     ap.add_argument("--cpu-sample", type=int, default=96,
                     help="utterances timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--cpu-allcore-per-proc", type=int, default=24,
+    ap.add_argument("--cpu-allcore-per-proc", type=int, default=3,
                     help="utterances per worker process of the all-core CPU leg (0 = skip)")
     ap.add_argument("--sustain-sec", type=float, default=3.0,
                     help="after the timed steps keep stepping for this long so that an "
@@ -311,7 +311,7 @@ def cpu_allcore(args, C, N):
     except Exception:
         pass
     per = args.cpu_allcore_per_proc
-    start_at = time.time() + 25.0   # workers import numpy/scipy and synthesise first
+    start_at = time.time() + 20.0   # workers import numpy/scipy and synthesise first
     procs = [subprocess.Popen([sys.executable, "-c", _ALLCORE_WORKER, ROOT, str(i), str(per), str(C),
                                str(N), args.beamformer, repr(start_at)],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -407,19 +407,32 @@ def cpu_baseline(args, C, N, first_index, wave0):
 def end_to_end(args, C, N):
     """disk -> wav through the drop-in CLI (scripts/sptk/apply_adaptive_beamformer.py),
     PCM16 wav + numpy masks in, PCM16 wav out, on files written to /dev/shm (or
-    TMPDIR).  Two wall clocks: the whole process (python + torch import + plan +
-    pinned pools), and the CLI's own clock from its first scp read to the last wav
-    close (what a long scp amortises to)."""
+    TMPDIR).  Two runs (n and 4n utterances) give the marginal cost per utterance;
+    each run reports two wall clocks: the whole process (python + torch import +
+    plan + pinned pools) and the CLI's own clock from its first scp read to the
+    last wav close."""
     import shutil
     import subprocess
     import tempfile
     from setk_amd import synth
     from setk_amd.libs import wavio
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    n1 = args.e2e_utts
+    n2 = 4 * n1
+    T = 1 + N // 256
+    need = n2 * (2 * C * N + 4 * T * 257 + 2 * N) * 1.1
+    base = None
+    for cand in ("/dev/shm", os.environ.get("TMPDIR", "/tmp")):
+        try:
+            if os.path.isdir(cand) and os.access(cand, os.W_OK) and \
+                    shutil.disk_usage(cand).free > need:
+                base = cand
+                break
+        except OSError:
+            pass
+    if base is None:
+        return {"error": "no scratch directory with %.1f GB free" % (need / 1e9)}
     d = tempfile.mkdtemp(prefix="setk_e2e_", dir=base)
     try:
-        n = args.e2e_utts
-        T = 1 + N // 256
         rng = np.random.default_rng(0)
         os.makedirs(f"{d}/wav")
         os.makedirs(f"{d}/mask")
@@ -428,41 +441,55 @@ def end_to_end(args, C, N):
             mix = synth.synth_utterance(i, C, N)
             wavio.write_pcm16(f"{d}/wav/u{i}.wav", wavio.float_to_pcm16(mix.T), SR)
             np.save(f"{d}/mask/u{i}.npy", rng.uniform(0.05, 0.95, size=(T, 257)).astype(np.float32))
-        with open(f"{d}/wav.scp", "w") as ws, open(f"{d}/mask.scp", "w") as ms:
-            for i in range(n):
-                if i >= nd:
-                    shutil.copyfile(f"{d}/wav/u{i % nd}.wav", f"{d}/wav/u{i}.wav")
-                    shutil.copyfile(f"{d}/mask/u{i % nd}.npy", f"{d}/mask/u{i}.npy")
-                ws.write(f"u{i} {d}/wav/u{i}.wav\n")
-                ms.write(f"u{i} {d}/mask/u{i}.npy\n")
-        cmd = [sys.executable, os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py"),
-               "--mask-format", "numpy", "--beamformer", args.beamformer, "--profile", f"{d}/prof.json",
-               f"{d}/wav.scp", f"{d}/mask.scp", f"{d}/enh"]
-        t0 = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
-        wall = time.perf_counter() - t0
-        if r.returncode != 0:
-            return {"error": r.stderr[-500:]}
-        done = len([f for f in os.listdir(f"{d}/enh") if f.endswith(".wav")])
-        prof = {}
-        try:
-            with open(f"{d}/prof.json") as f:
-                prof = json.load(f)
-        except Exception:
-            pass
-        inner = prof.get("wall_s")
-        out = {"utts": n, "written": done, "audio_s": n * N / SR,
-               "workload": f"{n} x {C}-ch {N / SR:g} s PCM16 wav + float32 numpy masks on "
-                           f"{'/dev/shm' if base else 'TMPDIR'}, {args.beamformer}, PCM16 wav out",
-               "wall_s_process": round(wall, 3),
-               "value_process": round(n * N / SR / wall, 1),
-               "wall_s_first_read_to_last_write": None if inner is None else round(inner, 3),
-               "value_first_read_to_last_write":
-                   None if not inner else round(n * N / SR / inner, 1),
-               "ms_per_utt_first_read_to_last_write":
-                   None if not inner else round(1e3 * inner / n, 3),
+        for i in range(nd, n2):
+            shutil.copyfile(f"{d}/wav/u{i % nd}.wav", f"{d}/wav/u{i}.wav")
+            shutil.copyfile(f"{d}/mask/u{i % nd}.npy", f"{d}/mask/u{i}.npy")
+
+        def run_cli(n):
+            with open(f"{d}/wav.scp", "w") as ws, open(f"{d}/mask.scp", "w") as ms:
+                for i in range(n):
+                    ws.write(f"u{i} {d}/wav/u{i}.wav\n")
+                    ms.write(f"u{i} {d}/mask/u{i}.npy\n")
+            shutil.rmtree(f"{d}/enh", ignore_errors=True)
+            cmd = [sys.executable,
+                   os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py"),
+                   "--mask-format", "numpy", "--beamformer", args.beamformer,
+                   "--profile", f"{d}/prof.json", f"{d}/wav.scp", f"{d}/mask.scp", f"{d}/enh"]
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": r.stderr[-500:]}
+            done = len([f for f in os.listdir(f"{d}/enh") if f.endswith(".wav")])
+            prof = {}
+            try:
+                with open(f"{d}/prof.json") as f:
+                    prof = json.load(f)
+            except Exception:
+                pass
+            inner = prof.get("wall_s")
+            st = prof.get("stages") or {}
+            return {"utts": n, "written": done, "audio_s": n * N / SR,
+                    "wall_s_process": round(wall, 3),
+                    "value_process": round(n * N / SR / wall, 1),
+                    "wall_s_first_read_to_last_write": None if inner is None else round(inner, 3),
+                    "value_first_read_to_last_write":
+                        None if not inner else round(n * N / SR / inner, 1),
+                    "pipeline_wall_s": None if "wall_s" not in st else round(st["wall_s"], 3),
+                    "stages": {k: (round(v, 4) if isinstance(v, float) else v)
+                               for k, v in st.items()}}
+
+        r1, r2 = run_cli(n1), run_cli(n2)
+        out = {"workload": f"{C}-ch {N / SR:g} s PCM16 wav + float32 numpy masks on {base}, "
+                           f"{args.beamformer}, PCM16 wav out, through "
+                           "scripts/sptk/apply_adaptive_beamformer.py",
                "unit": "x real time (audio seconds per wall second)",
-               "stages": prof.get("stages")}
+               "runs": [r1, r2]}
+        if "error" not in r1 and "error" not in r2:
+            dm = (r2["wall_s_process"] - r1["wall_s_process"]) / (n2 - n1)
+            out["marginal_ms_per_utt"] = round(1e3 * dm, 4)
+            out["marginal_value"] = round((N / SR) / dm, 1) if dm > 0 else None
+            out["marginal_GBps_in"] = round((2 * C * N + 4 * T * 257) / dm / 1e9, 2) if dm > 0 else None
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)

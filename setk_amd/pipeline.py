@@ -249,7 +249,8 @@ class StreamPipeline(object):
         self.num_failed = 0
         self.exc = None
         self.stats = dict(batches=0, utts=0, bytes_in=0, bytes_out=0, t_read=0.0, t_h2d_wait=0.0,
-                          t_launch=0.0, t_d2h_wait=0.0, t_write=0.0, t_plan=0.0)
+                          t_launch=0.0, t_d2h_wait=0.0, t_write=0.0, t_plan=0.0, t_slot_wait=0.0,
+                          t_alloc=0.0)
         self.lock = threading.Lock()
         engine._plan()
         self.s_in = torch.cuda.Stream(device=self.dev)
@@ -305,11 +306,20 @@ class StreamPipeline(object):
         return Payload(array=m, nbytes=m.nbytes)
 
     def _get_slot(self, in_cap, f32_cap, out_cap):
+        t0 = time.perf_counter()
+        try:
+            return self._get_slot_inner(in_cap, f32_cap, out_cap)
+        finally:
+            self.stats["t_slot_wait"] += time.perf_counter() - t0
+
+    def _get_slot_inner(self, in_cap, f32_cap, out_cap):
         if self.slots_made < self.depth and self.free_slots.empty():
             self.slots_made += 1
             grow = 1.25  # head room: later batches of ragged lengths reuse the buffers
+            t0 = time.perf_counter()
             slot = _Slot(self.torch, self.dev, max(int(in_cap * grow), self.min_in),
                          int(f32_cap * grow), int(out_cap * grow))
+            self.stats["t_alloc"] += time.perf_counter() - t0
         else:
             while True:
                 try:
