@@ -101,8 +101,10 @@ const char* setk_last_error(setk_handle_t h);
  * n_fft = nextpow2(frame_len) | frame_len and evaluated the window
  * (scipy.signal.get_window(name, frame_len, fftbins=True) or sqrt-hann).
  * `window` = frame_len host floats, NULL = periodic hann.
- * n_fft must be a power of two in [64, 4096]; n_fft == 512 selects the
- * register/LDS radix-16 kernels, other sizes a generic LDS radix-2 kernel. */
+ * n_fft must be even, in [16, 4096]; n_fft == 512 selects the register/LDS
+ * radix-16 kernels, other powers of two (>= 64) a generic LDS radix-2 kernel,
+ * anything else (--round-power-of-two false with e.g. frame_len 400) Bluestein's
+ * chirp-z form on top of the radix-2 kernel. */
 int setk_stft_plan(setk_handle_t h, int frame_len, int frame_hop, int n_fft,
                    int center, const float* window);
 /* frames produced for `num_samples` input samples, < 0 on error */

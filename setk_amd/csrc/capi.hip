@@ -41,6 +41,11 @@ struct setk_context {
     float2* d_tw256 = nullptr;  // [256]
     float2* d_tw512 = nullptr;  // [129]
     float2* d_twn = nullptr;    // [n_fft / 2] exp(-2 pi i k / n_fft), generic kernels
+                                // (Bluestein plans: [M / 2] exp(-2 pi i k / M))
+    // n_fft that is not a power of two: Bluestein tables (modular.hip)
+    int blu_M = 0;
+    float2* d_chirp = nullptr;  // [n_fft]
+    float2* d_bhat = nullptr;   // [M], bit-reversed order
     // device arena (bump allocated per call, blocks reused across calls)
     std::vector<Block> blocks;
     // descriptor cache of the fused path
@@ -268,6 +273,8 @@ int setk_destroy(setk_handle_t h) {
     if (h->d_tw256) (void)hipFree(h->d_tw256);
     if (h->d_tw512) (void)hipFree(h->d_tw512);
     if (h->d_twn) (void)hipFree(h->d_twn);
+    if (h->d_chirp) (void)hipFree(h->d_chirp);
+    if (h->d_bhat) (void)hipFree(h->d_bhat);
     if (h->d_desc) (void)hipFree(h->d_desc);
     for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
     for (auto& e : h->ev_used) (void)hipEventDestroy(e);
@@ -308,8 +315,11 @@ int setk_last_stage_ms(setk_handle_t h, float out[4]) {
 int setk_stft_plan(setk_handle_t h, int frame_len, int frame_hop, int n_fft, int center,
                    const float* window) {
     if (!h) return SETK_ERR_INVALID;
-    if (frame_len <= 0 || frame_hop <= 0 || n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)))
-        return fail(h, SETK_ERR_INVALID, "n_fft must be a power of two in [64, 4096]");
+    const bool pow2 = (n_fft & (n_fft - 1)) == 0;
+    if (frame_len <= 0 || frame_hop <= 0 || n_fft < 16 || n_fft > 4096 || (n_fft & 1) ||
+        (pow2 && n_fft < 64))
+        return fail(h, SETK_ERR_INVALID,
+                    "n_fft must be even, in [16, 4096] (powers of two: [64, 4096])");
     if (frame_len > n_fft) return fail(h, SETK_ERR_INVALID, "frame_len > n_fft");
     HIP_TRY(h, hipSetDevice(h->device));
     std::vector<float> w(n_fft, 0.f), w2(n_fft, 0.f);
@@ -341,10 +351,74 @@ int setk_stft_plan(setk_handle_t h, int frame_len, int frame_hop, int n_fft, int
     HIP_TRY(h, hipMemcpy(h->d_winsq, w2.data(), n_fft * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_tw256, t256.data(), 256 * sizeof(float2), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_tw512, t512.data(), 129 * sizeof(float2), hipMemcpyHostToDevice));
+    h->blu_M = 0;
+    if (h->d_chirp) (void)hipFree(h->d_chirp);
+    if (h->d_bhat) (void)hipFree(h->d_bhat);
+    h->d_chirp = h->d_bhat = nullptr;
+    int tw_n = n_fft;
+    if (!pow2) {
+        // Bluestein: chirp c[k] = exp(-i pi k^2 / n) (k^2 reduced mod 2n in integers),
+        // and the length-M spectrum of the wrapped conj(c), in bit-reversed order
+        int M = 1;
+        while (M < 2 * n_fft - 1) M <<= 1;
+        int logM = 0;
+        while ((1 << logM) < M) ++logM;
+        std::vector<double> cr(n_fft), ci(n_fft);
+        for (int k = 0; k < n_fft; ++k) {
+            const long k2 = ((long)k * k) % (2L * n_fft);
+            const double ang = -kPi * (double)k2 / (double)n_fft;
+            cr[k] = std::cos(ang);
+            ci[k] = std::sin(ang);
+        }
+        std::vector<double> br(M, 0.0), bi(M, 0.0);
+        for (int k = 0; k < n_fft; ++k) {
+            br[k] = cr[k];
+            bi[k] = -ci[k];
+            if (k) {
+                br[M - k] = cr[k];
+                bi[M - k] = -ci[k];
+            }
+        }
+        // iterative radix-2 DIT in double (bit reversal first)
+        for (int i = 0; i < M; ++i) {
+            int r = 0;
+            for (int b = 0; b < logM; ++b) r |= ((i >> b) & 1) << (logM - 1 - b);
+            if (r > i) {
+                std::swap(br[i], br[r]);
+                std::swap(bi[i], bi[r]);
+            }
+        }
+        for (int len = 2; len <= M; len <<= 1) {
+            const double a0 = -2.0 * kPi / (double)len;
+            for (int i0 = 0; i0 < M; i0 += len)
+                for (int k = 0; k < len / 2; ++k) {
+                    const double wr = std::cos(a0 * k), wi = std::sin(a0 * k);
+                    const int a = i0 + k, b = a + len / 2;
+                    const double tr = br[b] * wr - bi[b] * wi, ti = br[b] * wi + bi[b] * wr;
+                    br[b] = br[a] - tr;
+                    bi[b] = bi[a] - ti;
+                    br[a] += tr;
+                    bi[a] += ti;
+                }
+        }
+        std::vector<float2> chirp(n_fft), bhat(M);
+        for (int k = 0; k < n_fft; ++k) chirp[k] = make_float2((float)cr[k], (float)ci[k]);
+        for (int i = 0; i < M; ++i) {
+            int r = 0;
+            for (int b = 0; b < logM; ++b) r |= ((i >> b) & 1) << (logM - 1 - b);
+            bhat[r] = make_float2((float)br[i], (float)bi[i]);
+        }
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_chirp), n_fft * sizeof(float2)));
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_bhat), M * sizeof(float2)));
+        HIP_TRY(h, hipMemcpy(h->d_chirp, chirp.data(), n_fft * sizeof(float2), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_bhat, bhat.data(), M * sizeof(float2), hipMemcpyHostToDevice));
+        h->blu_M = M;
+        tw_n = M;
+    }
     {
-        std::vector<float2> tn(n_fft / 2);
-        for (int k = 0; k < n_fft / 2; ++k) {
-            const double ang = -2.0 * kPi * (double)k / (double)n_fft;
+        std::vector<float2> tn(tw_n / 2);
+        for (int k = 0; k < tw_n / 2; ++k) {
+            const double ang = -2.0 * kPi * (double)k / (double)tw_n;
             tn[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
         }
         if (h->d_twn) (void)hipFree(h->d_twn);
@@ -384,6 +458,8 @@ static int stft_generic(setk_handle_t h, const float* audio, int C, int N, float
     const int T = setk_stft_num_frames(h, N);
     if (T < 0) return T;
     const int F = h->n_fft / 2 + 1;
+    const BluesteinPlan bp = {h->blu_M, reinterpret_cast<const float*>(h->d_chirp),
+                              reinterpret_cast<const float*>(h->d_bhat)};
     arena_reset(h, s);
     const float* d_audio;
     int rc = stage_in(h, audio, (size_t)C * N, s, &d_audio);
@@ -393,7 +469,7 @@ static int stft_generic(setk_handle_t h, const float* audio, int C, int N, float
     if (rc) return rc;
     HIP_TRY(h, launch_stft_generic(d_audio, C, N, T, h->n_fft, h->hop, h->center ? h->n_fft / 2 : 0,
                                    h->d_window, reinterpret_cast<const float*>(h->d_twn),
-                                   static_cast<float*>(ob.dev), s));
+                                   static_cast<float*>(ob.dev), &bp, s));
     rc = copy_back(h, ob, s);
     if (rc) return rc;
     if (ob.host) HIP_TRY(h, hipStreamSynchronize(s));
@@ -403,6 +479,8 @@ static int stft_generic(setk_handle_t h, const float* audio, int C, int N, float
 static int istft_generic(setk_handle_t h, const float* spec, int B, int T, int nsamps,
                          const float* norm, float* wave, hipStream_t s) {
     const int F = h->n_fft / 2 + 1;
+    const BluesteinPlan bp = {h->blu_M, reinterpret_cast<const float*>(h->d_chirp),
+                              reinterpret_cast<const float*>(h->d_bhat)};
     const int L = setk_istft_num_samples(h, T, nsamps);
     int T_eff = T;
     if (nsamps >= 0) {
@@ -436,7 +514,8 @@ static int istft_generic(setk_handle_t h, const float* spec, int B, int T, int n
                                     h->d_window, h->d_winsq,
                                     reinterpret_cast<const float*>(h->d_twn), d_frames,
                                     static_cast<float*>(ob.dev), d_omax,
-                                    norm ? static_cast<const float*>(d_norm) : nullptr, T_eff, s));
+                                    norm ? static_cast<const float*>(d_norm) : nullptr, T_eff, &bp,
+                                    s));
     rc = copy_back(h, ob, s);
     if (rc) return rc;
     if (ob.host) HIP_TRY(h, hipStreamSynchronize(s));
@@ -590,8 +669,8 @@ int setk_covar(setk_handle_t h, const float* spec, const float* mask, int num_ch
                int num_frames, int num_bins, float* covar, void* stream) {
     if (!h || !spec || !mask || !covar || num_frames <= 0 || num_bins <= 0)
         return fail(h, SETK_ERR_INVALID, "bad args");
-    if (num_channels < 1 || num_channels > kMaxChannels)
-        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    if (num_channels < 1 || num_channels > kMaxChannels16)
+        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 16");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
     arena_reset(h, s);
@@ -620,15 +699,18 @@ int setk_covar(setk_handle_t h, const float* spec, const float* mask, int num_ch
 }
 
 static int run_weights(setk_handle_t h, const setk_bf_opts& o, int kind, const float* Rs,
-                       const float* Rn, const float* Ry, int F, int C, float* weight, int* status,
-                       int* ref_out, hipStream_t s) {
+                       const float* Rn, const float* Ry, int F, int C_in, float* weight,
+                       int* status, int* ref_out, hipStream_t s) {
+    // 8 < C <= 16: embedded in 16 x 16 problems, blkdiag(Rs, 0) / blkdiag(Rn, I): same
+    // solution in the first C components, 16 lanes per problem (solve.hip)
+    const int C = C_in > kMaxChannels ? kMaxChannels16 : C_in;
     const int NP = npairs(C);
     const int pitch = pitch_of(F);
     const bool mpdr = (kind == SETK_BF_MPDR || kind == SETK_BF_MPDR_WHITEN);
     const int planes = mpdr ? 6 * NP : (Rn ? 4 * NP : 2 * NP);
     arena_reset(h, s);
     const float *d_Rs, *d_Rn = nullptr, *d_Ry = nullptr;
-    const size_t nmat = (size_t)F * C * C * 2;
+    const size_t nmat = (size_t)F * C_in * C_in * 2;
     int rc = stage_in(h, Rs, nmat, s, &d_Rs);
     if (rc) return rc;
     if (Rn) {
@@ -644,11 +726,11 @@ static int run_weights(setk_handle_t h, const setk_bf_opts& o, int kind, const f
     int* d_bin = static_cast<int*>(arena_alloc(h, (size_t)F * 4));
     if (!d_planes || !d_w || !d_bin) return fail(h, SETK_ERR_NOMEM, "arena");
     HIP_TRY(h, hipMemsetAsync(d_planes, 0, (size_t)planes * pitch * 4, s));
-    HIP_TRY(h, launch_pack_covar(d_Rs, F, C, d_planes, 0, s));
-    if (d_Rn) HIP_TRY(h, launch_pack_covar(d_Rn, F, C, d_planes, 2 * NP, s));
-    if (d_Ry) HIP_TRY(h, launch_pack_covar(d_Ry, F, C, d_planes, 4 * NP, s));
+    HIP_TRY(h, launch_pack_covar(d_Rs, F, C_in, C, 0.f, d_planes, 0, s));
+    if (d_Rn) HIP_TRY(h, launch_pack_covar(d_Rn, F, C_in, C, 1.f, d_planes, 2 * NP, s));
+    if (d_Ry) HIP_TRY(h, launch_pack_covar(d_Ry, F, C_in, C, 1.f, d_planes, 4 * NP, s));
     OutBuf ob;
-    rc = stage_out(h, weight, (size_t)F * C * sizeof(float2), &ob);
+    rc = stage_out(h, weight, (size_t)F * C_in * sizeof(float2), &ob);
     if (rc) return rc;
     SolveArgs a;
     memset(&a, 0, sizeof(a));
@@ -673,7 +755,7 @@ static int run_weights(setk_handle_t h, const setk_bf_opts& o, int kind, const f
     }
     HIP_TRY(h, launch_solve(a, s));
     if (kind == SETK_BF_PMWF && o.pmwf_ref < 0) HIP_TRY(h, launch_pmwf_select(a, d_ref, s));
-    HIP_TRY(h, launch_unpack_weight(d_w, F, C, static_cast<float*>(ob.dev), s));
+    HIP_TRY(h, launch_unpack_weight(d_w, F, C_in, static_cast<float*>(ob.dev), s));
     rc = copy_back(h, ob, s);
     if (rc) return rc;
     if (status) {
@@ -696,8 +778,8 @@ static int run_weights(setk_handle_t h, const setk_bf_opts& o, int kind, const f
 int setk_pevd(setk_handle_t h, const float* Rs, const float* Rn, int num_bins, int num_channels,
               int flags, float* pvec, int* status, void* stream) {
     if (!h || !Rs || !pvec || num_bins <= 0) return fail(h, SETK_ERR_INVALID, "bad args");
-    if (num_channels < 1 || num_channels > kMaxChannels)
-        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    if (num_channels < 1 || num_channels > kMaxChannels16)
+        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 16");
     HIP_TRY(h, hipSetDevice(h->device));
     setk_bf_opts o;
     memset(&o, 0, sizeof(o));
@@ -711,8 +793,8 @@ int setk_weights(setk_handle_t h, const setk_bf_opts* opts, const float* Rs, con
                  int* ref_out, void* stream) {
     if (!h || !opts || !Rs || !weight || num_bins <= 0)
         return fail(h, SETK_ERR_INVALID, "bad args");
-    if (num_channels < 1 || num_channels > kMaxChannels)
-        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    if (num_channels < 1 || num_channels > kMaxChannels16)
+        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 16");
     const int kind = opts->kind;
     if (kind < SETK_BF_MVDR || kind > SETK_BF_MPDR_WHITEN)
         return fail(h, SETK_ERR_INVALID, "unknown beamformer kind");
@@ -800,8 +882,8 @@ int setk_pcm16_to_float_batch(setk_handle_t h, int n_utts, int num_channels,
 int setk_rank1(setk_handle_t h, const float* Rs, const float* Rn, int num_bins,
                int num_channels, float* out, int* status, void* stream) {
     if (!h || !Rs || !out || num_bins <= 0) return fail(h, SETK_ERR_INVALID, "bad args");
-    if (num_channels < 1 || num_channels > kMaxChannels)
-        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    if (num_channels < 1 || num_channels > kMaxChannels16)
+        return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 16");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
     const int F = num_bins, C = num_channels;

@@ -127,20 +127,28 @@ hipError_t launch_covar_spec(int C, const float* spec, const float* mask, int T,
                              float* partials, int t_split, hipStream_t s);
 hipError_t launch_covar_spec_finalize(int C, const float* partials, int nparts, int F,
                                       float* covar_fcc, hipStream_t s);
-hipError_t launch_pack_covar(const float* fcc, int F, int C, float* planes, int plane0,
-                             hipStream_t s);
+hipError_t launch_pack_covar(const float* fcc, int F, int C, int Cp, float pad_diag,
+                             float* planes, int plane0, hipStream_t s);
 hipError_t launch_unpack_weight(const float* wplanes, int F, int C, float* w_fc, hipStream_t s);
 hipError_t launch_unpack_covar(const float* planes, int n_utts, int n_planes, int plane0, int F,
                                int C, float* out, hipStream_t s);
 hipError_t launch_unpack_weight_batch(const float* wplanes, int n_utts, int F, int C, float* w,
                                       hipStream_t s);
+// n_fft that is not a power of two: Bluestein tables (device), M = 0 when unused.
+// `tw` of the generic launchers then holds exp(-2 pi i k / M), k < M / 2.
+struct BluesteinPlan {
+    int M;                 // convolution length, power of two >= 2 n_fft - 1
+    const float* chirp;    // [n_fft] float2 exp(-i pi k^2 / n_fft)
+    const float* bhat_br;  // [M] float2 FFT_M of the wrapped conj(chirp), bit-reversed order
+};
 hipError_t launch_stft_generic(const float* audio, int C, int n_samp, int T, int n_fft, int hop,
                                int pad, const float* window, const float* tw, float* spec,
-                               hipStream_t s);
+                               const BluesteinPlan* bp, hipStream_t s);
 hipError_t launch_istft_generic(const float* spec, int B, int T, int n_fft, int hop, int pad,
                                 int out_len, const float* window, const float* winsq,
                                 const float* tw, float* frames, float* wave, unsigned* outmax,
-                                const float* norm, int T_eff, hipStream_t s);
+                                const float* norm, int T_eff, const BluesteinPlan* bp,
+                                hipStream_t s);
 size_t cgmm_fill_args(void* args_out, int C, const float* spec, int T, int F,
                       const float* init_mask, float* gamma_opt, float* mask_out, void* scratch);
 size_t cgmm_args_bytes();

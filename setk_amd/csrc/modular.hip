@@ -52,10 +52,61 @@ __global__ __launch_bounds__(256) void covar_spec_kernel(const cf* __restrict__ 
     P[(size_t)(2 * NP) * pitch + f] = sum;
 }
 
+// 8 < C <= 16: one workgroup row (blockIdx.z = i) accumulates the pairs (i, j >= i)
+// of the upper triangle; the channels are re-read per row (the fused kernels stop
+// at C = 8, this keeps the operator whole for larger arrays).
+__global__ __launch_bounds__(256) void covar_spec_wide_kernel(const cf* __restrict__ spec,
+                                                              const float* __restrict__ mask, int C,
+                                                              int T, int F, int pitch,
+                                                              int t_per_split,
+                                                              float* __restrict__ partials) {
+    const int NP = npairs(C);
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int split = blockIdx.y, i = blockIdx.z;
+    if (f >= F) return;
+    const int t0 = split * t_per_split;
+    const int t1 = min(T, t0 + t_per_split);
+    cf acc[kMaxChannels16];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxChannels16; ++j) acc[j] = make_float2(0.f, 0.f);
+    for (int t = t0; t < t1; ++t) {
+        const float m = mask[(size_t)t * F + f];
+        const cf xi = spec[((size_t)i * T + t) * F + f];
+        const cf mxi = make_float2(m * xi.x, m * xi.y);
+        sum += m;
+#pragma unroll
+        for (int j = 0; j < kMaxChannels16; ++j) {
+            if (j >= i && j < C) {
+                const cf xj = spec[((size_t)j * T + t) * F + f];
+                const cf p = cmulc(mxi, xj);
+                acc[j].x += p.x;
+                acc[j].y += p.y;
+            }
+        }
+    }
+    float* P = partials + (size_t)split * (2 * NP + 1) * pitch;
+#pragma unroll
+    for (int j = 0; j < kMaxChannels16; ++j) {
+        if (j >= i && j < C) {
+            const int e = pair_index(i, j, C);
+            P[(size_t)e * pitch + f] = acc[j].x;
+            P[(size_t)(NP + e) * pitch + f] = (i == j) ? 0.f : acc[j].y;
+        }
+    }
+    if (i == 0) P[(size_t)(2 * NP) * pitch + f] = sum;
+}
+
 hipError_t launch_covar_spec(int C, const float* spec, const float* mask, int T, int F,
                              float* partials, int t_split, hipStream_t s) {
     const int pitch = ((F + 7) / 8) * 8;
     const int per = (T + t_split - 1) / t_split;
+    if (C > kMaxChannels && C <= kMaxChannels16) {
+        hipLaunchKernelGGL(covar_spec_wide_kernel, dim3((F + 255) / 256, t_split, C), dim3(256), 0,
+                           s, reinterpret_cast<const cf*>(spec), mask, C, T, F, pitch, per,
+                           partials);
+        return hipGetLastError();
+    }
     dim3 grid((F + 255) / 256, t_split);
 #define SETK_CASE(c)                                                                         \
     case c:                                                                                  \
@@ -145,6 +196,104 @@ SETK_DEV void fft_radix2_lds(cf* buf, const cf* tw, int n, int logn) {
         }
     }
     __syncthreads();
+}
+
+// natural order in -> bit-reversed order out (decimation in frequency)
+template <int DIR>
+SETK_DEV void fft_radix2_dif_lds(cf* buf, const cf* tw, int n, int logn) {
+    for (int s = logn; s >= 1; --s) {
+        const int half = 1 << (s - 1);
+        const int stride = n >> s;
+        __syncthreads();
+        for (int b = threadIdx.x; b < n / 2; b += blockDim.x) {
+            const int grp = b / half, pos = b - grp * half;
+            const int i0 = grp * 2 * half + pos, i1 = i0 + half;
+            cf w = tw[pos * stride];
+            if (DIR > 0) w.y = -w.y;
+            const cf u = buf[i0], v = buf[i1];
+            buf[i0] = cadd(u, v);
+            buf[i1] = cmul(csub(u, v), w);
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// Transform sizes that are not a power of two (--round-power-of-two false with
+// e.g. frame_len 400; libs/utils.py:115 hands n_fft = frame_len to librosa):
+// Bluestein's chirp-z form of the length-n DFT on top of the radix-2 routines,
+//   X[k] = c[k] * sum_j (x[j] c[j]) conj(c[k - j]),  c[k] = exp(-i pi k^2 / n),
+// i.e. one circular convolution of length M = 2^m >= 2n - 1: forward DIF ->
+// multiply by the (host-computed, bit-reversed) spectrum of conj(c) -> inverse
+// DIT.  On entry buf[0..n) holds x[j] c[j] (natural order), buf[n..M) zeros; on
+// return buf[k], k < n, holds M * sum_j ... (the caller scales by c[k] / M).
+// ---------------------------------------------------------------------------
+SETK_DEV void bluestein_core(cf* buf, const cf* tw, const cf* __restrict__ bhat_br, int M,
+                             int logM) {
+    fft_radix2_dif_lds<-1>(buf, tw, M, logM);
+    for (int i = threadIdx.x; i < M; i += blockDim.x) buf[i] = cmul(buf[i], bhat_br[i]);
+    fft_radix2_lds<+1>(buf, tw, M, logM);
+}
+
+__global__ __launch_bounds__(256) void stft_bluestein_kernel(
+    const float* __restrict__ audio, int n_samp, int T, int n_fft, int M, int logM, int hop, int pad,
+    const float* __restrict__ window, const cf* __restrict__ twg, const cf* __restrict__ chirp,
+    const cf* __restrict__ bhat_br, cf* __restrict__ spec) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    cf* buf = reinterpret_cast<cf*>(gsm);
+    cf* tw = buf + M;
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int F = n_fft / 2 + 1;
+    const float* x = audio + (size_t)c * n_samp;
+    const int s0 = t * hop - pad;
+    for (int i = threadIdx.x; i < M / 2; i += blockDim.x) tw[i] = twg[i];
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        cf v = make_float2(0.f, 0.f);
+        if (i < n_fft) {
+            const float xv = 2.f * window[i] * x[reflect_idx_g(s0 + i, n_samp)];
+            v = make_float2(xv * chirp[i].x, xv * chirp[i].y);
+        }
+        buf[i] = v;
+    }
+    bluestein_core(buf, tw, bhat_br, M, logM);
+    cf* out = spec + ((size_t)c * T + t) * F;
+    const float sc = 1.f / (float)M;
+    for (int k = threadIdx.x; k < F; k += blockDim.x) out[k] = cscale(cmul(buf[k], chirp[k]), sc);
+}
+
+// irfft through the same forward core: x = conj(DFT(conj(Y))) / n
+__global__ __launch_bounds__(256) void istft_frames_bluestein_kernel(
+    const cf* __restrict__ spec, int T, int n_fft, int M, int logM,
+    const float* __restrict__ window, const cf* __restrict__ twg, const cf* __restrict__ chirp,
+    const cf* __restrict__ bhat_br, float* __restrict__ frames) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    cf* buf = reinterpret_cast<cf*>(gsm);
+    cf* tw = buf + M;
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int F = n_fft / 2 + 1;
+    const cf* in = spec + ((size_t)b * T + t) * F;
+    for (int i = threadIdx.x; i < M / 2; i += blockDim.x) tw[i] = twg[i];
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        cf v = make_float2(0.f, 0.f);
+        if (i < n_fft) {
+            cf y;
+            if (i < F) {
+                y = in[i];
+                if (i == 0 || i == n_fft / 2) y.y = 0.f;  // numpy irfft drops these
+            } else {
+                const cf m = in[n_fft - i];
+                y = make_float2(m.x, -m.y);
+            }
+            v = cmul(make_float2(y.x, -y.y), chirp[i]);  // conj(Y) c
+        }
+        buf[i] = v;
+    }
+    bluestein_core(buf, tw, bhat_br, M, logM);
+    float* out = frames + ((size_t)b * T + t) * n_fft;
+    // Re(conj(z)) = Re(z); window table is 0.5-scaled
+    const float sc = 2.f / ((float)M * (float)n_fft);
+    for (int i = threadIdx.x; i < n_fft; i += blockDim.x)
+        out[i] = cmul(buf[i], chirp[i]).x * sc * window[i];
 }
 
 __global__ __launch_bounds__(256) void stft_generic_kernel(const float* __restrict__ audio,
@@ -244,9 +393,26 @@ __global__ void istft_scale_kernel(float* __restrict__ wave, int out_len,
         wave[(size_t)b * out_len + o] *= sc;
 }
 
+static hipError_t allow_lds(const void* fn, size_t lds) {
+    if (lds <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 hipError_t launch_stft_generic(const float* audio, int C, int n_samp, int T, int n_fft, int hop,
                                int pad, const float* window, const float* tw, float* spec,
-                               hipStream_t s) {
+                               const BluesteinPlan* bp, hipStream_t s) {
+    if (bp && bp->M) {
+        int logM = 0;
+        while ((1 << logM) < bp->M) ++logM;
+        const size_t lds = (size_t)bp->M * sizeof(cf) + (size_t)(bp->M / 2) * sizeof(cf);
+        hipError_t e = allow_lds(reinterpret_cast<const void*>(stft_bluestein_kernel), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(stft_bluestein_kernel, dim3(T, C), dim3(256), lds, s, audio, n_samp, T,
+                           n_fft, bp->M, logM, hop, pad, window, reinterpret_cast<const cf*>(tw),
+                           reinterpret_cast<const cf*>(bp->chirp),
+                           reinterpret_cast<const cf*>(bp->bhat_br), reinterpret_cast<cf*>(spec));
+        return hipGetLastError();
+    }
     int logn = 0;
     while ((1 << logn) < n_fft) ++logn;
     const size_t lds = (size_t)n_fft * sizeof(cf) + (size_t)(n_fft / 2) * sizeof(cf);
@@ -259,13 +425,26 @@ hipError_t launch_stft_generic(const float* audio, int C, int n_samp, int T, int
 hipError_t launch_istft_generic(const float* spec, int B, int T, int n_fft, int hop, int pad,
                                 int out_len, const float* window, const float* winsq,
                                 const float* tw, float* frames, float* wave, unsigned* outmax,
-                                const float* norm, int T_eff, hipStream_t s) {
-    int logn = 0;
-    while ((1 << logn) < n_fft) ++logn;
-    const size_t lds = (size_t)n_fft * sizeof(cf) + (size_t)(n_fft / 2) * sizeof(cf);
-    hipLaunchKernelGGL(istft_frames_kernel, dim3(T_eff, B), dim3(256), lds, s,
-                       reinterpret_cast<const cf*>(spec), T, n_fft, logn, window,
-                       reinterpret_cast<const cf*>(tw), frames);
+                                const float* norm, int T_eff, const BluesteinPlan* bp,
+                                hipStream_t s) {
+    if (bp && bp->M) {
+        int logM = 0;
+        while ((1 << logM) < bp->M) ++logM;
+        const size_t lds = (size_t)bp->M * sizeof(cf) + (size_t)(bp->M / 2) * sizeof(cf);
+        hipError_t e = allow_lds(reinterpret_cast<const void*>(istft_frames_bluestein_kernel), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(istft_frames_bluestein_kernel, dim3(T_eff, B), dim3(256), lds, s,
+                           reinterpret_cast<const cf*>(spec), T, n_fft, bp->M, logM, window,
+                           reinterpret_cast<const cf*>(tw), reinterpret_cast<const cf*>(bp->chirp),
+                           reinterpret_cast<const cf*>(bp->bhat_br), frames);
+    } else {
+        int logn = 0;
+        while ((1 << logn) < n_fft) ++logn;
+        const size_t lds = (size_t)n_fft * sizeof(cf) + (size_t)(n_fft / 2) * sizeof(cf);
+        hipLaunchKernelGGL(istft_frames_kernel, dim3(T_eff, B), dim3(256), lds, s,
+                           reinterpret_cast<const cf*>(spec), T, n_fft, logn, window,
+                           reinterpret_cast<const cf*>(tw), frames);
+    }
     int bx = (out_len + 256 * 4 - 1) / (256 * 4);
     bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
     hipLaunchKernelGGL(istft_ola_kernel, dim3(bx, B), dim3(256), 0, s, frames, T, T_eff, n_fft, hop, pad,

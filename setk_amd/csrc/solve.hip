@@ -41,7 +41,10 @@ SD cd zdiv(cd a, cd b) {
     return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
 }
 SD double zabs2(cd a) { return a.x * a.x + a.y * a.y; }
-SD cd zshfl(cd v, int src) { return make_double2(__shfl(v.x, src, 8), __shfl(v.y, src, 8)); }
+// lanes per problem: 8 for C <= 8, 16 for 8 < C <= 16
+template <int C> struct Grp { static constexpr int W = (C > 8) ? 16 : 8; };
+template <int W>
+SD cd zshfl(cd v, int src) { return make_double2(__shfl(v.x, src, W), __shfl(v.y, src, W)); }
 
 constexpr int kKindPevd = 100;  // internal: plain solve_pevd(Rs[, Rn])
 constexpr double kEpsF32 = 1.1920928955078125e-07;
@@ -90,6 +93,7 @@ SD bool jacobi_round(cd (&g)[C], int j) {
 // 0.174, 1e-14 0.170).
 template <int C>
 SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
+    constexpr int W = Grp<C>::W;
     bool done = false;
     for (int sweep = 0; sweep < 40 && !done; ++sweep) {
         bool rot = false;
@@ -100,19 +104,29 @@ SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
         rot |= jacobi_round<C, 5>(g, j);
         rot |= jacobi_round<C, 6>(g, j);
         rot |= jacobi_round<C, 7>(g, j);
+        if constexpr (W == 16) {
+            rot |= jacobi_round<C, 8>(g, j);
+            rot |= jacobi_round<C, 9>(g, j);
+            rot |= jacobi_round<C, 10>(g, j);
+            rot |= jacobi_round<C, 11>(g, j);
+            rot |= jacobi_round<C, 12>(g, j);
+            rot |= jacobi_round<C, 13>(g, j);
+            rot |= jacobi_round<C, 14>(g, j);
+            rot |= jacobi_round<C, 15>(g, j);
+        }
         done = !__any(rot);
     }
     if (!done) noconv = 1;
     double m = 0.0;
 #pragma unroll
     for (int i = 0; i < C; ++i) m += zabs2(g[i]);
-    // argmax over the 8 lanes of the group (lowest lane wins ties)
+    // argmax over the lanes of the group (lowest lane wins ties)
     double best = m;
     int bj = j;
 #pragma unroll
-    for (int s = 1; s < 8; s <<= 1) {
-        const double ob = __shfl_xor(best, s, 8);
-        const int oj = __shfl_xor(bj, s, 8);
+    for (int s = 1; s < W; s <<= 1) {
+        const double ob = __shfl_xor(best, s, W);
+        const int oj = __shfl_xor(bj, s, W);
         if (ob > best || (ob == best && oj < bj)) {
             best = ob;
             bj = oj;
@@ -122,7 +136,7 @@ SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
     const double inv = (lam > 0.0) ? 1.0 / lam : 0.0;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-        out[i] = zscale(zshfl(g[i], bj), inv);
+        out[i] = zscale(zshfl<W>(g[i], bj), inv);
         if (!(lam > 0.0)) out[i] = make_double2((i == 0) ? 1.0 : 0.0, 0.0);
     }
 }
@@ -155,7 +169,7 @@ SD int chol_lds(const cd (&col)[C], cd* L, double* piv, int j) {
         if (i == j) diag = col[i].x;
     double scale = diag;
 #pragma unroll
-    for (int s = 1; s < 8; s <<= 1) scale = fmax(scale, __shfl_xor(scale, s, 8));
+    for (int s = 1; s < Grp<C>::W; s <<= 1) scale = fmax(scale, __shfl_xor(scale, s, Grp<C>::W));
     int bad = !(scale > 0.0);
     const double floor_piv = kEpsF32 * scale;
 #pragma unroll
@@ -204,9 +218,10 @@ SD void bwd_solve(const cd* L, cd (&y)[C]) {
     }
 }
 
+template <int W>
 SD double group_sum(double v) {
 #pragma unroll
-    for (int s = 1; s < 8; s <<= 1) v += __shfl_xor(v, s, 8);
+    for (int s = 1; s < W; s <<= 1) v += __shfl_xor(v, s, W);
     return v;
 }
 
@@ -253,7 +268,7 @@ SD void herm_matvec(const cd (&col)[C], const cd (&x)[C], cd (&y)[C]) {
 #pragma unroll
     for (int m = 0; m < C; ++m) mine = zadd(mine, zcmul(col[m], x[m]));
 #pragma unroll
-    for (int i = 0; i < C; ++i) y[i] = zshfl(mine, i);
+    for (int i = 0; i < C; ++i) y[i] = zshfl<Grp<C>::W>(mine, i);
 }
 
 // KIND is a template parameter: every beamformer gets its own register
@@ -267,28 +282,30 @@ SD void herm_matvec(const cd (&col)[C], const cd (&x)[C], cd (&y)[C]) {
 #define SETK_SOLVE_WAVES 2
 #endif
 template <int C, int KIND>
-__global__ __launch_bounds__(64, SETK_SOLVE_WAVES) void solve_kernel(SolveArgs a, int pitch, int lds_mats) {
+__global__ __launch_bounds__(64, (C > 8) ? 1 : SETK_SOLVE_WAVES) void solve_kernel(SolveArgs a, int pitch, int lds_mats) {
     constexpr int NP = npairs(C);
-    // dynamic LDS, 8 problems per workgroup: [L | Wk | Rs | Rn] (lds_mats of them).
+    constexpr int W = Grp<C>::W;   // lanes per problem
+    constexpr int PW = 64 / W;     // problems per wavefront (= workgroup)
+    // dynamic LDS, PW problems per workgroup: [L | Wk | Rs | Rn] (lds_mats of them).
     // L: Cholesky factor (all kinds but plain pevd); Wk: transposes of the reduced
     // pencil; Rs, Rn: full matrices, only for the PMWF reference-channel search.
     extern __shared__ __attribute__((aligned(16))) char solve_smem[];
     cd* mats = reinterpret_cast<cd*>(solve_smem);
-    double* sPiv = reinterpret_cast<double*>(mats + (size_t)lds_mats * 8 * C * C);
+    double* sPiv = reinterpret_cast<double*>(mats + (size_t)lds_mats * PW * C * C);
 
     const int tid = threadIdx.x;
-    const int j = tid & 7, q = tid >> 3;
+    const int j = tid & (W - 1), q = tid / W;
     const int F = a.num_bins;
     const long n_prob = (long)a.n_utts * F;
-    long prob = (long)blockIdx.x * 8 + q;
+    long prob = (long)blockIdx.x * PW + q;
     const bool live = prob < n_prob;
     if (!live) prob = n_prob - 1;  // keep the lanes in step; no stores
     const int u = (int)(prob / F), f = (int)(prob % F);
 
-    cd* L = mats + ((size_t)0 * 8 + q) * C * C;
-    cd* Wk = mats + ((size_t)(lds_mats > 1 ? 1 : 0) * 8 + q) * C * C;
-    cd* Rsf = mats + ((size_t)(lds_mats > 2 ? 2 : 0) * 8 + q) * C * C;
-    cd* Rnf = mats + ((size_t)(lds_mats > 3 ? 3 : 0) * 8 + q) * C * C;
+    cd* L = mats + ((size_t)0 * PW + q) * C * C;
+    cd* Wk = mats + ((size_t)(lds_mats > 1 ? 1 : 0) * PW + q) * C * C;
+    cd* Rsf = mats + ((size_t)(lds_mats > 2 ? 2 : 0) * PW + q) * C * C;
+    cd* Rnf = mats + ((size_t)(lds_mats > 3 ? 3 : 0) * PW + q) * C * C;
     double* piv = &sPiv[q];
 
     constexpr int kind = KIND;
@@ -419,7 +436,7 @@ __global__ __launch_bounds__(64, SETK_SOLVE_WAVES) void solve_kernel(SolveArgs a
                 if (i == j) dj = rs[i].x;
                 pn += zabs2(pv[i]);
             }
-            const double tr = group_sum(dj);
+            const double tr = group_sum<Grp<C>::W>(dj);
             const double sc = tr / fmax(pn, kEpsF32);
             cd pj = make_double2(0.0, 0.0);
 #pragma unroll
@@ -438,12 +455,12 @@ __global__ __launch_bounds__(64, SETK_SOLVE_WAVES) void solve_kernel(SolveArgs a
 #pragma unroll
         for (int i = 0; i < C; ++i)
             if (i == j) diag = x[i];
-        cd den = make_double2(group_sum(diag.x) + (double)a.pmwf_beta, group_sum(diag.y));
+        cd den = make_double2(group_sum<Grp<C>::W>(diag.x) + (double)a.pmwf_beta, group_sum<Grp<C>::W>(diag.y));
 #pragma unroll
         for (int i = 0; i < C; ++i) x[i] = zdiv(x[i], den);
         if (a.pmwf_ref >= 0) {
 #pragma unroll
-            for (int i = 0; i < C; ++i) w[i] = zshfl(x[i], a.pmwf_ref);
+            for (int i = 0; i < C; ++i) w[i] = zshfl<Grp<C>::W>(x[i], a.pmwf_ref);
         } else {
             // estimated SNR of every candidate column (libs/beamformer.py:620-630):
             // needs the full (possibly rank-1 replaced) Rs and Rn in every lane
@@ -493,8 +510,8 @@ __global__ __launch_bounds__(64, SETK_SOLVE_WAVES) void solve_kernel(SolveArgs a
 #pragma unroll
         for (int i = 0; i < C; ++i)
             if (i == j) wj = w[i];
-        const double nom = group_sum(zabs2(uj));
-        const double den = group_sum(zcmul(wj, uj).x);
+        const double nom = group_sum<Grp<C>::W>(zabs2(uj));
+        const double den = group_sum<Grp<C>::W>(zcmul(wj, uj).x);
         const double filt = sqrt(nom) / fmax(den, kEpsF32);
 #pragma unroll
         for (int i = 0; i < C; ++i) w[i] = zscale(w[i], filt);
@@ -526,7 +543,8 @@ __global__ __launch_bounds__(64, SETK_SOLVE_WAVES) void solve_kernel(SolveArgs a
 
 hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
     const long n_prob = (long)a.n_utts * a.num_bins;
-    const int blocks = (int)((n_prob + 7) / 8);
+    const int pw = a.num_channels > 8 ? 4 : 8;  // problems per wavefront
+    const int blocks = (int)((n_prob + pw - 1) / pw);
     const int pitch = (a.num_bins == kBins) ? kBinsPad : ((a.num_bins + 7) / 8) * 8;
     // L only: MVDR, MPDR; + Wk: the reduced-pencil kinds; + Rs, Rn: PMWF SNR search
     int lds_mats = 2;
@@ -534,7 +552,7 @@ hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
     if (a.kind == SETK_BF_PMWF) lds_mats = 4;
 #define SETK_LAUNCH(c, k)                                                              \
     hipLaunchKernelGGL((solve_kernel<c, k>), dim3(blocks), dim3(64),                   \
-                       (size_t)lds_mats * 8 * c * c * sizeof(cd) + 64, s, a, pitch, lds_mats)
+                       (size_t)lds_mats * pw * c * c * sizeof(cd) + 64, s, a, pitch, lds_mats)
 #define SETK_CASE(c)                                                                   \
     case c:                                                                            \
         switch (a.kind) {                                                              \
@@ -556,6 +574,7 @@ hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
         SETK_CASE(6)
         SETK_CASE(7)
         SETK_CASE(8)
+        SETK_CASE(16)  // 8 < C <= 16 arrive padded to 16 (capi.hip run_weights)
         default:
             return hipErrorInvalidValue;
     }
@@ -600,7 +619,7 @@ __global__ __launch_bounds__(256) void pmwf_select_kernel(SolveArgs a, int pitch
     if (f >= F) return;
     const size_t prob = (size_t)u * F + f;
     const float2* wm = reinterpret_cast<const float2*>(a.wmat) + (prob * C + ref) * C;
-    double2 w[kMaxChannels];
+    double2 w[kMaxChannels16];
     for (int i = 0; i < C; ++i) w[i] = make_double2(wm[i].x, wm[i].y);
     if (a.flags & SETK_FLAG_BAN) {
         const float* base = a.covar + (size_t)u * a.planes * pitch + f;
@@ -642,26 +661,33 @@ hipError_t launch_pmwf_select(const SolveArgs& a, int* ref_out, hipStream_t s) {
 // layout helpers for the modular API
 // ---------------------------------------------------------------------------
 // covar[F][C][C] complex64 -> packed planes [2*NP][pitch] starting at plane0
-__global__ void pack_covar_kernel(const float2* fcc, int F, int C, int pitch, float* planes,
-                                  int plane0) {
+// Cp >= C: the matrix is embedded in a Cp x Cp one, blkdiag(M, pad_diag * I): with
+// pad_diag = 1 for the matrices that get factored (Rn, Ry) and 0 for Rs the padded
+// problem has the original's solution in its first C components and zeros after.
+__global__ void pack_covar_kernel(const float2* fcc, int F, int C, int Cp, float pad_diag,
+                                  int pitch, float* planes, int plane0) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= pitch) return;
-    const int NP = npairs(C);
-    for (int i = 0; i < C; ++i)
-        for (int j = i; j < C; ++j) {
-            const int e = pair_index(i, j, C);
+    const int NP = npairs(Cp);
+    for (int i = 0; i < Cp; ++i)
+        for (int j = i; j < Cp; ++j) {
+            const int e = pair_index(i, j, Cp);
             float2 v = make_float2(0.f, 0.f);
-            if (f < F) v = fcc[((size_t)f * C + i) * C + j];
+            if (f < F) {
+                if (j < C) v = fcc[((size_t)f * C + i) * C + j];
+                else if (i == j) v = make_float2(pad_diag, 0.f);
+            }
             planes[(size_t)(plane0 + e) * pitch + f] = v.x;
             planes[(size_t)(plane0 + NP + e) * pitch + f] = v.y;
         }
 }
 
-hipError_t launch_pack_covar(const float* fcc, int F, int C, float* planes, int plane0,
-                             hipStream_t s) {
+hipError_t launch_pack_covar(const float* fcc, int F, int C, int Cp, float pad_diag,
+                             float* planes, int plane0, hipStream_t s) {
     const int pitch = (F == kBins) ? kBinsPad : ((F + 7) / 8) * 8;
     hipLaunchKernelGGL(pack_covar_kernel, dim3((pitch + 255) / 256), dim3(256), 0, s,
-                       reinterpret_cast<const float2*>(fcc), F, C, pitch, planes, plane0);
+                       reinterpret_cast<const float2*>(fcc), F, C, Cp, pad_diag, pitch, planes,
+                       plane0);
     return hipGetLastError();
 }
 
@@ -774,7 +800,7 @@ __global__ void rank1_kernel(const float2* __restrict__ pv, const float2* __rest
                              float2* __restrict__ out) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
-    double px[kMaxChannels], py[kMaxChannels];
+    double px[kMaxChannels16], py[kMaxChannels16];
     for (int i = 0; i < C; ++i) {
         if (Rn) {
             double ux = 0.0, uy = 0.0;

@@ -161,9 +161,10 @@ class BatchEnhancer(object):
         return results
 
     def _run_unfused(self, utts, batch, C, has_itf, results):
-        """n_fft != 512: the same stages through the stand-alone operators
-        (setk_stft -> setk_covar x2 -> setk_weights -> setk_beamform -> setk_istft),
-        everything resident on the device, one utterance at a time."""
+        """n_fft != 512 or more than 8 channels: the same stages through the
+        stand-alone operators (setk_stft -> setk_covar x2 -> setk_weights ->
+        setk_beamform -> setk_istft), everything resident on the device, one
+        utterance at a time."""
         torch, ctx, dev, F = self.torch, self.ctx, self.dev, self.num_bins
         mpdr = self.opts_kw["kind"] in (_ffi.BF_MPDR, _ffi.BF_MPDR_WHITEN)
         for i in batch:
@@ -220,7 +221,8 @@ class BatchEnhancer(object):
             results[i] = (out.cpu().numpy(), 0)
 
     def _run(self, utts, batch, C, has_itf, results):
-        if self.stft["n_fft"] != 512:
+        if self.stft["n_fft"] != 512 or C > 8:
+            # the fused kernels are specialised for n_fft = 512 and C <= 8
             return self._run_unfused(utts, batch, C, has_itf, results)
         kind = self.opts_kw["kind"]
         if has_itf and kind == _ffi.BF_MPDR_WHITEN:
@@ -347,7 +349,7 @@ class FixedBatchBeamformer(object):
 
     def _run(self, utts, batch, C, results):
         torch, ctx, dev = self.torch, self.ctx, self.dev
-        if self.n_fft != 512:
+        if self.n_fft != 512 or C > 8:
             return self._run_unfused(utts, batch, C, results)
         if self._d_weights is None:
             self._d_weights = torch.from_numpy(self.weights).to(dev)

@@ -86,9 +86,6 @@ def device_stft(samps, frame_len, frame_hop, round_power_of_two, center, window,
     """samps: C x N float32 -> C x T x F complex64 (time major, device layout)."""
     ctx = ctx or _ffi.default_context()
     n_fft = nextpow2(frame_len) if round_power_of_two else frame_len
-    if n_fft & (n_fft - 1):
-        raise _ffi.SetkUnsupported(
-            f"n_fft={n_fft} is not a power of two (use --round-power-of-two true)")
     _plan(ctx, frame_len, frame_hop, n_fft, center, window)
     samps = np.ascontiguousarray(samps, dtype=np.float32)
     C, N = samps.shape

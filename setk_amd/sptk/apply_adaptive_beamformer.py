@@ -168,7 +168,7 @@ def _fast_path_ok(args):
     configurations go through BatchEnhancer.enhance one batch at a time."""
     n_fft = nextpow2(args.frame_len) if args.round_power_of_two else args.frame_len
     if n_fft != 512 or not args.pipeline:
-        return False
+        return False  # (more than 8 channels: the pipeline hands those batches to the engine)
     if 0.5 < args.vad_proportion < 1:
         return False  # the VAD threshold is a host-side sort over |X_0|
     if args.itf_mask and args.beamformer == "mpdr-whiten":
@@ -243,6 +243,7 @@ def _run_pipeline(args, engine, writer, wav_reader, tgt, itf, keys):
 
     pipe = StreamPipeline(engine, sink, announce=announce, batch_utts=args.batch_utts,
                           depth=args.pipeline_depth, read_threads=args.read_threads or None)
+    wide = []  # more than 8 channels: stand-alone operators, after the pipeline drained
     try:
         for key in keys:
             if key not in tgt:
@@ -251,12 +252,17 @@ def _run_pipeline(args, engine, writer, wav_reader, tgt, itf, keys):
             if audio is None:
                 samps = wav_reader.read(key)
                 audio = samps[None] if samps.ndim == 1 else samps
+            if (audio[1] if isinstance(audio, tuple) else audio.shape[0]) > 8:
+                wide.append(key)
+                continue
             pipe.submit(key, audio, mask_source(tgt, key, files, engine.num_bins),
                         None if itf is None else mask_source(itf, key, files, engine.num_bins))
     finally:
-        out = pipe.close()
+        num_done, stats = pipe.close()
         files.close()
-    return out
+    if wide:
+        num_done += _run_batches(args, engine, writer, wav_reader, tgt, itf, wide)
+    return num_done, stats
 
 
 def _run_batches(args, engine, writer, wav_reader, tgt, itf, keys):

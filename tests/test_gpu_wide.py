@@ -1,0 +1,148 @@
+"""
+More than 8 channels (the reference has no channel cap: libs/beamformer.py:87-103,
+31-63) and transform sizes that are not a power of two
+(--round-power-of-two false, libs/utils.py:115): stand-alone operators and the
+unfused engine path against the oracle.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pcm16_rel_rms, rel_rms
+from oracle import np_oracle as o
+
+pytestmark = pytest.mark.gpu
+STFT_KW = dict(frame_len=512, frame_hop=256, window="hann", center=True)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from setk_amd import _ffi
+    c = _ffi.Context(0)
+    c.stft_plan(512, 256, 512, True)
+    yield c
+    c.close()
+
+
+def tmajor(obs):
+    return np.ascontiguousarray(np.transpose(obs, (0, 2, 1)))
+
+
+@pytest.mark.parametrize("C", [9, 12, 16])
+def test_wide_covar_pevd_weights(ctx, C):
+    from setk_amd import _ffi
+    mix, sp, nz = o.synth_utterance(40 + C, C, 12000, return_parts=True)
+    mask = (0.05 + 0.9 * o.irm_mask(sp, nz)).astype(np.float32)
+    obs = o.multichannel_stft(mix, transpose=False, **STFT_KW)
+    _, F, T = obs.shape
+    spec = tmajor(obs)
+    Rs_ref = np.ascontiguousarray(o.compute_covar(obs, mask).astype(np.complex64))
+    Rn_ref = np.ascontiguousarray(o.compute_covar(obs, 1 - mask).astype(np.complex64))
+    Ry_ref = np.ascontiguousarray(o.compute_covar(obs, np.ones_like(mask)).astype(np.complex64))
+    Rs = np.empty((F, C, C), np.complex64)
+    ctx.covar(spec, np.ascontiguousarray(mask), C, T, F, Rs)
+    assert rel_rms(Rs, Rs_ref) < 1e-5
+    assert np.max(np.abs(Rs - np.conj(np.transpose(Rs, (0, 2, 1))))) == 0
+    st = np.zeros(F, np.int32)
+    pv = np.empty((F, C), np.complex64)
+    ctx.pevd(Rs_ref, None, F, C, 0, pv, st)
+    assert not st.any()
+    assert rel_rms(pv, o.fix_gauge_evd(o.solve_pevd(Rs_ref))) < 1e-4
+    ctx.pevd(Rs_ref, Rn_ref, F, C, 0, pv, st)
+    assert not st.any()
+    ref = o.fix_gauge_gev(o.solve_pevd(Rs_ref, Rn_ref), Rn_ref.astype(np.complex128))
+    assert rel_rms(pv, ref) < 1e-4
+    kinds = [
+        ("mvdr", _ffi.BF_MVDR, {}, lambda: o.mvdr_weight(Rs_ref, Rn_ref, gauge=True)),
+        ("gevd", _ffi.BF_GEVD, {}, lambda: o.gevd_weight(Rs_ref, Rn_ref, gauge=True)),
+        ("pmwf0", _ffi.BF_PMWF, dict(pmwf_ref=-1), lambda: o.pmwf_weight(Rs_ref, Rn_ref, beta=0)),
+        ("pmwf1_ref10", _ffi.BF_PMWF, dict(pmwf_beta=1.0, pmwf_ref=C - 2),
+         lambda: o.pmwf_weight(Rs_ref, Rn_ref, beta=1, ref_channel=C - 2)),
+        ("pmwf0_gev", _ffi.BF_PMWF, dict(pmwf_ref=-1, rank1=_ffi.RANK1_GEV),
+         lambda: o.pmwf_weight(Rs_ref, Rn_ref, rank1_appro="gev")),
+        ("mpdr", _ffi.BF_MPDR, {}, lambda: o.mpdr_weight(Rs_ref, Ry_ref, gauge=True)),
+        ("mpdr_whiten", _ffi.BF_MPDR_WHITEN, {},
+         lambda: o.mpdr_weight(Rs_ref, Ry_ref, Rn=Rn_ref, gauge=True)),
+    ]
+    for kname, kind, kw, ref_fn in kinds:
+        for ban in (False, True):
+            if ban and kind == _ffi.BF_MPDR:
+                continue
+            opts = _ffi.BfOpts(kind=kind, flags=_ffi.FLAG_BAN if ban else 0,
+                               pmwf_beta=kw.get("pmwf_beta", 0.0),
+                               pmwf_ref=kw.get("pmwf_ref", -1), rank1=kw.get("rank1", 0))
+            w = np.empty((F, C), np.complex64)
+            ctx.weights(opts, Rs_ref, Rn_ref, Ry_ref, F, C, w, st)
+            assert not st.any(), (C, kname)
+            wref = ref_fn()
+            if ban:
+                wref = o.do_ban(wref, Rn_ref)
+            assert rel_rms(w, wref) < 2e-4, (C, kname, ban, rel_rms(w, wref))
+    wref = o.mvdr_weight(Rs_ref, Rn_ref, gauge=True).astype(np.complex64)
+    out = np.empty((T, F), np.complex64)
+    ctx.beamform(wref, spec, C, T, F, out)
+    assert rel_rms(out, o.beamform(wref, obs).T) < 1e-5
+
+
+@pytest.mark.parametrize("C,kind", [(12, "mvdr"), (16, "gevd"), (10, "pmwf-0")])
+def test_wide_engine_matches_oracle(C, kind):
+    from setk_amd.engine import BatchEnhancer
+    mix, sp, nz = o.synth_utterance(60 + C, C, 20000, return_parts=True)
+    mask = (0.05 + 0.9 * o.irm_mask(sp, nz)).astype(np.float32)
+    (wav, st), = BatchEnhancer(beamformer=kind).enhance([(mix, mask, None)])
+    assert st == 0
+    ref = o.enhance_utterance(mix, mask, kind=kind, gauge=True)
+    assert wav.shape == ref.shape
+    assert rel_rms(wav, ref) < 1e-3, (C, kind, rel_rms(wav, ref))
+
+
+@pytest.mark.parametrize("frame_len,hop,center,window", [(400, 160, True, "hann"),
+                                                         (400, 200, False, "hamming"),
+                                                         (320, 160, True, "sqrthann"),
+                                                         (600, 150, True, "hann"),
+                                                         (250, 125, True, "hann")])
+def test_non_power_of_two_stft_roundtrip_and_parity(frame_len, hop, center, window):
+    """--round-power-of-two false: n_fft = frame_len (Bluestein in the generic kernels)."""
+    from setk_amd.libs import utils
+    x = o.synth_utterance(9, 1, 9000)[0]
+    kw = dict(frame_len=frame_len, frame_hop=hop, round_power_of_two=False, center=center,
+              window=window)
+    ref = o.forward_stft(x, transpose=False, **kw)
+    got = utils.forward_stft(x, transpose=False, **kw)
+    assert got.shape == ref.shape == (frame_len // 2 + 1, ref.shape[1])
+    assert rel_rms(got, ref) < 1e-4, rel_rms(got, ref)
+    back_ref = o.inverse_stft(ref, frame_len=frame_len, frame_hop=hop, center=center, window=window,
+                              transpose=False)
+    back = utils.inverse_stft(got, frame_len=frame_len, frame_hop=hop, center=center, window=window,
+                              transpose=False)
+    assert back.shape == back_ref.shape
+    assert rel_rms(back, back_ref) < 1e-4
+
+
+def test_non_power_of_two_cli(tmp_path):
+    """apply_adaptive_beamformer.py --round-power-of-two false --frame-len 400 --frame-hop 160"""
+    import scipy.io.wavfile
+    from setk_amd.libs import wavio
+    td = str(tmp_path)
+    mix, sp, nz = o.synth_utterance(77, 4, 16000, return_parts=True)
+    kw = dict(frame_len=400, frame_hop=160, center=True, window="hann", round_power_of_two=False)
+    S = o.forward_stft(sp[0], transpose=False, **kw)
+    V = o.forward_stft(nz[0], transpose=False, **kw)
+    mask = (0.05 + 0.9 * np.abs(S) / np.sqrt(np.abs(S)**2 + np.abs(V)**2 + 1e-7)).T.astype(np.float32)
+    pcm = wavio.float_to_pcm16(mix.T)
+    wavio.write_pcm16(f"{td}/u.wav", pcm, 16000)
+    np.save(f"{td}/m.npy", mask)
+    open(f"{td}/wav.scp", "w").write(f"u {td}/u.wav\n")
+    open(f"{td}/mask.scp", "w").write(f"u {td}/m.npy\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts/sptk/apply_adaptive_beamformer.py"),
+                        "--mask-format", "numpy", "--round-power-of-two", "false", "--frame-len", "400",
+                        "--frame-hop", "160", f"{td}/wav.scp", f"{td}/mask.scp", f"{td}/enh"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    sr, y = scipy.io.wavfile.read(f"{td}/enh/u.wav")
+    samps = pcm.T.astype(np.float32) / 32768
+    ref = o.enhance_utterance(samps, mask, kind="mvdr", gauge=True, **kw)
+    assert pcm16_rel_rms(y, ref) < 1e-3, pcm16_rel_rms(y, ref)
