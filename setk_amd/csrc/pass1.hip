@@ -109,28 +109,6 @@ SETK_DEV void wg_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// ---- experiment hooks (tools/mk_abl.sh) ---------------------------------------
-// -DSETK_SYNC_COUNTERS: the two roles hand tiles over through two LDS counters
-//   (tiles produced / tiles consumed, counted in wave arrivals) instead of one
-//   workgroup s_barrier per tile: a role that is ahead keeps issuing until it
-//   runs out of buffers, instead of idling at the barrier with its SIMD partner.
-// -DSETK_PRIO_T=n / -DSETK_PRIO_C=n: s_setprio of the transform / covariance waves.
-SETK_DEV void sync_arrive(int* counter) {
-    // this wave's LDS traffic of the tile has completed (reads returned, writes
-    // performed: the LDS executes a CU's operations in order)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-SETK_DEV void sync_wait(int* counter, int target) {
-    while (true) {
-        const int v = __builtin_amdgcn_readfirstlane(
-            __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (v >= target) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 template <int C, bool DUMP>
 __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
     constexpr int NT = 1024;
@@ -151,9 +129,6 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
     float* xn0 = reinterpret_cast<float*>(win_l + table_entries(ROW));  // [2][32] nyquist bins (real)
     float* nym = xn0 + 64;                            // [2][2][8] bin-256 weights (speech|noise)
     float* red = nym + 32;                            // [16]
-    int* sync = reinterpret_cast<int*>(red + 16);     // [2] tiles produced | consumed (wave arrivals)
-    constexpr int NPW = (NF + 3) / 4;                 // transform waves of a tile
-    if (threadIdx.x < 2) sync[threadIdx.x] = 0;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,32 +219,9 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
             qr_stage23<ROW>(slot, xn0 + b * 32 + my_i, tw5_row, la);
         };
 
-#ifdef SETK_PRIO_T
-        __builtin_amdgcn_s_setprio(SETK_PRIO_T);
-#endif
         wg_barrier();  // tables ready
         if (producer) fetch(wi.t0 + my_set * TB);
         if (producer && my_set == 0) produce(0, wi.t0 + NS * TB);
-#ifdef SETK_SYNC_COUNTERS
-        // wave-uniform: does this wave own a transform of the tiles of set `my_set`?
-        const bool wave_prod = __builtin_amdgcn_readfirstlane((int)producer) != 0;
-        const int wave_set = __builtin_amdgcn_readfirstlane(my_set);
-        if (wave_prod && wave_set == 0) sync_arrive(&sync[0]);
-        int buf = 0, next_set = 1 % NS, tile = 0;
-#pragma unroll 1
-        for (int tb = wi.t0; tb < wi.t1; tb += TB, buf ^= 1, ++tile) {
-            const bool more = tb + TB < wi.t1;
-            const bool wprod = wave_prod && (wave_set == next_set) && more;
-            const bool prod = producer && (my_set == next_set) && more;
-            next_set = (next_set + 1 == NS) ? 0 : next_set + 1;
-            if (wprod) {
-                // tile + 1 goes into the buffer tile - 1 was folded from
-                if (tile >= 1) sync_wait(&sync[1], 8 * tile);
-                if (prod) produce(buf ^ 1, tb + TB + NS * TB);
-                sync_arrive(&sync[0]);
-            }
-        }
-#else
         wg_barrier();
         int buf = 0, next_set = 1 % NS;
 #pragma unroll 1
@@ -279,7 +231,6 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
             if (prod) produce(buf ^ 1, tb + TB + NS * TB);
             wg_barrier();
         }
-#endif
 #endif
     } else {
 #ifndef SETK_ONLY_PROD
@@ -319,22 +270,11 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
             }
         };
         if (!DUMP) fetch_masks(wi.t0, cur_s, cur_n);
-#ifdef SETK_PRIO_C
-        __builtin_amdgcn_s_setprio(SETK_PRIO_C);
-#endif
         wg_barrier();  // tables ready
-#ifndef SETK_SYNC_COUNTERS
         wg_barrier();  // tile 0 transformed
-#endif
         int buf = 0;
-#ifdef SETK_SYNC_COUNTERS
-        int tile = 0;
-#endif
 #pragma unroll 1
         for (int tb = wi.t0; tb < wi.t1; tb += TB, buf ^= 1) {
-#ifdef SETK_SYNC_COUNTERS
-            sync_wait(&sync[0], NPW * (tile + 1));
-#endif
             const cf* xt = xt0 + buf * NF * SL;
             const float* xn = xn0 + buf * 32;
             if (DUMP) {
@@ -380,12 +320,7 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
                     cur_n[tt] = nxt_n[tt];
                 }
             }
-#ifdef SETK_SYNC_COUNTERS
-            sync_arrive(&sync[1]);
-            ++tile;
-#else
             wg_barrier();
-#endif
         }
 #endif
     }
@@ -438,7 +373,7 @@ template <int C, bool DUMP>
 static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s) {
     constexpr int NF = pass1_tile_frames(C) * C;
     const size_t lds = (size_t)2 * NF * slot_entries(17) * sizeof(cf) + table_entries(17) * sizeof(cf) +
-                       (64 + 32 + 16 + 2) * sizeof(float);
+                       (64 + 32 + 16) * sizeof(float);
     auto k = stft_covar_kernel<C, DUMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
