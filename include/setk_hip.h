@@ -226,6 +226,23 @@ int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
                              const float* weights, int n_sets, const int* weight_index,
                              void* const* wave, int flags, void* stream);
 
+/* ---- WPE dereverberation --------------------------------------
+ * wpe_step of scripts/sptk/libs/wpe.py:58-81 (tap-stacked correlation, solve,
+ * filter; fp64 like the reference) iterated `num_iters` times as wpe() does
+ * (:84-110): spec / out [C][T][F] complex64.  lambda of the first iteration is
+ * compute_lambda(spec, context) (:32-55) or, when lambda_enh != NULL,
+ * max(|lambda_enh[t][f]|^2, eps) -- the previous enhanced signal of
+ * facted_wpd() (:146-149); later iterations use compute_lambda(dereverb).
+ * inv_lambda_out (may be NULL) receives 1 / lambda of the last iteration as a
+ * float32 [T][F] array: passed to setk_covar as the mask it yields the
+ * power-weighted covariance of facted_wpd (:160-162, up to a per-bin scale that
+ * cancels in the MVDR weight).  status[F] (may be NULL) receives SETK_NUM_*;
+ * SETK_NUM_SINGULAR is numpy's LinAlgError.  num_channels * taps <= 96. */
+int setk_wpe(setk_handle_t h, const float* spec, int num_channels, int num_frames,
+             int num_bins, int taps, int delay, int context, int num_iters,
+             const float* lambda_enh, float* out, float* inv_lambda_out,
+             int* status, void* stream);
+
 /* ---- fused hot path ------------------------------------------------------
  * The compute body of apply_adaptive_beamformer.py:130-178 for a batch of
  * utterances that share the channel count, in four kernel stages:

@@ -429,6 +429,77 @@ def enhance_utterance(samps, mask, kind="mvdr", itf_mask=None, frame_len=512,
 
 
 # ----------------------------------------------------------------------------
+# WPE / facted WPD (libs/wpe.py)
+# ----------------------------------------------------------------------------
+def compute_tap_mat(obs, taps, delay):
+    """libs/wpe.py:13-29.  obs F x N x T -> F x NK x T, row k N + n = channel n
+    delayed by k + delay frames."""
+    F, N, T = obs.shape
+    y = np.zeros([F, N * taps, T], dtype=obs.dtype)
+    for k in range(taps):
+        d = k + delay
+        if d >= T:
+            break
+        y[:, k * N:(k + 1) * N, d:] = obs[:, :, :T - d]
+    return y
+
+
+def compute_lambda(dereverb, ctx=0):
+    """libs/wpe.py:32-55: channel-mean power, averaged over the +-ctx frames that
+    exist, floored at eps_f32.  F x N x T -> F x T (float64 through the count)."""
+    L = np.mean(dereverb.real**2 + dereverb.imag**2, axis=1)
+    _, T = L.shape
+    counts = np.zeros(T)
+    lam = np.zeros_like(L)
+    for c in range(-ctx, ctx + 1):
+        s, e = max(c, 0), min(T, T + c)
+        lam[:, s:e] += L[:, max(-c, 0):min(T, T - c)]
+        counts[s:e] += 1
+    return np.maximum(lam / counts, EPSILON)
+
+
+def wpe_step(reverb, yt, lam):
+    """libs/wpe.py:58-81.  reverb F x N x T, yt F x NK x T, lam F x T."""
+    yn = yt / lam[:, None, :]
+    R = np.einsum("...mt,...nt->...mn", yn, yt.conj())
+    r = np.einsum("...mt,...nt->...mn", yn, reverb.conj())
+    G = np.linalg.solve(R, r)
+    return reverb - np.einsum("...na,...nb->...ab", G.conj(), yt)
+
+
+def wpe(reverb, taps=10, delay=3, context=1, num_iters=3):
+    """libs/wpe.py:84-110.  F x N x T -> F x N x T."""
+    yt = compute_tap_mat(reverb, taps, delay)
+    dereverb = reverb
+    for _ in range(num_iters):
+        dereverb = wpe_step(reverb, yt, compute_lambda(dereverb, ctx=context))
+    return dereverb
+
+
+def facted_wpd(obs, cgmm_iters=10, wpd_iters=3, taps=10, delay=3, context=1, gauge=False):
+    """libs/wpe.py:113-177 (update_alpha=False).  obs N x T x F ->
+    (tf_mask T x F x 2, wpd_enh T x F).  gauge=True fixes the sign of the
+    steering vector (solve_pevd) as everywhere else in this oracle."""
+    obs = np.einsum("ntf->fnt", obs)
+    yt = compute_tap_mat(obs, taps, delay)
+    wpd_enh = None
+    for i in range(wpd_iters):
+        lam = compute_lambda(obs, ctx=context) if i == 0 else np.abs(wpd_enh)**2
+        lam = np.maximum(lam, EPSILON)
+        der = wpe_step(obs, yt, lam)
+        der_r = np.einsum("fnt->nft", der)
+        gamma = cgmm_gamma(der_r, cgmm_iters)  # K x F x T
+        Rd = np.einsum("...nt,...mt->...nm", der / lam[:, None], der.conj()) / der.shape[-1]
+        Rs = compute_covar(der_r, gamma[0].T)
+        sv = solve_pevd(Rs, gauge=gauge)
+        num = _solve_vec(Rd, sv)
+        den = np.einsum("...d,...d->...", sv.conj(), num)
+        weight = num / den[:, None]
+        wpd_enh = np.einsum("...n,...nt->...t", weight.conj(), der)
+    return np.transpose(gamma, (2, 1, 0)), wpd_enh.T
+
+
+# ----------------------------------------------------------------------------
 # CGMM mask estimation (libs/cluster.py) -- K=2, deterministic init
 # ----------------------------------------------------------------------------
 class _Covariance:
@@ -451,6 +522,12 @@ class _Covariance:
 def cgmm_masks(stft_mat, num_iters=20, init_mask=None):
     """CgmmTrainer(K=2).train + estimate_cgmm_masks.py:44-64.
     stft_mat N x F x T -> speech mask T x F float32."""
+    gamma = cgmm_gamma(stft_mat, num_iters, init_mask)
+    return np.transpose(gamma, (0, 2, 1))[0].astype(np.float32)
+
+
+def cgmm_gamma(stft_mat, num_iters=20, init_mask=None):
+    """CgmmTrainer(stft_mat, 2).train(num_iters): posteriors K x F x T (float64)."""
     obs = np.einsum("mft->fmt", stft_mat)
     F, M, T = obs.shape
     if init_mask is None:  # libs/cluster.py:419-425
@@ -483,7 +560,7 @@ def cgmm_masks(stft_mat, num_iters=20, init_mask=None):
         phi = np.einsum("...xt,...xy,...yt->...t", obs.conj(), cov.inv(), obs)
         phi = np.maximum(np.abs(phi), EPSILON) / M
         gamma = predict(cov, phi)
-    return np.transpose(gamma, (0, 2, 1))[0].astype(np.float32)
+    return gamma
 
 
 # ----------------------------------------------------------------------------

@@ -53,7 +53,7 @@ def exported_symbols():
         "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
         "setk_cgmm_masks_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
-        "setk_directional_feats", "setk_set_profiling",
+        "setk_directional_feats", "setk_wpe", "setk_set_profiling",
         "setk_last_stage_ms"
     ]
 
@@ -106,6 +106,8 @@ def load_library():
     ]
     lib.setk_enhance_batch_taps.argtypes = lib.setk_enhance_batch.argtypes[:-1] + [
         POINTER(BatchTaps), c_void_p]
+    lib.setk_wpe.argtypes = [H, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, fp, fp, fp,
+                             fp, c_void_p]
     lib.setk_directional_feats.argtypes = [H, fp, fp, POINTER(c_int), c_int, c_int, c_int, c_int,
                                            fp, c_void_p]
     lib.setk_apply_weights_batch.argtypes = [
@@ -352,6 +354,15 @@ class Context:
             self._lib.setk_apply_weights_batch(
                 self._h, n, int(num_channels), A, NS, _ptr(weights), int(n_sets), IDX, W,
                 int(flags), current_stream_ptr() if stream is None else stream))
+
+    def wpe(self, spec, C, T, F, taps, delay, context, num_iters, out, lambda_enh=None,
+            inv_lambda_out=None, status=None, stream=None):
+        """spec / out [C][T][F] complex64; status int32[F] (numpy) or None."""
+        self.check(
+            self._lib.setk_wpe(self._h, _ptr(spec), int(C), int(T), int(F), int(taps), int(delay),
+                               int(context), int(num_iters), _ptr(lambda_enh), _ptr(out),
+                               _ptr(inv_lambda_out), _ptr(status),
+                               current_stream_ptr() if stream is None else stream))
 
     def set_profiling(self, on):
         self.check(self._lib.setk_set_profiling(self._h, 1 if on else 0))

@@ -1156,6 +1156,84 @@ int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
     return SETK_OK;
 }
 
+// wpe_step (libs/wpe.py:58-81) `num_iters` times.  lambda of iteration 0 comes from
+// `lambda_enh` (facted_wpd: |previous enhanced|^2) when given, else from
+// compute_lambda(spec); later iterations use compute_lambda(dereverb).
+int setk_wpe(setk_handle_t h, const float* spec, int num_channels, int num_frames, int num_bins,
+             int taps, int delay, int context, int num_iters, const float* lambda_enh,
+             float* out, float* inv_lambda_out, int* status, void* stream) {
+    if (!h || !spec || !out || num_frames <= 0 || num_bins <= 0 || num_iters <= 0 || delay < 0 ||
+        context < 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    const int C = num_channels, T = num_frames, F = num_bins;
+    if (!wpe_supported(C, taps))
+        return fail(h, SETK_ERR_UNSUPPORTED,
+                    "WPE needs num_channels * taps <= 96 (R is factored in LDS)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h, s);
+    const size_t n = (size_t)C * T * F;
+    const float* d_spec;
+    int rc = stage_in(h, spec, n * 2, s, &d_spec);
+    if (rc) return rc;
+    const float* d_enh = nullptr;
+    if (lambda_enh) {
+        rc = stage_in(h, lambda_enh, (size_t)T * F * 2, s, &d_enh);
+        if (rc) return rc;
+    }
+    OutBuf ob, ob_il;
+    rc = stage_out(h, out, n * sizeof(float2), &ob);
+    if (rc) return rc;
+    if (inv_lambda_out) {
+        rc = stage_out(h, inv_lambda_out, (size_t)T * F * sizeof(float), &ob_il);
+        if (rc) return rc;
+    }
+    float* x_fct = static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
+    float* d_a = static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
+    float* d_b = static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
+    double* lam = static_cast<double*>(arena_alloc(h, (size_t)T * F * sizeof(double)));
+    int* d_st = static_cast<int*>(arena_alloc(h, (size_t)F * sizeof(int) * (size_t)num_iters));
+    if (!x_fct || !d_a || !d_b || !lam || !d_st) return fail(h, SETK_ERR_NOMEM, "arena");
+    HIP_TRY(h, launch_wpe_transpose(d_spec, C, T, F, x_fct, true, s));
+    const float* cur = x_fct;
+    float* bufs[2] = {d_a, d_b};
+    for (int it = 0; it < num_iters; ++it) {
+        if (it == 0 && d_enh)
+            HIP_TRY(h, launch_wpe_lambda_from_enh(d_enh, T, F, lam, s));
+        else
+            HIP_TRY(h, launch_wpe_lambda(cur, C, T, F, context, lam, s));
+        float* dst = bufs[it & 1];
+        HIP_TRY(h, launch_wpe_step(x_fct, lam, C, T, F, taps, delay, dst, d_st + (size_t)it * F, s));
+        cur = dst;
+    }
+    HIP_TRY(h, launch_wpe_transpose(cur, C, T, F, static_cast<float*>(ob.dev), false, s));
+    if (inv_lambda_out)
+        HIP_TRY(h, launch_wpe_inv_lambda(lam, T, F, static_cast<float*>(ob_il.dev), s));
+    rc = copy_back(h, ob, s);
+    if (rc) return rc;
+    if (inv_lambda_out) {
+        rc = copy_back(h, ob_il, s);
+        if (rc) return rc;
+    }
+    bool sync = ob.host || (inv_lambda_out && ob_il.host);
+    if (status) {
+        // worst status over the iterations, per bin
+        std::vector<int> st((size_t)F * num_iters);
+        HIP_TRY(h, hipMemcpyAsync(st.data(), d_st, st.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        std::vector<int> worst(F, 0);
+        for (int it = 0; it < num_iters; ++it)
+            for (int f = 0; f < F; ++f) worst[f] = std::max(worst[f], st[(size_t)it * F + f]);
+        if (is_device_ptr(status))
+            HIP_TRY(h, hipMemcpy(status, worst.data(), F * sizeof(int), hipMemcpyHostToDevice));
+        else
+            memcpy(status, worst.data(), F * sizeof(int));
+        sync = false;
+    }
+    if (sync) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
 int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, int num_channels,
                        const float* const* audio, const int* num_samples,
                        const float* const* mask_s, const float* const* mask_n,

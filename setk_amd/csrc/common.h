@@ -172,4 +172,16 @@ hipError_t launch_pcm16_to_float_batch(const void* d_items, int n_utts, int C, i
 hipError_t launch_beamform_spec(const float* w_fc, const float* spec, int C, int T, int F,
                                 float* out, hipStream_t s);
 
+// WPE (wpe.hip)
+bool wpe_supported(int N, int taps);
+hipError_t launch_wpe_transpose(const float* in, int C, int T, int F, float* out, bool to_fct,
+                                hipStream_t s);
+hipError_t launch_wpe_lambda(const float* d_fct, int C, int T, int F, int ctx, double* lam,
+                             hipStream_t s);
+hipError_t launch_wpe_lambda_from_enh(const float* enh_tf, int T, int F, double* lam,
+                                      hipStream_t s);
+hipError_t launch_wpe_inv_lambda(const double* lam, int T, int F, float* out, hipStream_t s);
+hipError_t launch_wpe_step(const float* x_fct, const double* lam, int N, int T, int F, int taps,
+                           int delay, float* out_fct, int* status, hipStream_t s);
+
 }  // namespace setk

@@ -1,0 +1,116 @@
+"""
+GPU parity of WPE / factorised WPD (libs/wpe.py) against the oracle
+restatement (itself equal to the unmodified reference, tests/test_oracle_golden.py)
+and the reference's stored doc outputs (doc/wpe/asset).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, pcm16_rel_rms, rel_rms, rms
+from oracle import np_oracle as o
+from oracle import make_golden as mg
+
+pytestmark = pytest.mark.gpu
+STFT_KW = dict(frame_len=512, frame_hop=256, window="hann", center=True)
+
+
+def test_wpe_small_known_answer():
+    from setk_amd.libs import wpe as W
+    g = load_golden("ref_wpe.npz")
+    rev, _ = mg.wpe_small_case()
+    out = W.wpe(rev, taps=4, delay=2, context=1, num_iters=2)
+    assert out.shape == g["small.wpe"].shape and out.dtype == np.complex128
+    assert rel_rms(out, g["small.wpe"]) < 1e-5, rel_rms(out, g["small.wpe"])
+    assert np.array_equal(W.compute_tap_mat(rev, 3, 1), g["small.tap"])
+    assert np.allclose(W.compute_lambda(rev, ctx=2), g["small.lambda"], rtol=1e-6)
+    # one step with caller supplied variances
+    lam = o.compute_lambda(rev, ctx=1)
+    yt = o.compute_tap_mat(rev, 4, 2)
+    assert rel_rms(W.wpe_step(rev, yt, lam), o.wpe_step(rev, yt, lam)) < 1e-5
+
+
+@pytest.mark.parametrize("C,taps,N", [(8, 10, 40000), (2, 12, 20000), (6, 5, 30000), (1, 10, 16000)])
+def test_wpe_matches_oracle(C, taps, N):
+    """Up to NK = 80 tap-stacked channels (8 ch x 10 taps): cond(R) reaches 1e10, the
+    reference computes in complex128 -- the device result must agree to 1e-4."""
+    from setk_amd.libs import wpe as W
+    mix = o.synth_utterance(90 + C, C, N)
+    # reverberate: a few decaying reflections per channel
+    rng = np.random.default_rng(C)
+    rev = mix.copy()
+    for d in (700, 1500, 2600, 4100):
+        rev[:, d:] += 0.4 * rng.uniform(0.5, 1.0) * mix[:, :-d][::-1]
+    kw = dict(frame_len=512, frame_hop=128, window="hann", center=True)
+    obs = o.multichannel_stft(rev, transpose=True, **kw)
+    if obs.ndim == 2:
+        obs = obs[None]
+    fnt = np.transpose(obs, (2, 0, 1))
+    ref = o.wpe(fnt, taps=taps, delay=3, context=1, num_iters=3)
+    out = W.wpe(fnt, taps=taps, delay=3, context=1, num_iters=3)
+    assert rel_rms(out, ref) < 1e-4, (C, taps, rel_rms(out, ref))
+
+
+def test_wpe_too_many_taps_is_refused():
+    from setk_amd import _ffi
+    from setk_amd.libs import wpe as W
+    fnt = np.zeros((9, 8, 50), np.complex64)
+    with pytest.raises(_ffi.SetkUnsupported):
+        W.wpe(fnt, taps=13)
+
+
+def test_wpe_singular_is_linalg_error():
+    from setk_amd.libs import wpe as W
+    fnt = np.zeros((5, 2, 40), np.complex64)  # all-zero observation: R = 0
+    with pytest.raises(np.linalg.LinAlgError):
+        W.wpe(fnt, taps=3, delay=1)
+
+
+def test_facted_wpd_matches_oracle():
+    from setk_amd.libs import wpe as W
+    _, mix = mg.wpe_small_case()
+    obs = o.multichannel_stft(mix, transpose=True, **STFT_KW)
+    mask_ref, enh_ref = o.facted_wpd(obs, cgmm_iters=3, wpd_iters=2, taps=4, delay=2, context=1,
+                                     gauge=True)
+    mask, enh = W.facted_wpd(obs, cgmm_iters=3, wpd_iters=2, taps=4, delay=2, context=1)
+    assert mask.shape == mask_ref.shape and enh.shape == enh_ref.shape
+    assert np.mean(np.abs(mask - mask_ref)) < 2e-4
+    assert rel_rms(enh, enh_ref) < 1e-3, rel_rms(enh, enh_ref)
+
+
+def test_doc_wpe_and_wpd_clis(tmp_path):
+    """doc/wpe/README.md: the two command lines, against the stored wavs."""
+    import scipy.io.wavfile
+    from test_oracle_golden import resolve_gauge
+    g = load_golden("ref_wpe.npz")
+    td = str(tmp_path)
+    scipy.io.wavfile.write(f"{td}/egs.wav", 16000, g["egs"])
+    open(f"{td}/wav.scp", "w").write(f"egs {td}/egs.wav\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts/sptk/apply_wpe.py"),
+                        "--frame-len", "512", "--frame-hop", "128", f"{td}/wav.scp", f"{td}/wpe"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Processed 1 utterances over 1" in r.stderr
+    sr, y = scipy.io.wavfile.read(f"{td}/wpe/egs.wav")
+    assert y.shape == g["wpe_egs"].shape and y.dtype == np.int16
+    err = rms(y.astype(np.float64), g["wpe_egs"].astype(np.float64)) / rms(g["wpe_egs"].astype(np.float64))
+    assert err < 1e-3, err
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts/sptk/apply_wpd.py"),
+                        "--frame-len", "512", "--taps", "10", "--delay", "3", "--context", "1",
+                        "--wpd-iters", "2", "--cgmm-iters", "10", "--update-alpha", "false",
+                        "--dump-mask", "true", f"{td}/wav.scp", f"{td}/wpd"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    sr, y = scipy.io.wavfile.read(f"{td}/wpd/egs.wav")
+    assert y.shape == g["wpd_egs"].shape
+    assert np.load(f"{td}/wpd/egs.npy").shape == (209, 257)
+    # the stored wav carries LAPACK's per-bin signs, ours the declared gauge:
+    # compare with the gauge-fixed oracle, and the oracle with the stored wav
+    samps = (g["egs"].astype(np.float32) / 32768.0).T.copy()
+    obs = o.multichannel_stft(samps, transpose=True, **STFT_KW)
+    _, enh = o.facted_wpd(obs, cgmm_iters=10, wpd_iters=2, taps=10, delay=3, context=1, gauge=True)
+    ref = o.inverse_stft(enh, norm=np.max(np.abs(samps)), transpose=True, **STFT_KW)
+    assert pcm16_rel_rms(y, ref) < 1e-3, pcm16_rel_rms(y, ref)

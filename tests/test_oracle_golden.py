@@ -238,3 +238,41 @@ def test_consumer_cli_goldens():
         df = o.directional_feats(obs, sv.T, df_pair=[(0, 1), (1, 3), (0, 2)])
         assert df.shape == g[f"{k}.df"].shape
         assert np.max(np.abs(df - g[f"{k}.df"])) < 2e-3
+
+
+# ---------------------------------------------------------------------------
+# WPE / facted WPD (libs/wpe.py)
+# ---------------------------------------------------------------------------
+def test_wpe_restatement_equals_reference_vectors():
+    g = load_golden("ref_wpe.npz")
+    rev, mix = mg.wpe_small_case()
+    assert np.array_equal(o.compute_tap_mat(rev, 3, 1), g["small.tap"])
+    assert np.allclose(o.compute_lambda(rev, ctx=2), g["small.lambda"], rtol=1e-12, atol=0)
+    assert rel_rms(o.wpe(rev, taps=4, delay=2, context=1, num_iters=2), g["small.wpe"]) < 1e-10
+    obs = o.multichannel_stft(mix, transpose=True, **STFT_KW)
+    mask, enh = o.facted_wpd(obs, cgmm_iters=3, wpd_iters=2, taps=4, delay=2, context=1)
+    assert np.max(np.abs(mask - g["small.wpd_mask"])) < 1e-5
+    # per-bin sign of the steering vector is LAPACK's: compare up to it
+    ref = g["small.wpd_enh"]
+    sign = np.sign(np.real(np.sum(enh * np.conj(ref), axis=0)))
+    assert rel_rms(enh * sign[None, :], ref) < 1e-6
+
+
+def test_wpe_doc_assets():
+    """doc/wpe: apply_wpe.py --frame-len 512 --frame-hop 128 (3 iterations, 10 taps,
+    delay 3) and apply_wpd.py --frame-len 512 --wpd-iters 2 --cgmm-iters 10, against
+    the wavs the reference's author stored."""
+    g = load_golden("ref_wpe.npz")
+    samps = (g["egs"].astype(np.float32) / 32768.0).T.copy()
+    kw = dict(frame_len=512, frame_hop=128, window="hann", center=True)
+    obs = o.multichannel_stft(samps, transpose=True, **kw)           # N x T x F
+    der = o.wpe(np.transpose(obs, (2, 0, 1)), taps=10, delay=3, context=1, num_iters=3)
+    wav = np.stack([o.inverse_stft(x, transpose=True, **kw) for x in np.transpose(der, (1, 2, 0))])
+    stored = pcm_to_float(g["wpe_egs"]).T
+    assert wav.shape == stored.shape == (4, 53248)
+    assert rms(float_to_pcm(wav) / 32768.0, stored) / rms(stored) < 1e-3
+    obs = o.multichannel_stft(samps, transpose=True, **STFT_KW)
+    _, enh = o.facted_wpd(obs, cgmm_iters=10, wpd_iters=2, taps=10, delay=3, context=1)
+    stored = pcm_to_float(g["wpd_egs"])
+    _, best = resolve_gauge(enh.T, np.max(np.abs(samps)), stored)
+    assert best / rms(stored) < 1e-3, best / rms(stored)
