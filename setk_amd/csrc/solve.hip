@@ -674,8 +674,16 @@ __global__ void pack_covar_kernel(const float2* fcc, int F, int C, int Cp, float
             const int e = pair_index(i, j, Cp);
             float2 v = make_float2(0.f, 0.f);
             if (f < F) {
-                if (j < C) v = fcc[((size_t)f * C + i) * C + j];
-                else if (i == j) v = make_float2(pad_diag, 0.f);
+                // the element of the LOWER triangle, as LAPACK's UPLO = 'L' (numpy eigh,
+                // scipy eigh(lower=True)) reads it: a float32 covariance is Hermitian
+                // only to rounding and the two triangles give eigenvectors 1e-4 apart
+                // on a pencil with a 1 % eigenvalue gap
+                if (j < C) {
+                    const float2 l = fcc[((size_t)f * C + j) * C + i];
+                    v = make_float2(l.x, i == j ? 0.f : -l.y);
+                } else if (i == j) {
+                    v = make_float2(pad_diag, 0.f);
+                }
             }
             planes[(size_t)(plane0 + e) * pitch + f] = v.x;
             planes[(size_t)(plane0 + NP + e) * pitch + f] = v.y;

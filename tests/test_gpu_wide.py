@@ -54,7 +54,8 @@ def test_wide_covar_pevd_weights(ctx, C):
     ctx.pevd(Rs_ref, Rn_ref, F, C, 0, pv, st)
     assert not st.any()
     # the oracle's pencil solve runs LAPACK chegvd in complex64 on these inputs, the
-    # device in fp64: at C > 8 the oracle's own rounding shows at 1e-4
+    # device in fp64: at C > 8 the oracle's own rounding shows at 1e-4, so the
+    # comparison is with the oracle evaluated in complex128
     ref = o.fix_gauge_gev(o.solve_pevd(Rs_ref.astype(np.complex128), Rn_ref.astype(np.complex128)),
                           Rn_ref.astype(np.complex128))
     assert rel_rms(pv, ref) < 1e-4
