@@ -31,8 +31,18 @@ def test_doc_pipeline_mask_and_pmwf_golden():
     assert np.allclose(gamma.sum(0), 1.0, atol=1e-5)
     mask = gamma[0].T.astype(np.float32)
     ref = doc["cgmm_mask"]
-    assert np.mean(np.abs(mask - ref)) < 1e-4
-    assert np.max(np.abs(mask - ref)) < 2e-2
+    d = np.abs(mask - ref)
+    big = d > 1e-3
+    # where the deviations sit: cells whose posterior is undecided (the two class
+    # log-likelihoods differ by < 1 nat), i.e. on the steep part of the softmax,
+    # where a 1e-6 relative change of x^H R^-1 x moves gamma most
+    undecided = (ref > 0.02) & (ref < 0.98)
+    print(f"[doc cgmm] mean |d| {d.mean():.2e}, max |d| {d.max():.2e}, cells > 1e-3: "
+          f"{int(big.sum())} of {d.size} ({int((big & undecided).sum())} of them undecided cells, "
+          f"{undecided.mean():.1%} of all cells are undecided)")
+    assert d.mean() < 1e-4
+    assert d.max() < 2e-2
+    assert big.mean() < 2e-3 and (big & ~undecided).sum() <= 0.2 * max(big.sum(), 1)
     (wav, st), = BatchEnhancer(beamformer="pmwf-0", pcm16=True).enhance([(samps, mask, None)])
     assert st == 0
     stored = doc["pmwf_0"].astype(np.float64)
