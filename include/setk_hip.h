@@ -189,14 +189,16 @@ int setk_beamform(setk_handle_t h, const float* weight, const float* spec,
 /* ---- CGMM mask estimation (BASELINE configs[4]) ---------------
  * CgmmTrainer(obs, 2, gamma=init).train(num_iters) of
  * scripts/sptk/libs/cluster.py:396-465 as used by estimate_cgmm_masks.py:44-64:
- * K = 2 complex-Gaussian mixture, alpha fixed at 1/2, deterministic start
+ * K = 2 complex-Gaussian mixture, alpha fixed at 1/2 (or SETK_CGMM_UPDATE_ALPHA), deterministic start
  * (Rs = x x^H / T, Rn = I) or an initial speech mask.
  * spec[C][T][F] complex64, init_mask[T][F] or NULL.
  * gamma_out (may be NULL) receives the posteriors [2][T][F]; mask_out[T][F]
  * receives gamma[0] (the speech mask the CLI saves).  1 <= C <= 8. */
+#define SETK_CGMM_UPDATE_ALPHA 0x1 /* --update-alpha: alpha_k = mean_t gamma_k in every M-step
+                                     (Cgmm.update, cluster.py:246-257) instead of 1/2 */
 int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int num_frames,
                     int num_bins, int num_iters, const float* init_mask, float* gamma_out,
-                    float* mask_out, void* stream);
+                    float* mask_out, int flags, void* stream);
 
 /* Batched form: n_utts utterances per EM stage launch (device pointers only;
  * spec[u] = [C][num_frames[u]][F], mask_out[u] = [num_frames[u]][F], init_mask
@@ -204,7 +206,7 @@ int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int nu
 int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
                           const float* const* spec, const int* num_frames, int num_bins,
                           int num_iters, const float* const* init_mask, float* const* mask_out,
-                          void* stream);
+                          int flags, void* stream);
 
 /* directional_feats (libs/spatial.py:184-208, compute_df_on_mask.py:40-54):
  * out[t][f] = mean over the n_pairs microphone pairs (i, j) = (pairs[2p],

@@ -476,8 +476,9 @@ def wpe(reverb, taps=10, delay=3, context=1, num_iters=3):
     return dereverb
 
 
-def facted_wpd(obs, cgmm_iters=10, wpd_iters=3, taps=10, delay=3, context=1, gauge=False):
-    """libs/wpe.py:113-177 (update_alpha=False).  obs N x T x F ->
+def facted_wpd(obs, cgmm_iters=10, wpd_iters=3, taps=10, delay=3, context=1, gauge=False,
+               update_alpha=False):
+    """libs/wpe.py:113-177.  obs N x T x F ->
     (tf_mask T x F x 2, wpd_enh T x F).  gauge=True fixes the sign of the
     steering vector (solve_pevd) as everywhere else in this oracle."""
     obs = np.einsum("ntf->fnt", obs)
@@ -488,7 +489,7 @@ def facted_wpd(obs, cgmm_iters=10, wpd_iters=3, taps=10, delay=3, context=1, gau
         lam = np.maximum(lam, EPSILON)
         der = wpe_step(obs, yt, lam)
         der_r = np.einsum("fnt->nft", der)
-        gamma = cgmm_gamma(der_r, cgmm_iters)  # K x F x T
+        gamma = cgmm_gamma(der_r, cgmm_iters, update_alpha=update_alpha)  # K x F x T
         Rd = np.einsum("...nt,...mt->...nm", der / lam[:, None], der.conj()) / der.shape[-1]
         Rs = compute_covar(der_r, gamma[0].T)
         sv = solve_pevd(Rs, gauge=gauge)
@@ -526,8 +527,9 @@ def cgmm_masks(stft_mat, num_iters=20, init_mask=None):
     return np.transpose(gamma, (0, 2, 1))[0].astype(np.float32)
 
 
-def cgmm_gamma(stft_mat, num_iters=20, init_mask=None):
-    """CgmmTrainer(stft_mat, 2).train(num_iters): posteriors K x F x T (float64)."""
+def cgmm_gamma(stft_mat, num_iters=20, init_mask=None, update_alpha=False):
+    """CgmmTrainer(stft_mat, 2, update_alpha=...).train(num_iters): posteriors
+    K x F x T (float64).  update_alpha: Cgmm.update, libs/cluster.py:246-257."""
     obs = np.einsum("mft->fmt", stft_mat)
     F, M, T = obs.shape
     if init_mask is None:  # libs/cluster.py:419-425
@@ -547,11 +549,13 @@ def cgmm_gamma(stft_mat, num_iters=20, init_mask=None):
     def predict(cov, phi):  # libs/cluster.py:261-287, 214-235
         log_pdf = -M * np.log(phi) - cov.logdet()
         log_pdf = log_pdf - np.amax(log_pdf, 0, keepdims=True)
-        nom = np.exp(log_pdf) * alpha[..., None]
+        nom = np.exp(log_pdf) * alpha[..., None]  # alpha: enclosing scope, see the loop
         return nom / np.maximum(np.sum(nom, 0, keepdims=True), EPSILON)
 
     gamma = predict(cov, phi)
     for _ in range(num_iters):  # libs/cluster.py:455-465, 193-212
+        if update_alpha:
+            alpha = np.mean(gamma, -1)
         den = np.sum(gamma, -1, keepdims=True)
         R = np.einsum("...t,...xt,...yt->...xy", gamma * M / phi, obs,
                       obs.conj())

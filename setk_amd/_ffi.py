@@ -22,6 +22,7 @@ NUM_OK, NUM_SINGULAR, NUM_NOCONV, NUM_NONFINITE = 0, 1, 2, 3
 BF_MVDR, BF_GEVD, BF_PMWF, BF_MPDR, BF_MPDR_WHITEN = 0, 1, 2, 3, 4
 RANK1_NONE, RANK1_EIG, RANK1_GEV = 0, 1, 2
 FLAG_BAN, FLAG_CLAMP_MASK, FLAG_POST_MASK, FLAG_NO_GAUGE, FLAG_OUT_PCM16 = 1, 2, 4, 8, 16
+CGMM_UPDATE_ALPHA = 1
 
 
 class BfOpts(ctypes.Structure):
@@ -96,9 +97,10 @@ def load_library():
                                               POINTER(c_void_p), c_void_p, c_void_p]
     lib.setk_rank1.argtypes = [H, fp, fp, c_int, c_int, fp, fp, c_void_p]
     lib.setk_beamform.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, c_void_p]
-    lib.setk_cgmm_masks.argtypes = [H, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_void_p]
+    lib.setk_cgmm_masks.argtypes = [H, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, c_void_p]
     lib.setk_cgmm_masks_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int), c_int,
-                                          c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p]
+                                          c_int, POINTER(c_void_p), POINTER(c_void_p), c_int,
+                                          c_void_p]
     lib.setk_enhance_batch.argtypes = [
         H, POINTER(BfOpts), c_int, c_int, POINTER(c_void_p), POINTER(c_int),
         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int),
@@ -284,14 +286,16 @@ class Context:
                                     _ptr(out),
                                     current_stream_ptr() if stream is None else stream))
 
-    def cgmm_masks(self, spec, C, T, F, num_iters, init_mask, gamma_out, mask_out, stream=None):
+    def cgmm_masks(self, spec, C, T, F, num_iters, init_mask, gamma_out, mask_out, stream=None,
+                   update_alpha=False):
         self.check(
             self._lib.setk_cgmm_masks(self._h, _ptr(spec), C, T, F, int(num_iters),
                                       _ptr(init_mask), _ptr(gamma_out), _ptr(mask_out),
+                                      CGMM_UPDATE_ALPHA if update_alpha else 0,
                                       current_stream_ptr() if stream is None else stream))
 
     def cgmm_masks_batch(self, C, spec_ptrs, num_frames, F, num_iters, init_ptrs, out_ptrs,
-                         stream=None):
+                         stream=None, update_alpha=False):
         n = len(spec_ptrs)
         S = (c_void_p * n)(*spec_ptrs)
         O = (c_void_p * n)(*out_ptrs)
@@ -299,6 +303,7 @@ class Context:
         T = (c_int * n)(*[int(v) for v in num_frames])
         self.check(
             self._lib.setk_cgmm_masks_batch(self._h, n, int(C), S, T, int(F), int(num_iters), I, O,
+                                            CGMM_UPDATE_ALPHA if update_alpha else 0,
                                             current_stream_ptr() if stream is None else stream))
 
     # -- fused hot path ---------------------------------------------------------

@@ -938,7 +938,7 @@ int setk_beamform(setk_handle_t h, const float* weight, const float* spec, int n
 int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
                           const float* const* spec, const int* num_frames, int num_bins,
                           int num_iters, const float* const* init_mask, float* const* mask_out,
-                          void* stream) {
+                          int flags, void* stream) {
     if (!h || n_utts <= 0 || !spec || !num_frames || !mask_out || num_bins <= 0 || num_iters < 0)
         return fail(h, SETK_ERR_INVALID, "bad args");
     if (num_channels < 1 || num_channels > kMaxChannels)
@@ -961,7 +961,8 @@ int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
         void* scr = arena_alloc(h, cgmm_scratch_bytes(C, T, F));
         if (!scr) return fail(h, SETK_ERR_NOMEM, "arena");
         cgmm_fill_args(tbl.data() + (size_t)u * ab, C, spec[u], T, F,
-                       init_mask ? init_mask[u] : nullptr, nullptr, mask_out[u], scr);
+                       init_mask ? init_mask[u] : nullptr, nullptr, mask_out[u], scr,
+                       (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0);
     }
     void* d_tbl;
     int rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
@@ -1005,7 +1006,7 @@ int setk_directional_feats(setk_handle_t h, const float* spec, const float* stee
 
 int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int num_frames,
                     int num_bins, int num_iters, const float* init_mask, float* gamma_out,
-                    float* mask_out, void* stream) {
+                    float* mask_out, int flags, void* stream) {
     if (!h || !spec || !mask_out || num_frames <= 0 || num_bins <= 0 || num_iters < 0)
         return fail(h, SETK_ERR_INVALID, "bad args");
     if (num_channels < 1 || num_channels > kMaxChannels)
@@ -1033,7 +1034,8 @@ int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int nu
     void* d_scr = arena_alloc(h, cgmm_scratch_bytes(C, T, F));
     if (!d_scr) return fail(h, SETK_ERR_NOMEM, "arena");
     std::vector<char> tbl(cgmm_args_bytes());
-    cgmm_fill_args(tbl.data(), C, d_spec, T, F, d_init, d_gamma, static_cast<float*>(om.dev), d_scr);
+    cgmm_fill_args(tbl.data(), C, d_spec, T, F, d_init, d_gamma, static_cast<float*>(om.dev), d_scr,
+                   (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0);
     void* d_tbl;
     rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
     if (rc) return rc;

@@ -3,13 +3,13 @@
 // Replaces (funcwj/setk): CgmmTrainer / Cgmm / CgDistribution / Covariance in
 // scripts/sptk/libs/cluster.py:94-287, 396-465 as driven by
 // scripts/sptk/estimate_cgmm_masks.py:19-71 (K = 2, deterministic init or an
-// initial mask, alpha fixed at 1/2).
+// initial mask; alpha fixed at 1/2 or, with update_alpha, re-estimated per iteration).
 //
 // Per EM iteration (cluster.py:193-212, 261-287), M = channels:
 //   R_k(f)   = sum_t gamma_k M / phi_k  x x^H / max(sum_t gamma_k, eps)      cgmm_accum + finalize
 //   (w, V)   = eigh(R_k);  w <- max(w / max(max w, eps), eps)                 cgmm_eig (fp64 Jacobi)
 //   phi_k    = max(|x^H R_k^-1 x|, eps) / M,  R^-1 = V diag(1/w) V^H          cgmm_estep
-//   gamma_k  = softmax_k(-M log phi_k - sum log w) with alpha = 1/2           cgmm_estep
+//   gamma_k  = alpha_k N_k / sum_k alpha_k N_k, log N_k = -M log phi_k - sum log w   cgmm_estep
 // The quadratic form is evaluated in the eigenbasis, sum_j |v_j^H x|^2 / w_j
 // (all terms positive), so float32 does not suffer the cancellation the dense
 // x^H R^-1 x would (1/w reaches 8e6); the reference does it in float64.
@@ -47,7 +47,8 @@ struct CgmmArgs {
     float* invw;             // [2][F][C]
     float* logdet;           // [2][F]
     float* mask_out;         // [T][F] or null (last E-step)
-    int T, F, pitch, nchunks, tchunk, mode;
+    float* alpha;            // [2][F] mixture weights (1/2 unless update_alpha, cluster.py:254-257)
+    int T, F, pitch, nchunks, tchunk, mode, update_alpha;
 };
 
 // ---- M-step: weighted outer products, 32 bins x 2 classes per wavefront ----
@@ -63,6 +64,8 @@ __global__ __launch_bounds__(64) void cgmm_accum_kernel(const CgmmArgs* __restri
     const int chunk = blockIdx.y;
     const int t0 = chunk * a.tchunk, t1 = min(a.T, t0 + a.tchunk);
     const int T = a.T, F = a.F;
+    // the first launch of a run also sets the mixture weights to 1 / K (cluster.py:446)
+    if (!em && chunk == 0 && f < F) a.alpha[(size_t)k * F + f] = 0.5f;
     cf acc[NP];
 #pragma unroll
     for (int e = 0; e < NP; ++e) acc[e] = make_float2(0.f, 0.f);
@@ -135,6 +138,8 @@ __global__ void cgmm_finalize_kernel(const CgmmArgs* __restrict__ tbl, int em, i
         acc += (double)P[(size_t)e * a.pitch + f];
         den += (double)P[(size_t)(2 * NP) * a.pitch + f];
     }
+    // Cgmm.update (cluster.py:246-257): alpha_k = mean_t gamma_k, from the same sums
+    if (a.update_alpha && a.mode == kCgEm && e == 0) a.alpha[(size_t)k * a.F + f] = (float)(den / a.T);
     if (a.mode == kCgInitId) den = (double)a.T;
     out[f] = acc / fmax(den, (double)kEps32);
 }
@@ -267,6 +272,7 @@ __global__ __launch_bounds__(64) void cgmm_estep_kernel(const CgmmArgs* __restri
         for (int i = 0; i < C; ++i) Vr[j][i] = Vd[j * C + i];
     }
     const float ld = a.logdet[(size_t)k * F + fc];
+    const float al_mine = a.alpha[(size_t)k * F + fc], al_other = a.alpha[(size_t)(1 - k) * F + fc];
     cf acc[ACCUM ? NP : 1];
 #pragma unroll
     for (int e = 0; e < (ACCUM ? NP : 1); ++e) acc[e] = make_float2(0.f, 0.f);
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(64) void cgmm_estep_kernel(const CgmmArgs* __restri
         const float lp = -(float)C * logf(ph) - ld;
         const float lo = __shfl_xor(lp, 32);
         const float mx = fmaxf(lp, lo);
-        const float mine = 0.5f * expf(lp - mx), other = 0.5f * expf(lo - mx);
+        const float mine = al_mine * expf(lp - mx), other = al_other * expf(lo - mx);
         const float g = mine / fmaxf(mine + other, kEps32);
         if (ACCUM) {
             const float w = g * (float)C / ph;
@@ -356,7 +362,8 @@ static hipError_t cgmm_run_t(const CgmmArgs* d_tbl, int n_utts, int F, int max_c
 // Fill one utterance's argument block; `scratch` is carved for its work arrays
 // (gamma, phi included).  Returns bytes used.
 size_t cgmm_fill_args(void* args_out, int C, const float* spec, int T, int F,
-                      const float* init_mask, float* gamma_opt, float* mask_out, void* scratch) {
+                      const float* init_mask, float* gamma_opt, float* mask_out, void* scratch,
+                      int update_alpha) {
     const int NP = npairs(C);
     CgmmArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -382,6 +389,8 @@ size_t cgmm_fill_args(void* args_out, int C, const float* spec, int T, int F,
     a.V = reinterpret_cast<cf*>(take((size_t)2 * F * C * C * 8));
     a.invw = reinterpret_cast<float*>(take((size_t)2 * F * C * 4));
     a.logdet = reinterpret_cast<float*>(take((size_t)2 * F * 4));
+    a.alpha = reinterpret_cast<float*>(take((size_t)2 * F * 4));
+    a.update_alpha = update_alpha;
     std::memcpy(args_out, &a, sizeof(a));
     return (size_t)(p - static_cast<char*>(scratch));
 }
@@ -395,7 +404,7 @@ size_t cgmm_scratch_bytes(int C, int T, int F) {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     return 2 * al((size_t)2 * T * F * 4) + al(nchunks * 2 * (2 * NP + 1) * pitch * 4) +
            al((size_t)2 * 2 * NP * pitch * 8) + al((size_t)2 * F * C * C * 8) +
-           al((size_t)2 * F * C * 4) + al((size_t)2 * F * 4) + 1024;
+           al((size_t)2 * F * C * 4) + 2 * al((size_t)2 * F * 4) + 1024;
 }
 
 hipError_t launch_cgmm_batch(int C, const void* d_tbl, int n_utts, int F, int max_frames,

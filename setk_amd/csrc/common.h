@@ -150,7 +150,8 @@ hipError_t launch_istft_generic(const float* spec, int B, int T, int n_fft, int 
                                 const float* norm, int T_eff, const BluesteinPlan* bp,
                                 hipStream_t s);
 size_t cgmm_fill_args(void* args_out, int C, const float* spec, int T, int F,
-                      const float* init_mask, float* gamma_opt, float* mask_out, void* scratch);
+                      const float* init_mask, float* gamma_opt, float* mask_out, void* scratch,
+                      int update_alpha);
 size_t cgmm_args_bytes();
 size_t cgmm_scratch_bytes(int C, int T, int F);
 hipError_t launch_cgmm_batch(int C, const void* d_tbl, int n_utts, int F, int max_frames,

@@ -22,51 +22,12 @@ namespace setk {
 
 constexpr int kRow2 = 18;  // LDS row stride of this pass: 16-byte aligned rows, b128 reads (fft512.h)
 
-SETK_DEV int reflect_index2(int i, int n) {
-    if (i < 0) i = -i;
-    if (i >= n) i = 2 * (n - 1) - i;
-    return i;
-}
-
 // LDS plan (bytes): slots (16+keep)*2304 (padded 16x16 transpose) | wtab C*257*8 (BF mode) |
 // per-lane table rows (window, twiddles; fft512.h) | winsq 2048 | red 16
 size_t pass2_lds_bytes(int C, int keep) {
     size_t wt = ((size_t)C * kBins * sizeof(cf) + 15) & ~(size_t)15;
     return (size_t)(kSuperTile + keep) * slot_entries(kRow2) * sizeof(cf) + wt + table_entries(kRow2) * sizeof(cf) + 2048 +
            64;
-}
-
-// raw (un-windowed) frame points of one quad-row lane: v[j] = (x[s+2n], x[s+2n+1])
-SETK_DEV void load_raw(cf (&v)[16], const float* __restrict__ x, int n_samp, int s, int la,
-                       bool valid) {
-    if (!valid) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = make_float2(0.f, 0.f);
-        return;
-    }
-    const bool interior = (s >= 0) && (s + kNfft <= n_samp) &&
-                          ((reinterpret_cast<uintptr_t>(x + s) & 7) == 0);
-    if (interior) {
-        const float2* p = reinterpret_cast<const float2*>(x + s);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = p[la + 16 * j];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int n = la + 16 * j;
-            v[j] = make_float2(x[reflect_index2(s + 2 * n, n_samp)],
-                               x[reflect_index2(s + 2 * n + 1, n_samp)]);
-        }
-    }
-}
-
-// lane la <- value of lane (16 - la) & 15 of the same quad-row (a DPP row):
-// row_mirror (la -> 15 - la) then row_ror:1
-SETK_DEV float qr_partner2(float x) {
-    int v = __builtin_bit_cast(int, x);
-    v = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
-    v = __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, true);
-    return __builtin_bit_cast(float, v);
 }
 
 // ISTFT_ONLY: Y comes from the per-item spectrogram (ud.audio reinterpreted as
@@ -154,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
             }
         } else {
             cf nxt[16];
-            load_raw(nxt, ud.audio, n_samp, t * hop - a.g.pad, la, tvalid);
+            load_raw<const float*>(nxt, ud.audio, n_samp, t * hop - a.g.pad, la, tvalid);
 #pragma unroll 1
             for (int c = 0; c < C; ++c) {
                 cf v[16];
@@ -162,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                 for (int j = 0; j < 16; ++j) v[j] = nxt[j];
                 apply_window<kRow2>(v, win_row);
                 if (c + 1 < C)
-                    load_raw(nxt, ud.audio + (size_t)(c + 1) * n_samp, n_samp, t * hop - a.g.pad,
+                    load_raw<const float*>(nxt, ud.audio + (size_t)(c + 1) * n_samp, n_samp, t * hop - a.g.pad,
                              la, tvalid);
                 fft256_stage_a_pad<-1, kRow2>(v, slot, tw_row, la);
                 __builtin_amdgcn_wave_barrier();
@@ -181,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                     const cf Zk = v[dft16_pos(m)];
                     const cf src = v[dft16_pos(15 - m)];
                     const cf own = v[dft16_pos((16 - m) & 15)];
-                    cf Zm = make_float2(qr_partner2(src.x), qr_partner2(src.y));
+                    cf Zm = make_float2(qr_partner(src.x), qr_partner(src.y));
                     Zm.x = lane0 ? own.x : Zm.x;
                     Zm.y = lane0 ? own.y : Zm.y;
                     cf Xk, Xm;
@@ -253,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
             for (int j = 8; j < 16; ++j) {
                 const cf src = Zhi[15 - j];
                 const cf own = Zhi[(16 - j) & 7];
-                cf pv = make_float2(qr_partner2(src.x), qr_partner2(src.y));
+                cf pv = make_float2(qr_partner(src.x), qr_partner(src.y));
                 v[j].x = lane0 ? own.x : pv.x;
                 v[j].y = lane0 ? own.y : pv.y;
             }

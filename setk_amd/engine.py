@@ -398,9 +398,10 @@ class CgmmEstimator(object):
     (setk_cgmm_masks_batch).  n_fft must be 512 for the device STFT used here."""
 
     def __init__(self, frame_len=512, frame_hop=256, center=True, round_power_of_two=True,
-                 window="hann", num_iters=20, device=None, ctx=None):
+                 window="hann", num_iters=20, device=None, ctx=None, update_alpha=False):
         import torch
         self.torch = torch
+        self.update_alpha = bool(update_alpha)
         if not torch.cuda.is_available():
             raise _ffi.SetkError("CgmmEstimator needs an MI355X (no CPU fallback)")
         self.ctx = ctx or _ffi.default_context(device)
@@ -433,7 +434,7 @@ class CgmmEstimator(object):
         if init_masks is not None:
             init = [0 if m is None else m.data_ptr() for m in init_masks]
         ctx.cgmm_masks_batch(C, [t.data_ptr() for t in specs], frames, F, self.num_iters, init,
-                             [t.data_ptr() for t in masks])
+                             [t.data_ptr() for t in masks], update_alpha=self.update_alpha)
         torch.cuda.current_stream().synchronize()  # specs must outlive the launches
         return masks
 

@@ -96,8 +96,6 @@ def wpe(reverb, taps=10, delay=3, context=1, num_iters=3):
 def facted_wpd(obs, cgmm_iters=10, wpd_iters=3, taps=10, delay=3, context=1, update_alpha=False):
     """Joint dereverberation & denoising (factorised WPD).  obs N x T x F ->
     (tf_mask T x F x 2, wpd_enh T x F)."""
-    if update_alpha:
-        raise _ffi.SetkUnsupported("update_alpha is not implemented in the device CGMM")
     ctx = _ffi.default_context()
     spec = np.ascontiguousarray(obs, dtype=np.complex64)  # [C][T][F]
     N, T, F = spec.shape
@@ -110,7 +108,7 @@ def facted_wpd(obs, cgmm_iters=10, wpd_iters=3, taps=10, delay=3, context=1, upd
         logger.info("Facted WPD: perform wpe...")
         der, inv_lam = _run(spec, taps, delay, context, 1, lambda_enh=enh, want_inv_lambda=True)
         logger.info("Facted WPD: mask estimation...")
-        ctx.cgmm_masks(der, N, T, F, cgmm_iters, None, gamma, mask)
+        ctx.cgmm_masks(der, N, T, F, cgmm_iters, None, gamma, mask, update_alpha=bool(update_alpha))
         logger.info("Facted WPD: perform weighted mvdr...")
         Rd = np.empty((F, N, N), dtype=np.complex64)
         Rs = np.empty((F, N, N), dtype=np.complex64)

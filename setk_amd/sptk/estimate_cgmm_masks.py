@@ -47,8 +47,14 @@ def build_parser():
 
 
 def run(args):
-    if args.num_classes != 2 or args.solve_permu or args.update_alpha:
-        raise _ffi.SetkUnsupported("only --num-classes 2 without --solve-permu/--update-alpha")
+    if args.num_classes != 2:
+        raise _ffi.SetkUnsupported("only --num-classes 2 (the reference draws the K > 2 start "
+                                   "from numpy's unseeded generator)")
+    # --solve-permu: with two classes and the deterministic start the aligner has
+    # nothing to permute between bins of the speech / noise pair the trainer keeps apart;
+    # the reference's aligner supports num_bins in its plan table only (cluster.py:40-91)
+    if args.solve_permu:
+        raise _ffi.SetkUnsupported("--solve-permu is not implemented")
     stft_kwargs = dict(frame_len=args.frame_len, frame_hop=args.frame_hop,
                        round_power_of_two=args.round_power_of_two, window=args.window,
                        center=args.center, transpose=False)
@@ -73,7 +79,8 @@ def run(args):
             if init_reader and key in init_reader:
                 init_mask = np.transpose(init_reader[key])  # T x F -> F x T
                 logger.info("Using external TF-mask to initialize cgmm")
-            trainer = CgmmTrainer(stft, args.num_classes, gamma=init_mask)
+            trainer = CgmmTrainer(stft, args.num_classes, gamma=init_mask,
+                                  update_alpha=bool(args.update_alpha))
             masks = np.transpose(trainer.train(args.num_iters), (0, 2, 1))  # K x T x F
             num_done += 1
             writer.write(key, masks[0].astype(np.float32))
@@ -92,7 +99,7 @@ def run_batched(args, shard):
     reader = WaveReader(args.wav_scp)
     est = CgmmEstimator(frame_len=args.frame_len, frame_hop=args.frame_hop,
                         center=bool(args.center), round_power_of_two=True, window=args.window,
-                        num_iters=args.num_iters,
+                        num_iters=args.num_iters, update_alpha=bool(args.update_alpha),
                         device=shard.device if shard.world > 1 else None)
     num_done = 0
     with NumpyWriter(args.dst_dir) as writer:

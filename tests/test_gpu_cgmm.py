@@ -61,6 +61,20 @@ def test_cgmm_matches_oracle(C, N, iters):
     assert np.mean(np.abs(mask - ref)) < 2e-4, np.mean(np.abs(mask - ref))
 
 
+@pytest.mark.parametrize("C,N,iters", [(6, 20000, 10), (3, 9000, 4)])
+def test_cgmm_update_alpha_matches_oracle(C, N, iters):
+    """--update-alpha: the mixture weights follow mean_t gamma (cluster.py:246-257)."""
+    from setk_amd.libs.cluster import CgmmTrainer
+    mix = o.synth_utterance(65 + C, C, N)
+    obs = o.multichannel_stft(mix, transpose=False, **STFT_KW)
+    ref = o.cgmm_gamma(obs, iters, update_alpha=True)          # K x F x T
+    fixed = o.cgmm_gamma(obs, iters, update_alpha=False)
+    gamma = CgmmTrainer(obs, 2, update_alpha=True).train(iters)
+    assert gamma.shape == ref.shape
+    assert np.mean(np.abs(gamma - ref)) < 2e-4, np.mean(np.abs(gamma - ref))
+    assert np.mean(np.abs(ref - fixed)) > 10 * np.mean(np.abs(gamma - ref))  # the option matters
+
+
 def test_cgmm_with_initial_mask():
     from setk_amd.libs.cluster import CgmmTrainer
     mix, sp, nz = o.synth_utterance(70, 5, 10000, return_parts=True)

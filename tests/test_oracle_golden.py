@@ -276,3 +276,13 @@ def test_wpe_doc_assets():
     stored = pcm_to_float(g["wpd_egs"])
     _, best = resolve_gauge(enh.T, np.max(np.abs(samps)), stored)
     assert best / rms(stored) < 1e-3, best / rms(stored)
+
+
+@pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+def test_cgmm_update_alpha_equals_live_reference():
+    libs = rh.load()
+    mix = o.synth_utterance(61, 4, 12000)
+    obs = o.multichannel_stft(mix, transpose=False, **STFT_KW)
+    for ua in (False, True):
+        ref = libs.cluster.CgmmTrainer(obs, 2, update_alpha=ua).train(5)
+        assert np.max(np.abs(o.cgmm_gamma(obs, 5, update_alpha=ua) - ref)) < 1e-9
