@@ -311,7 +311,7 @@ def cpu_allcore(args, C, N):
     except Exception:
         pass
     per = args.cpu_allcore_per_proc
-    start_at = time.time() + 20.0   # workers import numpy/scipy and synthesise first
+    start_at = time.time() + 40.0   # workers import numpy/scipy and synthesise first
     procs = [subprocess.Popen([sys.executable, "-c", _ALLCORE_WORKER, ROOT, str(i), str(per), str(C),
                                str(N), args.beamformer, repr(start_at)],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)

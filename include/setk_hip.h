@@ -120,6 +120,12 @@ int setk_istft_num_samples(setk_handle_t h, int num_frames, int nsamps);
 int setk_stft(setk_handle_t h, const float* audio, int num_channels,
               int num_samples, float* spec, void* stream);
 
+/* The same for a batch of utterances in ONE launch (device pointers, host tables;
+ * spec[u] = [C][T_u][F]; n_fft = 512 plan, C <= 8).  Asynchronous on `stream`. */
+int setk_stft_batch(setk_handle_t h, int n_utts, int num_channels,
+                    const float* const* audio, const int* num_samples,
+                    float* const* spec, void* stream);
+
 /* inverse_stft (libs/utils.py:142-173) for `batch` independent spectrograms
  * spec[B][T][F] -> wave[B][L], L = setk_istft_num_samples(h, T, nsamps).
  * norm: NULL or B floats; norm[b] > 0 rescales wave b to that max-abs

@@ -50,7 +50,7 @@ def exported_symbols():
     return [
         "setk_abi_version", "setk_create", "setk_destroy", "setk_last_error",
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
-        "setk_stft", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
+        "setk_stft", "setk_stft_batch", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
         "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
         "setk_cgmm_masks_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
@@ -86,6 +86,8 @@ def load_library():
     lib.setk_stft_num_frames.argtypes = [H, c_int]
     lib.setk_istft_num_samples.argtypes = [H, c_int, c_int]
     lib.setk_stft.argtypes = [H, fp, c_int, c_int, fp, c_void_p]
+    lib.setk_stft_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int),
+                                    POINTER(c_void_p), c_void_p]
     lib.setk_istft.argtypes = [H, fp, c_int, c_int, c_int, fp, fp, c_void_p]
     lib.setk_covar.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, c_void_p]
     lib.setk_pevd.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, fp, c_void_p]
@@ -225,6 +227,15 @@ class Context:
         self.check(
             self._lib.setk_stft(self._h, _ptr(audio), C, N, _ptr(out),
                                 current_stream_ptr() if stream is None else stream))
+
+    def stft_batch(self, C, audio_ptrs, num_samples, spec_ptrs, stream=None):
+        """One launch for the spectrograms of a batch (device addresses)."""
+        n = len(audio_ptrs)
+        A = (c_void_p * n)(*audio_ptrs)
+        S = (c_void_p * n)(*spec_ptrs)
+        NS = (c_int * n)(*[int(v) for v in num_samples])
+        self.check(self._lib.setk_stft_batch(self._h, n, int(C), A, NS, S,
+                                             current_stream_ptr() if stream is None else stream))
 
     def istft(self, spec, batch, num_frames, nsamps, norm, out, stream=None):
         self.check(

@@ -576,6 +576,51 @@ int setk_stft(setk_handle_t h, const float* audio, int num_channels, int num_sam
     return SETK_OK;
 }
 
+int setk_stft_batch(setk_handle_t h, int n_utts, int num_channels, const float* const* audio,
+                    const int* num_samples, float* const* spec, void* stream) {
+    if (!h || n_utts <= 0 || !audio || !num_samples || !spec)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    int rc = require_plan512(h);
+    if (rc) return rc;
+    const int C = num_channels;
+    if (C < 1 || C > kMaxChannels) return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h, s);
+    std::vector<UttDesc> uds(n_utts);
+    std::vector<WorkItem> items;
+    for (int u = 0; u < n_utts; ++u) {
+        const int T = setk_stft_num_frames(h, num_samples[u]);
+        if (T < 0) return T;
+        if (!audio[u] || !spec[u]) return fail(h, SETK_ERR_INVALID, "null utterance pointer");
+        UttDesc& ud = uds[u];
+        memset(&ud, 0, sizeof(ud));
+        ud.audio = audio[u];
+        ud.num_samples = num_samples[u];
+        ud.num_frames = T;
+        ud.wave_out = spec[u];
+        std::vector<std::pair<int, int>> ranges;
+        split_frames(T, 128, 32, &ranges);
+        for (auto& r : ranges) items.push_back({u, r.first, r.second, 0, r.second == T});
+    }
+    void *d_ud, *d_items;
+    rc = upload(h, uds.data(), uds.size() * sizeof(UttDesc), s, &d_ud);
+    if (rc) return rc;
+    rc = upload(h, items.data(), items.size() * sizeof(WorkItem), s, &d_items);
+    if (rc) return rc;
+    Pass1Args a;
+    memset(&a, 0, sizeof(a));
+    a.utts = static_cast<const UttDesc*>(d_ud);
+    a.items = static_cast<const WorkItem*>(d_items);
+    a.window = h->d_window;
+    a.tw256 = h->d_tw256;
+    a.tw512 = h->d_tw512;
+    a.spec_dump = nullptr;  // per-utterance outputs: UttDesc::wave_out
+    a.g = geom_of(h);
+    HIP_TRY(h, launch_pass1(C, true, a, (int)items.size(), s));
+    return SETK_OK;
+}
+
 int setk_istft(setk_handle_t h, const float* spec, int batch, int num_frames, int nsamps,
                const float* norm, float* wave, void* stream) {
     if (!h || !spec || !wave || batch <= 0 || num_frames <= 0)

@@ -283,8 +283,11 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
                     const int tt = i / C, c = i - tt * C;
                     const int t = tb + tt;
                     if (t < wi.t1) {
-                        float2* dst =
-                            reinterpret_cast<float2*>(a.spec_dump) + ((size_t)c * T + t) * F;
+                        // one spectrogram (setk_stft) or one per utterance (setk_stft_batch:
+                        // the descriptor's output pointer)
+                        float2* base = a.spec_dump ? reinterpret_cast<float2*>(a.spec_dump)
+                                                   : reinterpret_cast<float2*>(ud.wave_out);
+                        float2* dst = base + ((size_t)c * T + t) * F;
                         dst[f] = xt[i * SL + f];
                         if (f == 0) dst[256] = make_float2(xn[i], 0.f);
                     }

@@ -425,11 +425,12 @@ class CgmmEstimator(object):
         specs, masks, frames = [], [], []
         for a in audio:
             T = ctx.num_frames(a.shape[1])
-            sp = torch.empty((C, T, F), dtype=torch.complex64, device=dev)
-            ctx.stft(a, sp)
-            specs.append(sp)
+            specs.append(torch.empty((C, T, F), dtype=torch.complex64, device=dev))
             masks.append(torch.empty((T, F), dtype=torch.float32, device=dev))
             frames.append(T)
+        # all spectrograms in one launch
+        ctx.stft_batch(C, [a.data_ptr() for a in audio], [a.shape[1] for a in audio],
+                       [t.data_ptr() for t in specs])
         init = None
         if init_masks is not None:
             init = [0 if m is None else m.data_ptr() for m in init_masks]
