@@ -42,7 +42,7 @@ def test_doc_pipeline_mask_and_pmwf_golden():
           f"{undecided.mean():.1%} of all cells are undecided)")
     assert d.mean() < 1e-4
     assert d.max() < 2e-2
-    assert big.mean() < 2e-3 and (big & ~undecided).sum() <= 0.2 * max(big.sum(), 1)
+    assert big.mean() < 5e-3 and (big & ~undecided).sum() <= 0.2 * max(big.sum(), 1)
     (wav, st), = BatchEnhancer(beamformer="pmwf-0", pcm16=True).enhance([(samps, mask, None)])
     assert st == 0
     stored = doc["pmwf_0"].astype(np.float64)
