@@ -219,15 +219,23 @@ def test_cli_options_vad_postmask_itf_online(tmp_path):
         "vad": (["--vad-proportion", "0.9", "--post-masking", "true", "--ban", "true"],
                 dict(vad_proportion=0.9, post_mask=True, ban=True)),
         "itf": (["--itf-mask", os.path.join(td, "itf.scp")], dict(itf_mask=itf)),
+        # MPDR kinds with an interferer mask at the default transform size: mpdr never
+        # reads the mask (fused path), mpdr-whiten takes Rn from it (stand-alone operators)
+        "mpdr_itf": (["--beamformer", "mpdr", "--itf-mask", os.path.join(td, "itf.scp")],
+                     dict(kind="mpdr", itf_mask=itf)),
+        "mpdrw_itf": (["--beamformer", "mpdr-whiten", "--itf-mask", os.path.join(td, "itf.scp")],
+                      dict(kind="mpdr-whiten", itf_mask=itf)),
     }
     for name, (extra, okw) in cases.items():
+        okw = dict(okw)
+        kind = okw.pop("kind", "mvdr")
         dst = os.path.join(td, name)
         r = subprocess.run(base + extra + [os.path.join(td, "wav.scp"),
                                            os.path.join(td, "mask.scp"), dst],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         sr, y = scipy.io.wavfile.read(os.path.join(dst, "u0.wav"))
-        ref = o.enhance_utterance(samps, mask, kind="mvdr", gauge=True, **okw)
+        ref = o.enhance_utterance(samps, mask, kind=kind, gauge=True, **okw)
         assert pcm16_rel_rms(y, ref) < 1e-3, (name, pcm16_rel_rms(y, ref))
     # block-online mode runs (the reference's raises TypeError) and is sane
     dst = os.path.join(td, "online")
