@@ -95,6 +95,15 @@ int setk_destroy(setk_handle_t h);
 /* text of the last error on this handle (never NULL) */
 const char* setk_last_error(setk_handle_t h);
 
+/* ---- host-memory plumbing (used by the streaming host pipeline) -----------
+ * Pin an existing host range (e.g. the mmap of a wave file in the page cache) so
+ * that setk_memcpy_h2d_async DMAs straight out of it, and release it again once
+ * the copy has completed.  Thread safe; independent of the handle's arena. */
+int setk_host_register(setk_handle_t h, void* ptr, size_t bytes);
+int setk_host_unregister(setk_handle_t h, void* ptr);
+int setk_memcpy_h2d_async(setk_handle_t h, void* dst, const void* src, size_t bytes,
+                          void* stream);
+
 /* ---- STFT plan ---------------------------------------------------------
  * Mirrors the arguments of forward_stft / inverse_stft
  * (scripts/sptk/libs/utils.py:96-173) after the host resolved

@@ -49,6 +49,7 @@ def exported_symbols():
     """Names declared in include/setk_hip.h (checked by the CPU test-suite)."""
     return [
         "setk_abi_version", "setk_create", "setk_destroy", "setk_last_error",
+        "setk_host_register", "setk_host_unregister", "setk_memcpy_h2d_async",
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_stft_batch", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
         "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
@@ -80,6 +81,9 @@ def load_library():
     lib.setk_destroy.argtypes = [H]
     lib.setk_last_error.argtypes = [H]
     lib.setk_last_error.restype = c_char_p
+    lib.setk_host_register.argtypes = [H, c_void_p, ctypes.c_size_t]
+    lib.setk_host_unregister.argtypes = [H, c_void_p]
+    lib.setk_memcpy_h2d_async.argtypes = [H, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]
     lib.setk_set_profiling.argtypes = [H, c_int]
     lib.setk_last_stage_ms.argtypes = [H, POINTER(c_float)]
     lib.setk_stft_plan.argtypes = [H, c_int, c_int, c_int, c_int, fp]
@@ -190,6 +194,18 @@ class Context:
         if rc == ERR_UNSUPPORTED:
             raise SetkUnsupported(msg)
         raise SetkError(f"libsetk_hip error {rc}: {msg}")
+
+    # -- host-memory plumbing (thread safe) -----------------------------------
+    def host_register(self, ptr, nbytes):
+        """Pin [ptr, ptr + nbytes); returns False when the runtime refuses the range."""
+        return self._lib.setk_host_register(self._h, c_void_p(int(ptr)), int(nbytes)) == SETK_OK
+
+    def host_unregister(self, ptr):
+        self._lib.setk_host_unregister(self._h, c_void_p(int(ptr)))
+
+    def memcpy_h2d_async(self, dst, src, nbytes, stream):
+        self.check(self._lib.setk_memcpy_h2d_async(self._h, c_void_p(int(dst)), c_void_p(int(src)),
+                                                   int(nbytes), stream))
 
     # -- plan ---------------------------------------------------------------
     def stft_plan(self, frame_len, frame_hop, n_fft, center, window=None):

@@ -72,6 +72,10 @@ _OPTIONS = (
                            help="[setk_amd] streaming host pipeline (pinned staging, read / "
                                 "H2D / compute / D2H / write overlapped); false: one batch "
                                 "at a time")),
+    (("--zero-copy",), dict(default=True, type=lambda v: str(v).lower() in ("true", "1", "yes"),
+                            help="[setk_amd] DMA wave / mask payloads straight out of the page "
+                                 "cache (mmap + hipHostRegister); false: stage them through "
+                                 "page-locked slabs")),
     (("--pipeline-depth",), dict(default=3, type=int,
                                  help="[setk_amd] batches in flight in the host pipeline")),
     (("--read-threads",), dict(default=0, type=int,
@@ -242,7 +246,8 @@ def _run_pipeline(args, engine, writer, wav_reader, tgt, itf, keys):
         return True
 
     pipe = StreamPipeline(engine, sink, announce=announce, batch_utts=args.batch_utts,
-                          depth=args.pipeline_depth, read_threads=args.read_threads or None)
+                          depth=args.pipeline_depth, read_threads=args.read_threads or None,
+                          zero_copy=args.zero_copy)
     wide = []  # more than 8 channels: stand-alone operators, after the pipeline drained
     try:
         for key in keys:
