@@ -89,7 +89,7 @@ class Payload(object):
 
     def zero_copy_ok(self):
         """The payload is (nearly) the whole file: worth pinning the file's pages."""
-        return (self.array is None and self.fsize > 0 and self.nbytes >= (256 << 10) and
+        return (self.array is None and self.fsize > 0 and self.nbytes >= (32 << 10) and
                 self.fsize - self.nbytes <= (64 << 10))
 
     def load_into(self, dst):
