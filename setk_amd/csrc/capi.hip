@@ -168,6 +168,11 @@ int copy_back(setk_handle_t h, const OutBuf& ob, hipStream_t s) {
     return SETK_OK;
 }
 
+// Descriptor tables are built in ordinary (pageable) host vectors that die when
+// the entry point returns.  hipMemcpyAsync from pageable memory is staged by the
+// runtime before it returns (the documented behaviour of cudaMemcpyAsync /
+// hipMemcpyAsync for non-page-locked sources), so the source may be released;
+// only the device side of the copy is asynchronous.
 int upload(setk_handle_t h, const void* src, size_t bytes, hipStream_t s, void** out) {
     void* d = arena_alloc(h, bytes);
     if (!d) return fail(h, SETK_ERR_NOMEM, "device arena allocation failed");

@@ -11,13 +11,14 @@ side is organised as a pipeline with every stage overlapped:
 
   plan      (caller's thread)  wave / mask headers only: channels, samples, frames,
                                payload offsets -> byte offsets inside a slab
-  read+H2D  (thread pool,      zero copy: the file is mmap'ed, its page-cache pages are
-             copy-in stream)   pinned (hipHostRegister, 0.23 ms per 7.7 MB) and the wav's
-                               16-bit frames / the mask's float32 rows are DMA'd from where
-                               they lie (52 GB/s) -- no host copy at all.  Payloads that are a
-                               slice of a big archive, and arrays decoded on the host, are
-                               staged through the slot's page-locked slab (preadv / memcpy)
-                               and copied from there.
+  read+H2D  (thread pool,      os.preadv of the payload into the slot's page-locked slab --
+             copy-in stream)   the wav's 16-bit frames and the mask's float32 rows exactly as
+                               stored, no host conversion -- and an async copy of that slice.
+                               Option zero_copy: mmap the file, pin its page-cache pages
+                               (hipHostRegister) and DMA from where they lie; alone that is
+                               0.23 ms + 52 GB/s per 7.7 MB file, inside the pipeline it
+                               measured slower than staging (memory-map lock), so it is off
+                               by default.
   compute   (compute stream)   setk_pcm16_to_float_batch + setk_enhance_batch, status
                                and PCM16 output written into the device out-slab
   D2H       (copy-out stream)  ONE hipMemcpyAsync per batch
@@ -275,7 +276,7 @@ class StreamPipeline(object):
     """
 
     def __init__(self, engine, sink, announce=None, batch_utts=32, depth=3, read_threads=None,
-                 write_threads=4, slab_mb=0, zero_copy=True):
+                 write_threads=4, slab_mb=0, zero_copy=False):
         import torch
         self.torch = torch
         self.engine = engine

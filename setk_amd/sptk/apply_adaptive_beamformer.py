@@ -72,10 +72,11 @@ _OPTIONS = (
                            help="[setk_amd] streaming host pipeline (pinned staging, read / "
                                 "H2D / compute / D2H / write overlapped); false: one batch "
                                 "at a time")),
-    (("--zero-copy",), dict(default=True, type=lambda v: str(v).lower() in ("true", "1", "yes"),
+    (("--zero-copy",), dict(default=False, type=lambda v: str(v).lower() in ("true", "1", "yes"),
                             help="[setk_amd] DMA wave / mask payloads straight out of the page "
-                                 "cache (mmap + hipHostRegister); false: stage them through "
-                                 "page-locked slabs")),
+                                 "cache (mmap + hipHostRegister) instead of staging them through "
+                                 "page-locked slabs (measured slower inside the pipeline: "
+                                 "profiles/r02l_e2e_zero_copy_sweep.txt)")),
     (("--pipeline-depth",), dict(default=3, type=int,
                                  help="[setk_amd] batches in flight in the host pipeline")),
     (("--read-threads",), dict(default=0, type=int,

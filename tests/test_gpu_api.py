@@ -484,7 +484,8 @@ def test_streaming_pipeline_equals_batch_path(tmp_path):
     a = run(f"{td}/pipe", "numpy", f"{td}/mask.scp", "--profile", f"{td}/prof.json")
     b = run(f"{td}/batch", "numpy", f"{td}/mask.scp", "--pipeline", "false")
     c = run(f"{td}/kaldi", "kaldi", f"{td}/ark.scp")
-    d = run(f"{td}/staged", "numpy", f"{td}/mask.scp", "--zero-copy", "false")
+    d = run(f"{td}/zc", "numpy", f"{td}/mask.scp", "--zero-copy", "true", "--profile",
+            f"{td}/prof_zc.json")
     assert not os.path.exists(f"{td}/pipe/utt8.wav")
     for k, ref in refs.items():
         assert a[k].dtype == np.int16 and np.array_equal(a[k], b[k]), k
@@ -493,5 +494,6 @@ def test_streaming_pipeline_equals_batch_path(tmp_path):
     import json
     prof = json.load(open(f"{td}/prof.json"))
     assert prof["mode"] == "pipeline" and prof["utts"] == 8 and prof["stages"]["batches"] >= 3
-    # PCM16 wavs and float32 C-ordered masks went out of the page cache without a host copy
-    assert prof["stages"]["zero_copy_payloads"] >= 8
+    # --zero-copy: PCM16 wavs and float32 C-ordered masks leave the page cache without a host copy
+    assert json.load(open(f"{td}/prof_zc.json"))["stages"]["zero_copy_payloads"] >= 8
+    assert prof["stages"]["zero_copy_payloads"] == 0
