@@ -130,10 +130,12 @@ int setk_stft(setk_handle_t h, const float* audio, int num_channels,
               int num_samples, float* spec, void* stream);
 
 /* The same for a batch of utterances in ONE launch (device pointers, host tables;
- * spec[u] = [C][T_u][F]; n_fft = 512 plan, C <= 8).  Asynchronous on `stream`. */
+ * spec[u] = [C][T_u][spec_pitch], F entries used per row; spec_pitch = 0 means F, a
+ * multiple of 16 entries keeps every row 128-byte aligned for a streaming consumer;
+ * n_fft = 512 plan, C <= 8).  Asynchronous on `stream`. */
 int setk_stft_batch(setk_handle_t h, int n_utts, int num_channels,
                     const float* const* audio, const int* num_samples,
-                    float* const* spec, void* stream);
+                    float* const* spec, int spec_pitch, void* stream);
 
 /* inverse_stft (libs/utils.py:142-173) for `batch` independent spectrograms
  * spec[B][T][F] -> wave[B][L], L = setk_istft_num_samples(h, T, nsamps).
@@ -216,12 +218,12 @@ int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int nu
                     float* mask_out, int flags, void* stream);
 
 /* Batched form: n_utts utterances per EM stage launch (device pointers only;
- * spec[u] = [C][num_frames[u]][F], mask_out[u] = [num_frames[u]][F], init_mask
- * NULL or per-utterance NULL-able table).  Asynchronous on `stream`. */
+ * spec[u] = [C][num_frames[u]][spec_pitch] (0 = F), mask_out[u] = [num_frames[u]][F],
+ * init_mask NULL or per-utterance NULL-able table).  Asynchronous on `stream`. */
 int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
                           const float* const* spec, const int* num_frames, int num_bins,
                           int num_iters, const float* const* init_mask, float* const* mask_out,
-                          int flags, void* stream);
+                          int flags, int spec_pitch, void* stream);
 
 /* directional_feats (libs/spatial.py:184-208, compute_df_on_mask.py:40-54):
  * out[t][f] = mean over the n_pairs microphone pairs (i, j) = (pairs[2p],

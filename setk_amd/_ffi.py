@@ -91,7 +91,7 @@ def load_library():
     lib.setk_istft_num_samples.argtypes = [H, c_int, c_int]
     lib.setk_stft.argtypes = [H, fp, c_int, c_int, fp, c_void_p]
     lib.setk_stft_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int),
-                                    POINTER(c_void_p), c_void_p]
+                                    POINTER(c_void_p), c_int, c_void_p]
     lib.setk_istft.argtypes = [H, fp, c_int, c_int, c_int, fp, fp, c_void_p]
     lib.setk_covar.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, c_void_p]
     lib.setk_pevd.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, fp, c_void_p]
@@ -106,7 +106,7 @@ def load_library():
     lib.setk_cgmm_masks.argtypes = [H, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, c_void_p]
     lib.setk_cgmm_masks_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int), c_int,
                                           c_int, POINTER(c_void_p), POINTER(c_void_p), c_int,
-                                          c_void_p]
+                                          c_int, c_void_p]
     lib.setk_enhance_batch.argtypes = [
         H, POINTER(BfOpts), c_int, c_int, POINTER(c_void_p), POINTER(c_int),
         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int),
@@ -244,13 +244,13 @@ class Context:
             self._lib.setk_stft(self._h, _ptr(audio), C, N, _ptr(out),
                                 current_stream_ptr() if stream is None else stream))
 
-    def stft_batch(self, C, audio_ptrs, num_samples, spec_ptrs, stream=None):
+    def stft_batch(self, C, audio_ptrs, num_samples, spec_ptrs, stream=None, spec_pitch=0):
         """One launch for the spectrograms of a batch (device addresses)."""
         n = len(audio_ptrs)
         A = (c_void_p * n)(*audio_ptrs)
         S = (c_void_p * n)(*spec_ptrs)
         NS = (c_int * n)(*[int(v) for v in num_samples])
-        self.check(self._lib.setk_stft_batch(self._h, n, int(C), A, NS, S,
+        self.check(self._lib.setk_stft_batch(self._h, n, int(C), A, NS, S, int(spec_pitch),
                                              current_stream_ptr() if stream is None else stream))
 
     def istft(self, spec, batch, num_frames, nsamps, norm, out, stream=None):
@@ -322,7 +322,7 @@ class Context:
                                       current_stream_ptr() if stream is None else stream))
 
     def cgmm_masks_batch(self, C, spec_ptrs, num_frames, F, num_iters, init_ptrs, out_ptrs,
-                         stream=None, update_alpha=False):
+                         stream=None, update_alpha=False, spec_pitch=0):
         n = len(spec_ptrs)
         S = (c_void_p * n)(*spec_ptrs)
         O = (c_void_p * n)(*out_ptrs)
@@ -330,7 +330,7 @@ class Context:
         T = (c_int * n)(*[int(v) for v in num_frames])
         self.check(
             self._lib.setk_cgmm_masks_batch(self._h, n, int(C), S, T, int(F), int(num_iters), I, O,
-                                            CGMM_UPDATE_ALPHA if update_alpha else 0,
+                                            CGMM_UPDATE_ALPHA if update_alpha else 0, int(spec_pitch),
                                             current_stream_ptr() if stream is None else stream))
 
     # -- fused hot path ---------------------------------------------------------

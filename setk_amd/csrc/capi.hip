@@ -615,7 +615,8 @@ int setk_stft(setk_handle_t h, const float* audio, int num_channels, int num_sam
 }
 
 int setk_stft_batch(setk_handle_t h, int n_utts, int num_channels, const float* const* audio,
-                    const int* num_samples, float* const* spec, void* stream) {
+                    const int* num_samples, float* const* spec, int spec_pitch, void* stream) {
+    if (spec_pitch != 0 && spec_pitch < kBins) return fail(h, SETK_ERR_INVALID, "spec_pitch < F");
     if (!h || n_utts <= 0 || !audio || !num_samples || !spec)
         return fail(h, SETK_ERR_INVALID, "bad args");
     int rc = require_plan512(h);
@@ -654,6 +655,7 @@ int setk_stft_batch(setk_handle_t h, int n_utts, int num_channels, const float* 
     a.tw256 = h->d_tw256;
     a.tw512 = h->d_tw512;
     a.spec_dump = nullptr;  // per-utterance outputs: UttDesc::wave_out
+    a.dump_pitch = spec_pitch;
     a.g = geom_of(h);
     HIP_TRY(h, launch_pass1(C, true, a, (int)items.size(), s));
     return SETK_OK;
@@ -1021,7 +1023,8 @@ int setk_beamform(setk_handle_t h, const float* weight, const float* spec, int n
 int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
                           const float* const* spec, const int* num_frames, int num_bins,
                           int num_iters, const float* const* init_mask, float* const* mask_out,
-                          int flags, void* stream) {
+                          int flags, int spec_pitch, void* stream) {
+    if (spec_pitch != 0 && spec_pitch < num_bins) return fail(h, SETK_ERR_INVALID, "spec_pitch < F");
     if (!h || n_utts <= 0 || !spec || !num_frames || !mask_out || num_bins <= 0 || num_iters < 0)
         return fail(h, SETK_ERR_INVALID, "bad args");
     if (num_channels < 1 || num_channels > kMaxChannels)
@@ -1045,7 +1048,7 @@ int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
         if (!scr) return fail(h, SETK_ERR_NOMEM, "arena");
         cgmm_fill_args(tbl.data() + (size_t)u * ab, C, spec[u], T, F,
                        init_mask ? init_mask[u] : nullptr, nullptr, mask_out[u], scr,
-                       (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0);
+                       (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0, spec_pitch);
     }
     void* d_tbl;
     int rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
@@ -1118,7 +1121,7 @@ int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int nu
     if (!d_scr) return fail(h, SETK_ERR_NOMEM, "arena");
     std::vector<char> tbl(cgmm_args_bytes());
     cgmm_fill_args(tbl.data(), C, d_spec, T, F, d_init, d_gamma, static_cast<float*>(om.dev), d_scr,
-                   (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0);
+                   (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0, 0);
     void* d_tbl;
     rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
     if (rc) return rc;

@@ -37,7 +37,7 @@ constexpr float kEps32 = 1.1920928955078125e-07f;
 constexpr int kCgInitId = 0, kCgInitMask = 1, kCgEm = 2;
 
 struct CgmmArgs {
-    const cf* spec;          // [C][T][F]
+    const cf* spec;          // [C][T][spitch], F entries used per row
     float* gamma;            // [2][T][F]
     float* phi;              // [2][T][F]
     const float* init_mask;  // [T][F] or null
@@ -49,6 +49,7 @@ struct CgmmArgs {
     float* mask_out;         // [T][F] or null (last E-step)
     float* alpha;            // [2][F] mixture weights (1/2 unless update_alpha, cluster.py:254-257)
     int T, F, pitch, nchunks, tchunk, mode, update_alpha;
+    int spitch;              // row pitch of spec in complex entries (F, or padded to 128 bytes)
 };
 
 // ---- M-step: weighted outer products, 32 bins x 2 classes per wavefront ----
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(64) void cgmm_accum_kernel(const CgmmArgs* __restri
             sumg += g;
             cf x[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) x[c] = a.spec[((size_t)c * T + t) * F + f];
+            for (int c = 0; c < C; ++c) x[c] = a.spec[((size_t)c * T + t) * a.spitch + f];
             int e = 0;
 #pragma unroll
             for (int i = 0; i < C; ++i)
@@ -280,14 +281,14 @@ __global__ __launch_bounds__(64) void cgmm_estep_kernel(const CgmmArgs* __restri
     // the next frame's bins are requested one iteration ahead
     cf xn[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) xn[c] = a.spec[((size_t)c * T + min(t0, T - 1)) * F + fc];
+    for (int c = 0; c < C; ++c) xn[c] = a.spec[((size_t)c * T + min(t0, T - 1)) * a.spitch + fc];
     for (int t = t0; t < t1; ++t) {
         cf x[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) x[c] = xn[c];
         if (t + 1 < t1) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) xn[c] = a.spec[((size_t)c * T + t + 1) * F + fc];
+            for (int c = 0; c < C; ++c) xn[c] = a.spec[((size_t)c * T + t + 1) * a.spitch + fc];
         }
         float q = 0.f;
 #pragma unroll
@@ -363,7 +364,7 @@ static hipError_t cgmm_run_t(const CgmmArgs* d_tbl, int n_utts, int F, int max_c
 // (gamma, phi included).  Returns bytes used.
 size_t cgmm_fill_args(void* args_out, int C, const float* spec, int T, int F,
                       const float* init_mask, float* gamma_opt, float* mask_out, void* scratch,
-                      int update_alpha) {
+                      int update_alpha, int spec_pitch) {
     const int NP = npairs(C);
     CgmmArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -391,6 +392,7 @@ size_t cgmm_fill_args(void* args_out, int C, const float* spec, int T, int F,
     a.logdet = reinterpret_cast<float*>(take((size_t)2 * F * 4));
     a.alpha = reinterpret_cast<float*>(take((size_t)2 * F * 4));
     a.update_alpha = update_alpha;
+    a.spitch = spec_pitch > 0 ? spec_pitch : F;
     std::memcpy(args_out, &a, sizeof(a));
     return (size_t)(p - static_cast<char*>(scratch));
 }

@@ -63,6 +63,7 @@ struct Pass1Args {
     const float2* tw512;    // [129]     exp(-2 pi i k / 512)
     unsigned* norm_bits;    // [n_utts] max |audio| as float bits (atomicMax)
     float* spec_dump;       // DUMP mode: [C][T][F]
+    int dump_pitch;         // DUMP mode: row pitch in complex entries (0 = F)
     StftGeom g;
     int flags;
 };
@@ -151,7 +152,7 @@ hipError_t launch_istft_generic(const float* spec, int B, int T, int n_fft, int 
                                 hipStream_t s);
 size_t cgmm_fill_args(void* args_out, int C, const float* spec, int T, int F,
                       const float* init_mask, float* gamma_opt, float* mask_out, void* scratch,
-                      int update_alpha);
+                      int update_alpha, int spec_pitch);
 size_t cgmm_args_bytes();
 size_t cgmm_scratch_bytes(int C, int T, int F);
 hipError_t launch_cgmm_batch(int C, const void* d_tbl, int n_utts, int F, int max_frames,

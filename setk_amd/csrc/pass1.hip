@@ -287,7 +287,7 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
                         // the descriptor's output pointer)
                         float2* base = a.spec_dump ? reinterpret_cast<float2*>(a.spec_dump)
                                                    : reinterpret_cast<float2*>(ud.wave_out);
-                        float2* dst = base + ((size_t)c * T + t) * F;
+                        float2* dst = base + ((size_t)c * T + t) * (a.dump_pitch ? a.dump_pitch : F);
                         dst[f] = xt[i * SL + f];
                         if (f == 0) dst[256] = make_float2(xn[i], 0.f);
                     }

@@ -423,19 +423,23 @@ class CgmmEstimator(object):
         self._plan()
         C = audio[0].shape[0]
         specs, masks, frames = [], [], []
+        # rows padded to 128 bytes: the EM kernels stream 32-bin (256-byte) segments per
+        # wavefront and a 2056-byte row pitch makes every segment straddle an extra line
+        Fp = (F + 15) // 16 * 16
         for a in audio:
             T = ctx.num_frames(a.shape[1])
-            specs.append(torch.empty((C, T, F), dtype=torch.complex64, device=dev))
+            specs.append(torch.empty((C, T, Fp), dtype=torch.complex64, device=dev))
             masks.append(torch.empty((T, F), dtype=torch.float32, device=dev))
             frames.append(T)
         # all spectrograms in one launch
         ctx.stft_batch(C, [a.data_ptr() for a in audio], [a.shape[1] for a in audio],
-                       [t.data_ptr() for t in specs])
+                       [t.data_ptr() for t in specs], spec_pitch=Fp)
         init = None
         if init_masks is not None:
             init = [0 if m is None else m.data_ptr() for m in init_masks]
         ctx.cgmm_masks_batch(C, [t.data_ptr() for t in specs], frames, F, self.num_iters, init,
-                             [t.data_ptr() for t in masks], update_alpha=self.update_alpha)
+                             [t.data_ptr() for t in masks], update_alpha=self.update_alpha,
+                             spec_pitch=Fp)
         torch.cuda.current_stream().synchronize()  # specs must outlive the launches
         return masks
 
