@@ -17,7 +17,9 @@ independently: RCCL carries only the barriers and the max-over-ranks reduction.
 
 Outside the timed K steps (and reported in the same JSON line, N = 1 only unless
 noted): `sustained` (every rank keeps stepping for a few seconds so that an
-external GPU-busy sampler sees the run), `full_batch` (all 1000 utterances of
+external GPU-busy sampler sees the run), `uncached_call` (the step with new buffer
+addresses and a status read-back every call: the timed steps reuse one descriptor
+block and skip the read-back), `full_batch` (all 1000 utterances of
 configs[2] on the one GPU: the strong-scaling anchor), `cpu_baseline` (one core,
 all cores in the reference's process-per-shard mode, and the oracle check of the
 timed configuration's output) and `end_to_end` (disk -> wav through the CLI).
@@ -178,6 +180,31 @@ def main():
             torch.cuda.synchronize()
             n_sus += 50
         sustained = {"steps": n_sus, "ms_per_step": round(1e3 * (time.perf_counter() - t0) / n_sus, 4)}
+    # (a') the same step as a caller sees it who does NOT repeat himself: the utterance
+    #      tables alternate between two sets of buffers (so the descriptor block is rebuilt
+    #      and uploaded every call) and the per-utterance status words are read back
+    fresh = None
+    if rank == 0:
+        audio_b = [t.clone() for t in audio]
+        masks_b = [t.clone() for t in masks]
+        waves_b = [torch.empty(L, dtype=torch.float32, device=dev) for _ in range(U)]
+        sets = [(aptr, mptr, wptr),
+                ([t.data_ptr() for t in audio_b], [t.data_ptr() for t in masks_b],
+                 [t.data_ptr() for t in waves_b])]
+        for i in range(4):
+            ctx.enhance_batch(opts, C, sets[i & 1][0], ns, sets[i & 1][1], None, sets[i & 1][2],
+                              want_status=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kf = 20
+        for i in range(kf):
+            ctx.enhance_batch(opts, C, sets[i & 1][0], ns, sets[i & 1][1], None, sets[i & 1][2],
+                              want_status=True)
+        torch.cuda.synchronize()
+        fresh = {"steps": kf, "ms_per_step": round(1e3 * (time.perf_counter() - t0) / kf, 4),
+                 "what": "new buffer addresses every call (descriptors rebuilt + uploaded), "
+                         "status words read back (one stream synchronisation per call)"}
+        del audio_b, masks_b, waves_b
     # one output of the timed configuration, for the oracle check in cpu_baseline()
     wave0 = waves[0].cpu().numpy() if rank == 0 else None
     # (b) strong-scaling anchor: the whole configs[2] batch on this one GPU
@@ -240,6 +267,8 @@ def main():
         }
         if sustained is not None:
             out["sustained"] = sustained
+        if fresh is not None:
+            out["uncached_call"] = fresh
         if full_batch is not None:
             out["full_batch"] = full_batch
         if world == 1 and args.cpu_sample > 0:
