@@ -11,7 +11,16 @@ constexpr int kBins = 257;        // n_fft / 2 + 1
 constexpr int kBinsPad = 264;     // row pitch of per-bin planes (multiple of 8)
 constexpr int kMaxChannels = 8;   // register-resident covariance accumulators
 constexpr int kMaxChannels16 = 16; // modular (unfused) operators: covariance, solve, beamform
-constexpr int kSuperTile = 16;    // frames per inverse-transform batch (pass 2)
+// pass 2: frames per super-tile = quad-rows per workgroup (16 lanes each) and the
+// waves per SIMD its register budget is set for (tools/mk_abl.sh -DSETK_P2_ST=.. -DSETK_P2_WAVES=..)
+#ifndef SETK_P2_ST
+#define SETK_P2_ST 16
+#endif
+#ifndef SETK_P2_WAVES
+#define SETK_P2_WAVES 2
+#endif
+constexpr int kSuperTile = SETK_P2_ST;    // frames per inverse-transform batch (pass 2)
+constexpr int kPass2Threads = 16 * kSuperTile;
 constexpr int kMaxKeep = 7;       // ceil(512 / hop) - 1 for hop >= 64
 
 // number of Hermitian pairs (i <= j)

@@ -20,7 +20,23 @@
 
 namespace setk {
 
-constexpr int kRow2 = 18;  // LDS row stride of this pass: 16-byte aligned rows, b128 reads (fft512.h)
+// LDS row stride of this pass: 18 = 16-byte aligned rows, b128 reads (fft512.h), the
+// product at 256 VGPRs; 17 = the 8-byte form pass 1 uses, for tighter register budgets
+#ifndef SETK_P2_ROW
+#define SETK_P2_ROW 18
+#endif
+constexpr int kRow2 = SETK_P2_ROW;
+
+// N consecutive entries of a lane's table row (contiguous for even ROW, 16 apart for odd)
+template <int N>
+SETK_DEV void load_tab(const cf* row, cf (&out)[N]) {
+    if (LaneTab<kRow2>::rows) {
+        lds_row<N, true>(row, out);
+    } else {
+#pragma unroll
+        for (int n = 0; n < N; ++n) out[n] = row[n * 16];
+    }
+}
 
 // LDS plan (bytes): slots (16+keep)*2304 (padded 16x16 transpose) | wtab C*257*8 (BF mode) |
 // per-lane table rows (window, twiddles; fft512.h) | winsq 2048 | red 16
@@ -39,7 +55,8 @@ size_t pass2_lds_bytes(int C, int keep) {
 // inverse-transforms and leaves the windowed frame in its LDS slot.  Nothing in
 // that chain needs a workgroup barrier; only the overlap-add does.
 template <int C, bool ISTFT_ONLY>
-__global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
+__global__ __launch_bounds__(kPass2Threads, SETK_P2_WAVES) void beamform_istft_kernel(Pass2Args a) {
+    constexpr int NT = kPass2Threads;
     constexpr int F = kBins;
     constexpr int ST = kSuperTile;
 
@@ -51,8 +68,8 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
     cf* wtab = reinterpret_cast<cf*>(p);  // [C][257]
     p += ((size_t)C * F * sizeof(cf) + 15) & ~(size_t)15;
     cf* win_l = reinterpret_cast<cf*>(p);  // per-lane table rows (synthesis window ==
-    cf* tw_l = win_l + 16 * kRow2;          // analysis window)
-    cf* tw5_l = tw_l + 16 * kRow2;
+    cf* tw_l = win_l + LaneTab<kRow2>::size;  // analysis window)
+    cf* tw5_l = tw_l + LaneTab<kRow2>::size;
     p += table_entries(kRow2) * sizeof(cf);
     float* winsq = reinterpret_cast<float*>(p);
     p += 2048;
@@ -69,14 +86,14 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
     const bool post_mask = (a.flags & 0x4) != 0;
     const bool clamp = (a.flags & 0x2) != 0;
 
-    fill_lane_tables<kRow2>(win_l, tw_l, tw5_l, a.window, a.tw256, a.tw512, tid, 256);
-    for (int i = tid; i < kNfft; i += 256) winsq[i] = a.winsq[i];
-    const cf* win_row = win_l + la * kRow2;
-    const cf* tw_row = tw_l + la * kRow2;
-    const cf* tw5_row = tw5_l + la * kRow5;
+    fill_lane_tables<kRow2>(win_l, tw_l, tw5_l, a.window, a.tw256, a.tw512, tid, NT);
+    for (int i = tid; i < kNfft; i += NT) winsq[i] = a.winsq[i];
+    const cf* win_row = win_l + la * LaneTab<kRow2>::lstride;
+    const cf* tw_row = tw_l + la * LaneTab<kRow2>::lstride;
+    const cf* tw5_row = tw5_l + la * LaneTab<kRow2>::lstride5;
     if (!ISTFT_ONLY) {
         const cf* wsrc = reinterpret_cast<const cf*>(a.weight) + (size_t)wi.utt * C * kBinsPad;
-        for (int i = tid; i < C * F; i += 256) {
+        for (int i = tid; i < C * F; i += NT) {
             const int c = i / F, f = i - c * F;
             wtab[i] = wsrc[c * kBinsPad + f];
         }
@@ -85,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
 
     // frames needed to complete the first output position of this range
     const int t_first = max(wi.t0 - keep, 0);
-    for (int i = tid; i < keep * SL; i += 256) slots[i] = make_float2(0.f, 0.f);
+    for (int i = tid; i < keep * SL; i += NT) slots[i] = make_float2(0.f, 0.f);
 
     for (int ts = t_first; ts < wi.t1; ts += ST) {
         cf* slot = slots + (keep + grp) * SL;  // this quad-row's frame slot
@@ -133,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
                 const cf* wlo = wc + la;
                 const cf* wmir = wc + (256 - 16 * 7) - la;
                 cf t5[8];
-                lds_row<8>(tw5_row, t5);
+                load_tab<8>(tw5_row, t5);
                 // Hermitian split in registers: the mirror bin of k = la + 16 m is
                 // register 15 - m of lane (16 - la) & 15 (lane 0: own register 16 - m)
 #pragma unroll
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
         // ---- optional post-mask, merge into the packed inverse input (registers) ----
         cf Zlo[8], Zhi[8];  // 2 Z'[la + 16 m] and 2 Z'[256 - (la + 16 m)]
         cf t5m[8];
-        lds_row<8>(tw5_row, t5m);
+        load_tab<8>(tw5_row, t5m);
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int k = la + 16 * m;
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
             fft256_stage_b_pad<+1, kRow2>(v, slot, la);
             const float sc = tvalid ? (1.f / 256.f) : 0.f;
             cf wsyn[16];
-            lds_row<16>(win_row, wsyn);
+            load_tab<16>(win_row, wsyn);
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) {
                 const int n = la + 16 * kb;
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
             int pos0 = max(ts, wi.t0) * hop;
             int pos1 = min(ts + ST, wi.t1) * hop;
             if (wi.last && ts + ST >= wi.t1) pos1 = (T - 1) * hop + kNfft;
-            for (int n = pos0 + tid; n < pos1; n += 256) {
+            for (int n = pos0 + tid; n < pos1; n += NT) {
                 // frames t with t*hop <= n < t*hop + 512
                 int t_hi = min(n / hop, T - 1);
                 int t_lo = max((n - kNfft) / hop + 1, 0);
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
             float4* dst = reinterpret_cast<float4*>(slots);
             const float4* src = reinterpret_cast<const float4*>(slots + ST * SL);
             const int n4 = keep * (SL / 2);  // float4 per slot
-            for (int i = tid; i < n4; i += 256) dst[i] = src[i];
+            for (int i = tid; i < n4; i += NT) dst[i] = src[i];
         }
     }
     // ---- max |out| for the renorm ----
@@ -275,7 +292,9 @@ __global__ __launch_bounds__(256, 2) void beamform_istft_kernel(Pass2Args a) {
     if ((tid & 63) == 0) red[tid >> 6] = omax;
     __syncthreads();
     if (tid == 0) {
-        const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float m = red[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, red[w]);
         atomicMax(a.outmax_bits + wi.utt, __float_as_uint(m));
     }
 }
@@ -289,10 +308,10 @@ static hipError_t launch_pass2_t(const Pass2Args& a, int n_items, hipStream_t s)
     if (e != hipSuccess) return e;
     if (getenv("SETK_DEBUG")) {
         int nb = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), 256, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), kPass2Threads, lds);
         fprintf(stderr, "[setk] pass2<%d,%d> lds=%zu items=%d blocks/CU=%d\n", C, (int)IO, lds, n_items, nb);
     }
-    hipLaunchKernelGGL(k, dim3(n_items), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(n_items), dim3(kPass2Threads), lds, s, a);
     return hipGetLastError();
 }
 
