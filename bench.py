@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--full-batch", type=int, default=1000,
                     help="N=1 only: also time the whole configs[2] batch of this many "
                          "utterances on the one GPU (strong-scaling anchor; 0 = skip)")
+    ap.add_argument("--other-configs", type=int, default=1,
+                    help="N=1 only: also time BASELINE configs[1], [3] and [4] (short runs) and "
+                         "report them in `other_configs` (0 = skip)")
     ap.add_argument("--e2e-utts", type=int, default=192,
                     help="N=1 only: utterances of the end-to-end CLI leg (0 = skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
@@ -271,17 +274,118 @@ def main():
             out["uncached_call"] = fresh
         if full_batch is not None:
             out["full_batch"] = full_batch
+        if world == 1 and args.other_configs:
+            del audio, masks, waves
+            audio = masks = waves = []
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(torch, _ffi, synth, dev)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args, C, N, rank * U, wave0)
         if world == 1 and args.e2e_utts > 0:
             # free the resident shard first: the CLI leg is its own process
-            del audio, masks, waves
+            audio = masks = waves = None
             torch.cuda.empty_cache()
             out["end_to_end"] = end_to_end(args, C, N)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_configs(torch, _ffi, synth, dev):
+    """The other GPU configurations BASELINE.json names, timed briefly (inputs resident
+    in HBM, 10 steps each) so that one record carries all of them:
+    configs[1] 4-ch 10 s MVDR (500 utterances), configs[3] 8-ch 30 s GEV (125),
+    configs[4] 6-ch 30 s CGMM (20 EM iterations) -> MVDR (125)."""
+    from setk_amd.engine import CgmmEstimator
+    F = 257
+    res = {}
+
+    def shard(ctx, C, N, U, nd=8):
+        T = ctx.num_frames(N)
+        L = ctx.istft_num_samples(T)
+        audio, masks = [], []
+        for i in range(nd):
+            mix, sp, nz = synth.synth_utterance(1000 + i, C, N, return_parts=True)
+            a = torch.from_numpy(mix).to(dev)
+            parts = torch.from_numpy(np.stack([sp[0], nz[0]])).to(dev)
+            spec = torch.empty((2, T, F), dtype=torch.complex64, device=dev)
+            ctx.stft(parts, spec)
+            sa, va = spec[0].abs(), spec[1].abs()
+            audio.append(a)
+            masks.append((sa / torch.sqrt(sa * sa + va * va + synth.EPSILON)).contiguous())
+        for i in range(nd, U):
+            audio.append(audio[i % nd].clone())
+            masks.append(masks[i % nd].clone())
+        waves = [torch.empty(L, dtype=torch.float32, device=dev) for _ in range(U)]
+        return audio, masks, waves, T, L
+
+    def run(label, C, seconds, U, kind):
+        ctx = _ffi.Context(dev.index)
+        ctx.stft_plan(512, 256, 512, True)
+        N = int(round(seconds * SR))
+        audio, masks, waves, T, L = shard(ctx, C, N, U)
+        ap, mp, wp = ([t.data_ptr() for t in x] for x in (audio, masks, waves))
+        ns = [N] * U
+        opts = _ffi.BfOpts(kind=kind, flags=_ffi.FLAG_CLAMP_MASK, pmwf_beta=0.0, pmwf_ref=-1, rank1=0)
+        for _ in range(3):
+            ctx.enhance_batch(opts, C, ap, ns, mp, None, wp, want_status=False)
+        st = ctx.enhance_batch(opts, C, ap, ns, mp, None, wp, want_status=True)
+        ctx.set_profiling(True)
+        torch.cuda.synchronize()
+        k = 10
+        t0 = time.perf_counter()
+        for _ in range(k):
+            ctx.enhance_batch(opts, C, ap, ns, mp, None, wp, want_status=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / k
+        ctx.set_profiling(False)
+        sm = ctx.last_stage_ms()
+        b_k1 = U * (4.0 * C * N + 4.0 * T * F)
+        res[label] = {
+            "workload": f"{C}-ch {seconds:g} s x {U} utterances, "
+                        f"{'GEV' if kind == _ffi.BF_GEVD else 'MVDR'}, inputs resident in HBM",
+            "ms_per_step": round(1e3 * dt, 4), "value": round(U * seconds / dt, 1),
+            "status_ok": not any(st),
+            "stage_ms": {"stft_covar": round(sm[0], 4), "reduce_solve": round(sm[1], 4),
+                         "beamform_istft": round(sm[2], 4), "renorm": round(sm[3], 4)},
+            "stft_covar_roofline_frac": round(b_k1 / (sm[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        }
+        ctx.close()
+        del audio, masks, waves
+        torch.cuda.empty_cache()
+
+    run("configs[1] 4-ch MVDR", 4, 10.0, 500, _ffi.BF_MVDR)
+    run("configs[3] 8-ch GEV", 8, 30.0, 125, _ffi.BF_GEVD)
+    # configs[4]: CGMM mask estimation feeding MVDR
+    ctx = _ffi.Context(dev.index)
+    est = CgmmEstimator(num_iters=20, ctx=ctx)
+    est._plan()
+    C, N, U = 6, 30 * SR, 125
+    audio = [torch.from_numpy(synth.synth_utterance(2000 + (i % 8), C, N)).to(dev) for i in range(8)]
+    audio += [audio[i % 8].clone() for i in range(8, U)]
+    L = ctx.istft_num_samples(ctx.num_frames(N))
+    waves = [torch.empty(L, dtype=torch.float32, device=dev) for _ in range(U)]
+    opts = _ffi.BfOpts(kind=_ffi.BF_MVDR, flags=_ffi.FLAG_CLAMP_MASK, pmwf_ref=-1)
+
+    def cg_step():
+        m = est.estimate_device(audio)
+        ctx.enhance_batch(opts, C, [t.data_ptr() for t in audio], [N] * U,
+                          [t.data_ptr() for t in m], None, [w.data_ptr() for w in waves],
+                          want_status=False)
+        torch.cuda.synchronize()
+
+    cg_step()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        cg_step()
+    dt = (time.perf_counter() - t0) / 3
+    res["configs[4] 6-ch CGMM->MVDR"] = {
+        "workload": "6-ch 30 s x 125 utterances, CGMM (K = 2, 20 EM iterations) -> MVDR, "
+                    "inputs resident in HBM",
+        "ms_per_step": round(1e3 * dt, 3), "value": round(U * 30.0 / dt, 1)}
+    ctx.close()
+    return res
 
 
 def time_full_batch(args, ctx, opts, torch, audio, masks, C, N, L):
