@@ -279,9 +279,10 @@ def test_bench_contract_single_and_two_ranks():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     bench = os.path.join(root, "bench.py")
-    small = ["--steps", "2", "--warmup", "1", "--utts", "6", "--seconds", "4", "--cpu-sample", "0"]
-    r = subprocess.run([sys.executable, bench, "--gpus", "1"] + small, capture_output=True, text=True,
-                       timeout=600, cwd=root)
+    small = ["--steps", "2", "--warmup", "1", "--utts", "6", "--seconds", "4", "--cpu-sample", "0",
+             "--other-configs", "0", "--sustain-sec", "0.2", "--full-batch", "12"]
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--e2e-utts", "6"] + small,
+                       capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -291,6 +292,11 @@ def test_bench_contract_single_and_two_ranks():
         assert k in one, k
     assert one["n_gpus"] == 1 and one["steps"] == 2 and one["scaling"] == "weak"
     assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1
+    # the legs outside the timed steps
+    assert one["sustained"]["steps"] >= 50 and one["full_batch"]["utts"] == 12
+    assert one["uncached_call"]["ms_per_step"] > 0
+    e2e = one["end_to_end"]
+    assert [r_["written"] for r_ in e2e["runs"]] == [6, 24] and "marginal_ms_per_utt" in e2e
 
     env = dict(os.environ, SETK_BENCH_SHARE_GPU="1", SETK_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
