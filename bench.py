@@ -22,7 +22,10 @@ addresses and a status read-back every call: the timed steps reuse one descripto
 block and skip the read-back), `full_batch` (all 1000 utterances of
 configs[2] on the one GPU: the strong-scaling anchor), `cpu_baseline` (one core,
 all cores in the reference's process-per-shard mode, and the oracle check of the
-timed configuration's output) and `end_to_end` (disk -> wav through the CLI).
+timed configuration's output), `other_configs` (configs[1] 4-ch MVDR, configs[3]
+8-ch GEV and configs[4] 6-ch CGMM -> MVDR at their BASELINE sizes, each with its
+own stage times) and `end_to_end` (disk -> wav through the CLI, plus the host's
+RAM copy rate that bounds it).
 
 One JSON line on rank 0:
   value      aggregate real-time factor (audio seconds / wall second, all GPUs)
@@ -537,6 +540,28 @@ def cpu_baseline(args, C, N, first_index, wave0):
     return out
 
 
+def host_copy_rate(threads=(1, 8), nbytes=64 << 20, reps=4):
+    """RAM -> RAM copy rate of this host (numpy, GIL released), per thread count: the
+    ceiling of any path that stages file bytes through a page-locked buffer."""
+    import threading
+    out = {}
+    for nt in threads:
+        src = [np.ones(nbytes, dtype=np.uint8) for _ in range(nt)]
+        dst = [np.ones(nbytes, dtype=np.uint8) for _ in range(nt)]   # ones: pages touched
+
+        def work(k):
+            for _ in range(reps):
+                np.copyto(dst[k], src[k])
+        th = [threading.Thread(target=work, args=(k,)) for k in range(nt)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        out[str(nt)] = round(nt * reps * nbytes / (time.perf_counter() - t0) / 1e9, 2)
+    return out
+
+
 def end_to_end(args, C, N):
     """disk -> wav through the drop-in CLI (scripts/sptk/apply_adaptive_beamformer.py),
     PCM16 wav + numpy masks in, PCM16 wav out, on files written to /dev/shm (or
@@ -623,6 +648,9 @@ def end_to_end(args, C, N):
             out["marginal_ms_per_utt"] = round(1e3 * dm, 4)
             out["marginal_value"] = round((N / SR) / dm, 1) if dm > 0 else None
             out["marginal_GBps_in"] = round((2 * C * N + 4 * T * 257) / dm / 1e9, 2) if dm > 0 else None
+        # what the host can copy at all (threads -> GB/s): the input bytes are copied once
+        # from the page cache into page-locked slabs before the DMA
+        out["host_copy_GBps"] = host_copy_rate()
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
