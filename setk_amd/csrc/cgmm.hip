@@ -35,6 +35,12 @@ ZD zd zd_shfl(zd v, int src) { return make_double2(__shfl(v.x, src, 8), __shfl(v
 
 constexpr float kEps32 = 1.1920928955078125e-07f;
 constexpr int kCgInitId = 0, kCgInitMask = 1, kCgEm = 2;
+// frames per partial-sum chunk: one wavefront folds a chunk in float32, the chunks are summed in
+// float64 (cgmm_finalize).  Shorter chunks = more waves and more partial traffic.
+#ifndef SETK_CG_CHUNK
+#define SETK_CG_CHUNK 64
+#endif
+constexpr int kCgChunk = SETK_CG_CHUNK;
 
 struct CgmmArgs {
     const cf* spec;          // [C][T][spitch], F entries used per row
@@ -374,7 +380,7 @@ size_t cgmm_fill_args(void* args_out, int C, const float* spec, int T, int F,
     a.T = T;
     a.F = F;
     a.pitch = ((F + 7) / 8) * 8;
-    a.tchunk = 64;
+    a.tchunk = kCgChunk;
     a.nchunks = (T + a.tchunk - 1) / a.tchunk;
     a.mode = init_mask ? kCgInitMask : kCgInitId;
     char* p = static_cast<char*>(scratch);
@@ -402,7 +408,7 @@ size_t cgmm_args_bytes() { return sizeof(CgmmArgs); }
 size_t cgmm_scratch_bytes(int C, int T, int F) {
     const int NP = npairs(C);
     const size_t pitch = ((F + 7) / 8) * 8;
-    const size_t nchunks = (T + 63) / 64;
+    const size_t nchunks = (T + kCgChunk - 1) / kCgChunk;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     return 2 * al((size_t)2 * T * F * 4) + al(nchunks * 2 * (2 * NP + 1) * pitch * 4) +
            al((size_t)2 * 2 * NP * pitch * 8) + al((size_t)2 * F * C * C * 8) +
@@ -412,7 +418,7 @@ size_t cgmm_scratch_bytes(int C, int T, int F) {
 hipError_t launch_cgmm_batch(int C, const void* d_tbl, int n_utts, int F, int max_frames,
                              int num_iters, hipStream_t s) {
     const CgmmArgs* t = static_cast<const CgmmArgs*>(d_tbl);
-    const int max_chunks = (max_frames + 63) / 64;
+    const int max_chunks = (max_frames + kCgChunk - 1) / kCgChunk;
     switch (C) {
         case 1: return cgmm_run_t<1>(t, n_utts, F, max_chunks, num_iters, s);
         case 2: return cgmm_run_t<2>(t, n_utts, F, max_chunks, num_iters, s);
