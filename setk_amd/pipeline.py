@@ -79,14 +79,18 @@ class Mapping(object):
 
 
 class Payload(object):
-    """A contiguous byte range of an open file that IS the data wanted (int16 wav
-    frames [N][C] or float32 mask rows [T][F]), or a host array to copy."""
+    """A contiguous byte range of a file that IS the data wanted (int16 wav frames [N][C]
+    or float32 mask rows [T][F]), or a host array to copy.  The file is named, not held open:
+    the thread that reads it opens and closes it.  (Descriptors held until their batch was read
+    made the process's descriptor table grow to thousands of entries, and every doubling of that
+    table in a multi-threaded process waits for an RCU grace period: 0.1 - 0.15 s each on the
+    256-core host, tools/ubench/open_probe.py.)"""
 
-    __slots__ = ("fd", "offset", "nbytes", "array", "fsize")
+    __slots__ = ("path", "offset", "nbytes", "array", "fsize")
 
-    def __init__(self, fd=None, offset=0, nbytes=0, array=None, fsize=0):
-        self.fd, self.offset, self.nbytes, self.array = fd, offset, nbytes, array
-        self.fsize = fsize  # size of the file behind fd (0: unknown -> staged path)
+    def __init__(self, path=None, offset=0, nbytes=0, array=None, fsize=0):
+        self.path, self.offset, self.nbytes, self.array = path, offset, nbytes, array
+        self.fsize = fsize  # size of the file (0: unknown -> staged path)
 
     def zero_copy_ok(self):
         """The payload is (nearly) the whole file: worth pinning the file's pages."""
@@ -100,25 +104,23 @@ class Payload(object):
             return
         got = 0
         mv = memoryview(dst)
-        while got < self.nbytes:  # os.preadv releases the GIL, no seek state
-            n = os.preadv(self.fd, [mv[got:]], self.offset + got)
-            if n <= 0:
-                raise IOError("truncated payload")
-            got += n
+        fd = os.open(self.path, os.O_RDONLY)
+        try:
+            while got < self.nbytes:  # os.preadv releases the GIL, no seek state
+                n = os.preadv(fd, [mv[got:]], self.offset + got)
+                if n <= 0:
+                    raise IOError("truncated payload")
+                got += n
+        finally:
+            os.close(fd)
 
 
 class OpenFiles(object):
-    """Process-lifetime cache of read-only descriptors (the reference's readers
-    also keep archives open, data_handler.py:343, 522-529)."""
+    """Small cache of read-only descriptors for the header probes of the planning thread (the
+    reference's readers also keep archives open, data_handler.py:343, 522-529): an archive
+    that holds many entries is opened once, plain files pass through."""
 
-    def __init__(self, limit=None):
-        if limit is None:
-            try:
-                import resource
-                soft = resource.getrlimit(resource.RLIMIT_NOFILE)[0]
-                limit = max(64, min(4096, soft - 128))
-            except (ImportError, ValueError, OSError):
-                limit = 512
+    def __init__(self, limit=32):
         self.fds = {}
         self.limit = limit
         self.lock = threading.Lock()
@@ -128,8 +130,7 @@ class OpenFiles(object):
             fd = self.fds.get(path)
             if fd is None:
                 if len(self.fds) >= self.limit:
-                    # oldest quarter (their batches completed long ago: at most
-                    # depth x batch_utts x 3 descriptors are in flight)
+                    # oldest quarter (nothing else refers to these descriptors)
                     for p in list(self.fds)[:self.limit // 4]:
                         os.close(self.fds.pop(p))
                 fd = self.fds[path] = os.open(path, os.O_RDONLY)
@@ -288,7 +289,9 @@ class StreamPipeline(object):
         self.batch_utts = max(1, int(batch_utts))
         self.F = engine.num_bins
         ncpu = os.cpu_count() or 4
-        self.read_threads = read_threads or max(4, min(32, ncpu // 2))
+        # more readers are slower: the page-cache copies of many threads contend in the kernel
+        # (profiles/r02z_e2e_host_path.txt: 1024 utterances in 0.60 - 0.71 s with 6 - 16, 0.82 - 0.93 with 32)
+        self.read_threads = read_threads or max(4, min(12, ncpu // 2))
         self.readers = ThreadPoolExecutor(self.read_threads, thread_name_prefix="setk-read")
         self.writers = ThreadPoolExecutor(write_threads, thread_name_prefix="setk-write")
         self.depth = depth
@@ -424,7 +427,11 @@ class StreamPipeline(object):
         dst = slot.d_in.data_ptr() + off
         stream = self.s_in.cuda_stream
         if self.zero_copy and payload.zero_copy_ok():
-            m = Mapping(payload.fd, payload.fsize)
+            fd = os.open(payload.path, os.O_RDONLY)
+            try:
+                m = Mapping(fd, payload.fsize)  # the mapping keeps the file, not the descriptor
+            finally:
+                os.close(fd)
             if ctx.host_register(m.addr, m.size):
                 m.pinned = True
                 ctx.memcpy_h2d_async(dst, m.addr + payload.offset, payload.nbytes, stream)
@@ -615,7 +622,7 @@ def wav_source(wav_reader, key, files):
                 n = info["data_bytes"] // (2 * ch)
                 size = os.fstat(files.get(path)).st_size
                 n = min(n, max(0, (size - data_off) // (2 * ch)))
-                return (Payload(fd=files.get(path), offset=data_off, nbytes=2 * ch * n, fsize=size),
+                return (Payload(path=path, offset=data_off, nbytes=2 * ch * n, fsize=size),
                         ch, n)
     samps = wav_reader.read(key)
     return samps[None] if samps.ndim == 1 else samps
@@ -630,13 +637,13 @@ def mask_source(reader, key, files, num_bins):
             path = reader.index_dict[key]
             shape, dt, fortran, off = probe_npy(files, path)
             if dt == np.dtype("<f4") and not fortran and len(shape) == 2 and shape[1] == num_bins:
-                return Payload(fd=files.get(path), offset=off, nbytes=4 * shape[0] * shape[1],
+                return Payload(path=path, offset=off, nbytes=4 * shape[0] * shape[1],
                                fsize=os.fstat(files.get(path)).st_size)
         elif isinstance(reader, ScriptReader):
             path, offset = reader.locate(key)
             hit = probe_kaldi_matrix(files, path, offset)
             if hit and hit[2] == np.dtype("<f4") and hit[1] == num_bins:
-                return Payload(fd=files.get(path), offset=hit[3], nbytes=4 * hit[0] * hit[1],
+                return Payload(path=path, offset=hit[3], nbytes=4 * hit[0] * hit[1],
                                fsize=os.fstat(files.get(path)).st_size)
     except (OSError, ValueError, KeyError, SyntaxError):
         pass

@@ -33,11 +33,17 @@ try:
             ws.write(f"u{i} {d}/wav/u{i}.wav\n"); ms.write(f"u{i} {d}/mask/u{i}.npy\n")
     for flags in sys.argv[2:]:
         shutil.rmtree(f"{d}/enh", ignore_errors=True)
+        env = dict(os.environ)
+        # "KEY=VALUE ..." tokens in front of the flags go to the environment
+        toks = flags.split()
+        while toks and "=" in toks[0] and not toks[0].startswith("-"):
+            k, v = toks.pop(0).split("=", 1)
+            env[k] = v
         cmd = [sys.executable, os.path.join(ROOT, "scripts/sptk/apply_adaptive_beamformer.py"),
-               "--mask-format", "numpy", "--profile", f"{d}/prof.json"] + flags.split() + \
+               "--mask-format", "numpy", "--profile", f"{d}/prof.json"] + toks + \
               [f"{d}/wav.scp", f"{d}/mask.scp", f"{d}/enh"]
         t0 = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
         wall = time.perf_counter() - t0
         if r.returncode:
             print(flags, "FAILED", r.stderr[-400:]); continue
