@@ -80,7 +80,7 @@ _OPTIONS = (
     (("--pipeline-depth",), dict(default=3, type=int,
                                  help="[setk_amd] batches in flight in the host pipeline")),
     (("--read-threads",), dict(default=0, type=int,
-                               help="[setk_amd] file reader threads (0: half the cores, <= 32)")),
+                               help="[setk_amd] file reader threads (0: half the cores, <= 12)")),
     (("--profile",), dict(default="", type=str,
                           help="[setk_amd] write a JSON run summary (wall clock from the first "
                                "scp read to the last wav close, stage times, bytes) here")),
