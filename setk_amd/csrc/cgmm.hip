@@ -36,9 +36,10 @@ ZD zd zd_shfl(zd v, int src) { return make_double2(__shfl(v.x, src, 8), __shfl(v
 constexpr float kEps32 = 1.1920928955078125e-07f;
 constexpr int kCgInitId = 0, kCgInitMask = 1, kCgEm = 2;
 // frames per partial-sum chunk: one wavefront folds a chunk in float32, the chunks are summed in
-// float64 (cgmm_finalize).  Shorter chunks = more waves and more partial traffic.
+// float64 (cgmm_finalize).  Shorter chunks = more waves and more partial traffic
+// (configs[4], 125 x 30 s: 41.1 ms with 64, 39.5 with 128, 38.6 - 39.1 with 192).
 #ifndef SETK_CG_CHUNK
-#define SETK_CG_CHUNK 64
+#define SETK_CG_CHUNK 128
 #endif
 constexpr int kCgChunk = SETK_CG_CHUNK;
 
@@ -255,6 +256,8 @@ __global__ __launch_bounds__(64) void cgmm_eig_kernel(const CgmmArgs* __restrict
 // then streamed once per EM iteration instead of twice and gamma / phi never
 // leave the registers; the stand-alone E-step (ACCUM = false) only closes the
 // last iteration and writes the outputs.
+// 157 VGPRs at C = 6 (V, 1 / w, the accumulators and a prefetched frame): three waves per SIMD;
+// forced to 128 registers the kernel spills 47 of them and the EM runs 3 x slower
 template <int C, bool ACCUM>
 __global__ __launch_bounds__(64) void cgmm_estep_kernel(const CgmmArgs* __restrict__ tbl, int last) {
     constexpr int NP = npairs(C);
