@@ -648,6 +648,12 @@ def end_to_end(args, C, N):
             out["marginal_ms_per_utt"] = round(1e3 * dm, 4)
             out["marginal_value"] = round((N / SR) / dm, 1) if dm > 0 else None
             out["marginal_GBps_in"] = round((2 * C * N + 4 * T * 257) / dm / 1e9, 2) if dm > 0 else None
+            # the same from the CLI's own clocks (no interpreter start-up noise in the difference)
+            for name, key in (("marginal_ms_per_utt_first_read_to_last_write",
+                               "wall_s_first_read_to_last_write"),
+                              ("marginal_ms_per_utt_pipeline", "pipeline_wall_s")):
+                if r1.get(key) is not None and r2.get(key) is not None:
+                    out[name] = round(1e3 * (r2[key] - r1[key]) / (n2 - n1), 4)
         # what the host can copy at all (threads -> GB/s): the input bytes are copied once
         # from the page cache into page-locked slabs before the DMA
         out["host_copy_GBps"] = host_copy_rate()
