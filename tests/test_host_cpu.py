@@ -443,3 +443,35 @@ def test_writer_family(tmp_path):
     rd = WaveReader(str(tmp_path / "w.scp"))
     assert rd.peek_nsamps("s") == 100 and rd.peek_nsamps("p") == 100
     assert np.array_equal(rd.read_pcm16("p")[:, 0], np.arange(-50, 50, dtype=np.int16))
+
+
+def test_payload_reads_by_name_and_holds_no_descriptor(tmp_path):
+    """pipeline.Payload names its file: load_into opens, reads the byte range and closes (a run of
+    n utterances must not hold 2 n descriptors: the descriptor table's growth stalls a
+    multi-threaded process)."""
+    from setk_amd.pipeline import OpenFiles, Payload, probe_npy
+    blob = np.arange(5000, dtype=np.uint8).tobytes()
+    paths = []
+    for i in range(40):
+        p = tmp_path / f"p{i}.bin"
+        p.write_bytes(blob)
+        paths.append(str(p))
+    before = len(os.listdir("/proc/self/fd"))
+    for p in paths:
+        dst = np.zeros(1000, dtype=np.uint8)
+        Payload(path=p, offset=123, nbytes=1000).load_into(dst)
+        assert dst.tobytes() == blob[123:1123]
+    assert len(os.listdir("/proc/self/fd")) == before
+    with pytest.raises(IOError):
+        Payload(path=paths[0], offset=4500, nbytes=1000).load_into(np.zeros(1000, dtype=np.uint8))
+    assert len(os.listdir("/proc/self/fd")) == before
+    # the header-probe cache stays small whatever the number of files
+    files = OpenFiles()
+    for i in range(100):
+        q = tmp_path / f"m{i}.npy"
+        np.save(q, np.zeros((3, 257), dtype=np.float32))
+        shape, dt, fortran, off = probe_npy(files, str(q))
+        assert shape == (3, 257) and not fortran and dt == np.dtype("<f4")
+    assert len(files.fds) <= files.limit
+    files.close()
+    assert len(os.listdir("/proc/self/fd")) == before
