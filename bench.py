@@ -637,7 +637,17 @@ def end_to_end(args, C, N):
                     "stages": {k: (round(v, 4) if isinstance(v, float) else v)
                                for k, v in st.items()}}
 
-        r1, r2 = run_cli(n1), run_cli(n2)
+        # each size twice, the faster run counts: the first read of freshly written page-cache
+        # pages varies by 2x between otherwise identical runs
+        def best(n):
+            runs = [run_cli(n) for _ in range(2)]
+            good = [r for r in runs if "error" not in r]
+            if not good:
+                return runs[0]
+            r = min(good, key=lambda r_: r_["wall_s_process"])
+            r["wall_s_process_all"] = [r_["wall_s_process"] for r_ in good]
+            return r
+        r1, r2 = best(n1), best(n2)
         out = {"workload": f"{C}-ch {N / SR:g} s PCM16 wav + float32 numpy masks on {base}, "
                            f"{args.beamformer}, PCM16 wav out, through "
                            "scripts/sptk/apply_adaptive_beamformer.py",
