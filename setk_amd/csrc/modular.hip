@@ -486,16 +486,47 @@ struct PcmItem {
     int pad_;
 };
 
+// CT > 0: channel count known at compile time -- a thread takes FOUR frames (4 CT int16 = 64
+// bytes at CT = 8, the compiler merges the loads) and stores a float4 per channel; CT = 0: any C, one frame
+// and 2-byte loads per thread (also taken by a CT build when an item's pointers are not 4- / 8-byte
+// aligned or its frame count is not a multiple of four).  32 x (8 ch x 30 s): 0.34 ms (one frame per thread) -> 0.23 ms, 3.2 TB/s.
+template <int CT>
 __global__ __launch_bounds__(256) void pcm16_to_float_batch_kernel(const PcmItem* __restrict__ items,
                                                                    int C, double* power0) {
     const PcmItem it = items[blockIdx.y];
+    const float k = 1.0f / 32768.0f;
     float acc = 0.f;
-    for (int n = blockIdx.x * 256 + threadIdx.x; n < it.n; n += gridDim.x * 256) {
-        const int16_t* src = it.pcm + (size_t)n * C;
-        for (int c = 0; c < C; ++c) {
-            const float v = (float)src[c] * (1.0f / 32768.0f);
-            it.out[(size_t)c * it.n + n] = v;
-            if (c == 0) acc = fmaf(v, v, acc);
+    constexpr int CV = CT > 0 ? CT : 1;
+    constexpr int FR = 4;  // frames per thread: FR * CV int16 in, one float4 per channel out
+    const bool fast = CT > 0 && (reinterpret_cast<uintptr_t>(it.pcm) & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(it.out) & 15) == 0 && (it.n % FR) == 0;
+    if (fast) {
+        const int groups = it.n / FR;
+        for (int p = blockIdx.x * 256 + threadIdx.x; p < groups; p += gridDim.x * 256) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(it.pcm + (size_t)FR * p * CV);
+            int16_t v[FR * CV];
+#pragma unroll
+            for (int w = 0; w < FR * CV / 2; ++w) {
+                const uint32_t u = src[w];
+                v[2 * w] = (int16_t)(u & 0xffffu);
+                v[2 * w + 1] = (int16_t)(u >> 16);
+            }
+#pragma unroll
+            for (int c = 0; c < CV; ++c) {
+                const float4 o = make_float4((float)v[c] * k, (float)v[CV + c] * k,
+                                             (float)v[2 * CV + c] * k, (float)v[3 * CV + c] * k);
+                *reinterpret_cast<float4*>(it.out + (size_t)c * it.n + FR * p) = o;
+                if (c == 0) acc = fmaf(o.w, o.w, fmaf(o.z, o.z, fmaf(o.y, o.y, fmaf(o.x, o.x, acc))));
+            }
+        }
+    } else {
+        for (int n = blockIdx.x * 256 + threadIdx.x; n < it.n; n += gridDim.x * 256) {
+            const int16_t* src = it.pcm + (size_t)n * C;
+            for (int c = 0; c < C; ++c) {
+                const float v = (float)src[c] * k;
+                it.out[(size_t)c * it.n + n] = v;
+                if (c == 0) acc = fmaf(v, v, acc);
+            }
         }
     }
     if (power0) {
@@ -518,8 +549,15 @@ hipError_t launch_pcm16_to_float_batch(const void* d_items, int n_utts, int C, i
                                        double* power0, hipStream_t s) {
     int bx = (max_n + 256 * 8 - 1) / (256 * 8);
     bx = bx < 1 ? 1 : bx;
-    hipLaunchKernelGGL(pcm16_to_float_batch_kernel, dim3(bx, n_utts), dim3(256), 0, s,
-                       static_cast<const PcmItem*>(d_items), C, power0);
+    const PcmItem* items = static_cast<const PcmItem*>(d_items);
+    const dim3 grid(bx, n_utts), block(256);
+    switch (C) {
+        case 2: hipLaunchKernelGGL(pcm16_to_float_batch_kernel<2>, grid, block, 0, s, items, C, power0); break;
+        case 4: hipLaunchKernelGGL(pcm16_to_float_batch_kernel<4>, grid, block, 0, s, items, C, power0); break;
+        case 6: hipLaunchKernelGGL(pcm16_to_float_batch_kernel<6>, grid, block, 0, s, items, C, power0); break;
+        case 8: hipLaunchKernelGGL(pcm16_to_float_batch_kernel<8>, grid, block, 0, s, items, C, power0); break;
+        default: hipLaunchKernelGGL(pcm16_to_float_batch_kernel<0>, grid, block, 0, s, items, C, power0);
+    }
     return hipGetLastError();
 }
 
