@@ -586,6 +586,39 @@ def synth_utterance(index, num_channels, num_samples, return_parts=False):
     return mix
 
 
+
+def synth_scene(index, num_channels, num_samples, return_parts=False):
+    """A scene with time-frequency structure for the blind (CGMM) path: a gated,
+    spectrally coloured point source through a short random FIR per channel, in
+    spatially correlated (full-rank) diffuse noise.  default_rng(4321 + index)."""
+    rng = np.random.default_rng(4321 + index)
+    C, N = num_channels, num_samples
+    # source: coloured noise (two resonances), gated on/off in 0.1 - 0.6 s segments
+    src = rng.standard_normal(N + 64)
+    for fc, r in ((rng.uniform(300, 900), 0.97), (rng.uniform(1500, 3000), 0.9)):
+        a1, a2 = -2 * r * np.cos(2 * np.pi * fc / 16000.0), r * r
+        src = src + 0.7 * scipy.signal.lfilter([1.0], [1.0, a1, a2], src) * (1 - r)
+    env = np.zeros(N + 64)
+    pos, on = 0, bool(rng.integers(0, 2))
+    while pos < N + 64:
+        seg = int(rng.uniform(0.1, 0.6) * 16000)
+        if on:
+            env[pos:pos + seg] = rng.uniform(0.5, 1.0)
+        on = not on
+        pos += seg
+    src = src * env
+    src = src / max(np.sqrt(np.mean(src**2)), 1e-9)
+    taps = rng.standard_normal((C, 16)) * np.exp(-np.arange(16) / 3.0)
+    taps[:, 0] += 1.0
+    speech = np.stack([np.convolve(src, taps[c])[32:32 + N] for c in range(C)]) * 0.25
+    mixm = np.eye(C) + 0.4 * rng.standard_normal((C, C))
+    noise = (mixm @ rng.standard_normal((C, N))) * 0.08
+    mix = ((speech + noise) * 0.2).astype(np.float32)
+    if return_parts:
+        return mix, (speech * 0.2).astype(np.float32), (noise * 0.2).astype(np.float32)
+    return mix
+
+
 def irm_mask(speech, noise, frame_len=512, frame_hop=256, center=True):
     """compute_mask.py:77-107 "irm" on channel 0: |S| / sqrt(|S|^2+|V|^2+eps),
     T x F float32."""

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsetk_hip.so")
-SOURCES = ["pass1.hip", "pass2.hip", "solve.hip", "modular.hip", "cgmm.hip", "wpe.hip", "capi.hip"]
+SOURCES = ["pass1.hip", "pass2.hip", "solve.hip", "modular.hip", "cgmm.hip", "cgmm_bin.hip", "wpe.hip", "capi.hip"]
 HEADERS = ["common.h", "fft512.h", "dpp.h", os.path.join("..", "..", "include", "setk_hip.h")]
 ARCH = "gfx950"
 
@@ -57,6 +57,7 @@ def _build_locked(force, verbose):
              "solve.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
              "modular.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
              "cgmm.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+             "cgmm_bin.hip": [],
              "wpe.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
              "capi.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
     jobs = []

@@ -1020,6 +1020,58 @@ int setk_beamform(setk_handle_t h, const float* weight, const float* spec, int n
     return SETK_OK;
 }
 
+namespace {
+// The bin-resident EM (cgmm_bin.hip) when one bin of the longest utterance fits a CU,
+// otherwise (or with SETK_CGMM_STREAMING=1) the streaming kernels of cgmm.hip.
+bool cgmm_use_bin(int C, int max_frames) {
+    static const bool forced_off = [] {
+        const char* e = getenv("SETK_CGMM_STREAMING");
+        return e && *e && *e != '0';
+    }();
+    return !forced_off && cgmm_bin_threads(C, max_frames) != 0;
+}
+
+// spec / init / mask / gamma: device pointers per utterance (gamma entries may be null)
+int run_cgmm_bin(setk_handle_t h, int C, int n_utts, const float* const* spec, const int* frames,
+                 int F, int num_iters, const float* const* init, float* const* mask,
+                 float* const* gamma, int flags, int spec_pitch, hipStream_t s) {
+    const size_t ab = cgmm_bin_args_bytes();
+    std::vector<char> tbl((size_t)n_utts * ab);
+    std::vector<const float*> sp(n_utts);
+    std::vector<float*> mp(n_utts), gp(n_utts);
+    int max_frames = 0;
+    const int nout = gamma ? 2 : 1;
+    for (int u = 0; u < n_utts; ++u) {
+        const int T = frames[u], Tp = cgmm_bin_pitch(T);
+        max_frames = std::max(max_frames, T);
+        float* xb = static_cast<float*>(arena_alloc(h, (size_t)F * C * Tp * sizeof(float2)));
+        float* gb = static_cast<float*>(arena_alloc(h, (size_t)nout * F * Tp * sizeof(float)));
+        if (!xb || !gb) return fail(h, SETK_ERR_NOMEM, "arena");
+        cgmm_bin_fill_args(tbl.data() + (size_t)u * ab, xb, init ? init[u] : nullptr, gb, T, F,
+                           (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0, nout);
+        sp[u] = spec[u];
+        mp[u] = mask[u];
+        gp[u] = gamma ? gamma[u] : nullptr;
+    }
+    void *d_tbl, *d_sp, *d_mp, *d_gp = nullptr;
+    int rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
+    if (rc) return rc;
+    rc = upload(h, sp.data(), sp.size() * sizeof(void*), s, &d_sp);
+    if (rc) return rc;
+    rc = upload(h, mp.data(), mp.size() * sizeof(void*), s, &d_mp);
+    if (rc) return rc;
+    if (gamma) {
+        rc = upload(h, gp.data(), gp.size() * sizeof(void*), s, &d_gp);
+        if (rc) return rc;
+    }
+    HIP_TRY(h, launch_cgmm_bin(C, d_tbl, static_cast<const float* const*>(d_sp),
+                               spec_pitch > 0 ? spec_pitch : F, static_cast<float* const*>(d_mp),
+                               static_cast<float* const*>(d_gp), n_utts, F, max_frames, num_iters,
+                               nout, s));
+    return SETK_OK;
+}
+}  // namespace
+
 int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
                           const float* const* spec, const int* num_frames, int num_bins,
                           int num_iters, const float* const* init_mask, float* const* mask_out,
@@ -1042,8 +1094,13 @@ int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
         if (!is_device_ptr(spec[u]) || !is_device_ptr(mask_out[u]) ||
             (init_mask && init_mask[u] && !is_device_ptr(init_mask[u])))
             return fail(h, SETK_ERR_INVALID, "setk_cgmm_masks_batch takes device pointers");
+        max_frames = std::max(max_frames, num_frames[u]);
+    }
+    if (cgmm_use_bin(C, max_frames))
+        return run_cgmm_bin(h, C, n_utts, spec, num_frames, F, num_iters, init_mask, mask_out,
+                            nullptr, flags, spec_pitch, s);
+    for (int u = 0; u < n_utts; ++u) {
         const int T = num_frames[u];
-        max_frames = std::max(max_frames, T);
         void* scr = arena_alloc(h, cgmm_scratch_bytes(C, T, F));
         if (!scr) return fail(h, SETK_ERR_NOMEM, "arena");
         cgmm_fill_args(tbl.data() + (size_t)u * ab, C, spec[u], T, F,
@@ -1117,15 +1174,22 @@ int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int nu
         if (rc) return rc;
         d_gamma = static_cast<float*>(og.dev);
     }
-    void* d_scr = arena_alloc(h, cgmm_scratch_bytes(C, T, F));
-    if (!d_scr) return fail(h, SETK_ERR_NOMEM, "arena");
-    std::vector<char> tbl(cgmm_args_bytes());
-    cgmm_fill_args(tbl.data(), C, d_spec, T, F, d_init, d_gamma, static_cast<float*>(om.dev), d_scr,
-                   (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0, 0);
-    void* d_tbl;
-    rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
-    if (rc) return rc;
-    HIP_TRY(h, launch_cgmm_batch(C, d_tbl, 1, F, T, num_iters, s));
+    if (cgmm_use_bin(C, T)) {
+        float* mo = static_cast<float*>(om.dev);
+        rc = run_cgmm_bin(h, C, 1, &d_spec, &T, F, num_iters, d_init ? &d_init : nullptr, &mo,
+                          d_gamma ? &d_gamma : nullptr, flags, 0, s);
+        if (rc) return rc;
+    } else {
+        void* d_scr = arena_alloc(h, cgmm_scratch_bytes(C, T, F));
+        if (!d_scr) return fail(h, SETK_ERR_NOMEM, "arena");
+        std::vector<char> tbl(cgmm_args_bytes());
+        cgmm_fill_args(tbl.data(), C, d_spec, T, F, d_init, d_gamma, static_cast<float*>(om.dev),
+                       d_scr, (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0, 0);
+        void* d_tbl;
+        rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
+        if (rc) return rc;
+        HIP_TRY(h, launch_cgmm_batch(C, d_tbl, 1, F, T, num_iters, s));
+    }
     rc = copy_back(h, om, s);
     if (rc) return rc;
     if (gamma_out) {

@@ -166,6 +166,15 @@ size_t cgmm_args_bytes();
 size_t cgmm_scratch_bytes(int C, int T, int F);
 hipError_t launch_cgmm_batch(int C, const void* d_tbl, int n_utts, int F, int max_frames,
                              int num_iters, hipStream_t s);
+// bin-resident EM (cgmm_bin.hip)
+size_t cgmm_bin_args_bytes();
+int cgmm_bin_pitch(int T);
+int cgmm_bin_threads(int C, int max_frames);
+void cgmm_bin_fill_args(void* out, const float* xb, const float* init_mask, float* gamma_bm, int T,
+                        int F, int update_alpha, int nout);
+hipError_t launch_cgmm_bin(int C, const void* d_tbl, const float* const* d_spec_ptrs, int spec_pitch,
+                           float* const* d_mask_ptrs, float* const* d_gamma_ptrs, int n_utts, int F,
+                           int max_frames, int num_iters, int nout, hipStream_t s);
 hipError_t launch_ban(const float* w, const float* Rn, int F, int C, float* out, hipStream_t s);
 hipError_t launch_rank1(const float* pv, const float* Rs, const float* Rn, int F, int C,
                         float* out, hipStream_t s);

@@ -139,3 +139,61 @@ def test_cgmm_batched_ragged_equals_single():
         assert np.max(np.abs(m - single)) < 1e-5
         ref = o.cgmm_masks(o.multichannel_stft(u, transpose=False, **STFT_KW), 6)
         assert np.mean(np.abs(m - ref)) < 2e-4
+
+
+def _mask_report(tag, dev, ref):
+    d = np.abs(dev.astype(np.float64) - ref.astype(np.float64))
+    decided = np.abs(ref - 0.5) > 0.48
+    rep = dict(mean=float(d.mean()), max=float(d.max()),
+               max_decided=float(d[decided].max()) if decided.any() else 0.0,
+               decided=float(decided.mean()), over_1e3=float((d > 1e-3).mean()))
+    print(f"[{tag}] mean |d| {rep['mean']:.2e}  max {rep['max']:.2e}  max on decided cells "
+          f"{rep['max_decided']:.2e} ({rep['decided']:.1%} of cells)  cells > 1e-3: {rep['over_1e3']:.2e}")
+    return rep
+
+
+def test_cfg4_bench_shape_batched_masks_and_raw_mask_mvdr():
+    """BASELINE configs[4] the way bench.py times it: several DISTINCT 6-ch x 480 000
+    utterances in ONE batch through CgmmEstimator.estimate_device (batched device
+    STFT, padded pitch, 20 EM iterations), each mask against the oracle's float64
+    CGMM of the oracle's STFT; then MVDR with the RAW estimated mask.  The scene
+    (synth_scene) has gated speech in full-rank diffuse noise, so the noise
+    covariance is well conditioned and nothing needs softening."""
+    import torch
+    from setk_amd import _ffi
+    from setk_amd.engine import CgmmEstimator
+    C, N, n = 6, 480000, 8
+    ctx = _ffi.Context(0)
+    est = CgmmEstimator(num_iters=20, ctx=ctx)
+    utts = [o.synth_scene(500 + i, C, N) for i in range(n)]
+    dev = torch.device("cuda", 0)
+    audio = [torch.from_numpy(u).to(dev) for u in utts]
+    masks = [m.cpu().numpy() for m in est.estimate_device(audio)]
+    outs = [torch.empty(ctx.istft_num_samples(ctx.num_frames(N)), dtype=torch.float32, device=dev)
+            for _ in range(n)]
+    mdev = [torch.from_numpy(m).to(dev) for m in masks]
+    opts = _ffi.BfOpts(kind=_ffi.BF_MVDR, flags=_ffi.FLAG_CLAMP_MASK)
+    st = ctx.enhance_batch(opts, C, [t.data_ptr() for t in audio], [N] * n,
+                           [t.data_ptr() for t in mdev], None, [t.data_ptr() for t in outs])
+    torch.cuda.synchronize()
+    assert st == [0] * n
+    worst = dict(mean=0.0, max_decided=0.0, same=0.0, e2e=0.0)
+    for i in range(n):
+        obs = o.multichannel_stft(utts[i], transpose=False, **STFT_KW)
+        ref = o.cgmm_masks(obs, 20)
+        assert masks[i].shape == ref.shape == (1876, 257)
+        rep = _mask_report(f"cfg4 30 s utt {i}", masks[i], ref)
+        assert rep["mean"] < 1e-4, rep
+        assert rep["max_decided"] < 1e-3, rep
+        wave = outs[i].cpu().numpy()
+        same = o.enhance_utterance(utts[i], masks[i], kind="mvdr", gauge=True)
+        e2e = o.enhance_utterance(utts[i], ref, kind="mvdr", gauge=True)
+        es = rms(wave, same) / rms(same)
+        ee = rms(wave, e2e) / rms(e2e)
+        print(f"[cfg4 30 s utt {i}] raw-mask MVDR rel rms: same mask {es:.2e}, end to end {ee:.2e}")
+        assert es < 1e-3 and ee < 1e-3
+        worst = dict(mean=max(worst["mean"], rep["mean"]),
+                     max_decided=max(worst["max_decided"], rep["max_decided"]),
+                     same=max(worst["same"], es), e2e=max(worst["e2e"], ee))
+    print(f"[cfg4 30 s x {n}] worst: {worst}")
+    ctx.close()
