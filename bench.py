@@ -81,11 +81,36 @@ def parse():
     return ap.parse_args()
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks
+    ourselves, one per GPU -- what scripts/run_adapt_beamformer.sh:80-92 does with
+    run.pl JOB=1:nj -- and hand back the launcher's exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(relaunch_under_torchrun(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} "
+                         "ranks (one rank per GPU is the contract)")
     import torch
     import torch.distributed as dist
     from setk_amd import build as _build
@@ -159,14 +184,25 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
     stage_ms = ctx.last_stage_ms()
+    # every rank's own clock (its device work only, no barrier): an imbalance shows here
+    per_rank_ms = [round(1e3 * own_elapsed / args.steps, 4)]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        cdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([own_elapsed], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [round(1e3 * float(x.item()) / args.steps, 4) for x in allr]
+    print(f"[bench rank {rank}/{world}] cuda:{dev_index} ms_per_step {per_rank_ms[rank]:.4f}",
+          file=sys.stderr, flush=True)
 
     audio_sec = world * U * (N / SR) * args.steps
     value = audio_sec / elapsed
@@ -244,6 +280,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "per_gpu_value": round(value / world, 1),
+            "per_rank_ms_per_step": per_rank_ms,
             "config": {
                 "workload": f"{C}-ch 16 kHz oracle-mask {args.beamformer.upper()}, "
                             f"{args.seconds:g} s utterances, {U} per GPU "

@@ -1041,6 +1041,13 @@ int run_cgmm_bin(setk_handle_t h, int C, int n_utts, const float* const* spec, c
     std::vector<float*> mp(n_utts), gp(n_utts);
     int max_frames = 0;
     const int nout = gamma ? 2 : 1;
+    // diagnostic: SETK_CGMM_TIMING=<file> dumps the per-bin cycle counters of utterance 0
+    const char* timing_path = getenv("SETK_CGMM_TIMING");
+    void* d_timing = nullptr;
+    if (timing_path && *timing_path) {
+        d_timing = arena_alloc(h, (size_t)F * 8 * sizeof(long long));
+        if (d_timing) HIP_TRY(h, hipMemsetAsync(d_timing, 0, (size_t)F * 8 * sizeof(long long), s));
+    }
     for (int u = 0; u < n_utts; ++u) {
         const int T = frames[u], Tp = cgmm_bin_pitch(T);
         max_frames = std::max(max_frames, T);
@@ -1048,7 +1055,7 @@ int run_cgmm_bin(setk_handle_t h, int C, int n_utts, const float* const* spec, c
         float* gb = static_cast<float*>(arena_alloc(h, (size_t)nout * F * Tp * sizeof(float)));
         if (!xb || !gb) return fail(h, SETK_ERR_NOMEM, "arena");
         cgmm_bin_fill_args(tbl.data() + (size_t)u * ab, xb, init ? init[u] : nullptr, gb, T, F,
-                           (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0, nout);
+                           (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0, nout, u == 0 ? d_timing : nullptr);
         sp[u] = spec[u];
         mp[u] = mask[u];
         gp[u] = gamma ? gamma[u] : nullptr;
@@ -1068,6 +1075,21 @@ int run_cgmm_bin(setk_handle_t h, int C, int n_utts, const float* const* spec, c
                                spec_pitch > 0 ? spec_pitch : F, static_cast<float* const*>(d_mp),
                                static_cast<float* const*>(d_gp), n_utts, F, max_frames, num_iters,
                                nout, s));
+    if (d_timing) {
+        std::vector<long long> tm((size_t)F * 8);
+        HIP_TRY(h, hipMemcpyAsync(tm.data(), d_timing, tm.size() * sizeof(long long),
+                                  hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (FILE* fp = fopen(timing_path, "w")) {
+            fprintf(fp, "# bin frames rowsum barrier solve tail passes (shader cycles, summed over passes)\n");
+            for (int f = 0; f < F; ++f) {
+                fprintf(fp, "%d", f);
+                for (int k = 0; k < 8; ++k) fprintf(fp, " %lld", tm[(size_t)f * 8 + k]);
+                fprintf(fp, "\n");
+            }
+            fclose(fp);
+        }
+    }
     return SETK_OK;
 }
 }  // namespace

@@ -9,28 +9,36 @@
 // Cgmm.update/predict (:246-287), CgDistribution.update_parameters/log_pdf
 // (:193-235), Covariance (:94-133) for num_classes = 2.
 //
-// Per pass over the T frames (thread t owns frames t, t + NT, ...):
-//   E   q_k = x^H R_k^-1 x by forward substitution with the Cholesky factor of the
+// Per pass over the T frames (thread t owns frames t + NT u, u < U; the first RF of them
+// in registers, the others in the LDS tile), in phases that each keep few registers live:
+//   E0, E1  q_k = x^H R_k^-1 x by forward substitution with the Cholesky factor of the
 //       (eigenvalue-normalised, floored) R_k -- y = L^-1 x, q = |y|^2: every term
-//       positive, float32 loses only sqrt(cond) where the dense form loses cond;
-//       phi_k = max(q_k, eps) / M; log N_k = -M log phi_k - log det R_k; posterior.
-//   M   gamma_k M / phi_k  x x^H folded into 2 x (C(C+1)/2) register accumulators
-//       (outer products formed once for both classes), a DPP tree over each 16-lane
-//       row in float32 and the 4 x waves row sums in float64.
+//       positive, float32 loses only sqrt(cond) where the dense form loses cond.  One
+//       class's factor (C^2 floats, uniform over the workgroup) sits in SGPRs at a time.
+//   P   phi_k = max(q_k, eps) / M; log N_k = -M log phi_k - log det R_k; posterior;
+//       weights gamma_k M / phi_k.
+//   R, I  real, then imaginary parts of  sum_t w_k x x^H  in 2 x C(C+1)/2 (2 x C(C-1)/2)
+//       register accumulators, a DPP tree over the wavefront in float32, wave sums to
+//       LDS; the waves' sums are added in float64 by the solving wave.
 // Between two passes, wave k (k = 0, 1) solves class k on (C x C) lanes in float64:
-//   R_k -> two-sided Jacobi in the parallel (round-robin) order, warm-started from
-//   the previous iteration's eigenvectors (A = V^H R V), rotation angles in float32
-//   and the rotations themselves exactly unitary in float64, the sweep that starts
-//   with every |a_pq|^2 <= 1e-8 a_pp a_qq is the last -> eigenvalues scaled by
-//   1 / max(w_max, eps) and floored at eps (cluster.py:107-113) -> R_eff =
-//   V diag(w') V^H -> Cholesky.  The factor's 2 x (C^2) floats travel through LDS
-//   into SGPRs (they are uniform over the workgroup).
+//   fast path (EM iterations of bins without near-silent frames): Cholesky of R_k and a
+//   float32 bound  lambda_min >= 1 / trace(R^-1) >= 1.1 eps trace(R)  certifying that the
+//   reference's eigenvalue floor is inactive -- then its normalisation by lambda_max is a
+//   pure scale that cancels between phi and log det, and the factor of R itself serves;
+//   otherwise: two-sided Jacobi in the parallel (round-robin) order, warm-started from
+//   the previous eigenvectors (A = V^H R V), rotation angles in float32 and the rotations
+//   themselves exactly unitary in float64, the sweep that starts with every
+//   |a_pq|^2 <= 1e-8 a_pp a_qq is the last -> eigenvalues scaled by 1 / max(w_max, eps)
+//   and floored at eps (cluster.py:107-113) -> R_eff = V diag(w') V^H -> Cholesky.
 // Layout in: bin-major spectrogram [F][C][Tp] (frames contiguous; written by
 // spec_to_binmajor_kernel from the [C][T][Fp] dump); out: bin-major posteriors
 // [F][Tp], transposed back to the reference's T x F by binmajor_to_tf_kernel.
 // Roofline: VALU issue (about 340 float32 instructions per frame and iteration);
 // HBM traffic is one read of the spectrogram + one write of the masks.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include "common.h"
 #include "fft512.h"
 #include "../../include/setk_hip.h"
@@ -61,6 +69,7 @@ struct CgmmBinArgs {
     const cf* xb;            // [F][C][Tp]
     const float* init_mask;  // [T][F] or null
     float* gamma_bm;         // [nout][F][Tp]
+    long long* timing;       // diagnostic (SETK_CGMM_TIMING): [F][8] cycle counts, or null
     int T, Tp, F, update_alpha, nout, pad_;
 };
 
@@ -87,20 +96,33 @@ ZD double rcp64(double x) {
 ZD void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // compiler-only barrier: LDS loads are not merged or hoisted across it (the frames of a
 // chunk are re-read per phase instead of being kept in 12 VGPRs each)
-ZD void reload_fence() { asm volatile("" ::: "memory"); }
+ZD void reload_fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 template <int CTRL, int RM = 0xf>
 ZD float dppf(float v) {
     return __builtin_bit_cast(
         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RM, 0xf, true));
 }
-// sum over each 16-lane row, result in the row's lane 15
-ZD float row_sum16(float v) {
-    v += dppf<0x111>(v);  // row_shr:1
-    v += dppf<0x112>(v);  // row_shr:2
-    v += dppf<0x114>(v);  // row_shr:4
-    v += dppf<0x118>(v);  // row_shr:8
+// sum over the wavefront (pairwise tree), result in lane 63
+ZD float wave_sum(float v) {
+    v += dppf<0x111>(v);        // row_shr:1
+    v += dppf<0x112>(v);        // row_shr:2
+    v += dppf<0x114>(v);        // row_shr:4
+    v += dppf<0x118>(v);        // row_shr:8   -> lane 15 of each row
+    v += dppf<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dppf<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63
     return v;
+}
+
+template <int N, typename Fn, int I = 0>
+ZD void static_for(Fn&& fn) {
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        static_for<N, Fn, I + 1>(static_cast<Fn&&>(fn));
+    }
 }
 
 ZD float sgpr(float v) {
@@ -208,22 +230,72 @@ template <int C, int NT>
 struct BinSmem {
     static constexpr int M = (C + 1) & ~1;  // Jacobi dimension (even)
     static constexpr int NP = C * (C + 1) / 2, NPO = C * (C - 1) / 2;
-    static constexpr int NV = NP + NPO + 1;  // sums per class
+    static constexpr int NV = NP + NPO + 1;  // sums per class: re | im | sum gamma
     static constexpr int NW = NT / 64;
     zd A[2][M * M];
     zd V[2][M * M];
     zd W[2][M * M];
     double jp[2][M][4];          // per index: c, sigma.re, sigma.im
     double wv[2][M];             // w' per class
-    float red[NW * 4][2 * NV];
+    double tot[2][NV];           // float64 sums over the rows of `red`
+    float red[NW][2 * NV];
     float par[2][ParLayout<C>::SIZE];
+    float cert[2][M];
     int hasV[2];
+    int tiny;                    // some frame has |x|^2 < 1.5 eps: phi's floor may act
+    int nfast[2];
 };
 
+// Cholesky factor of the Hermitian positive definite matrix whose entry (i, j) the lane
+// holds in `re` (lower triangle used), cooperatively through sm.A[k].  Returns the lane's
+// L_ij (i > j) or, on a diagonal lane, (L_ii, 1 / L_ii).  ok = every pivot positive.
+template <int C, int M>
+ZD zd chol_lanes(zd* A, zd re, const int i, const int j, const int lane, const bool in, bool& ok) {
+    zd lcol = zmk(0.0, 0.0);
+    ok = true;
+#pragma unroll
+    for (int kk = 0; kk < C; ++kk) {
+        if (in) A[lane] = re;
+        wave_lds_fence();
+        if (in && i >= j && j >= kk) {
+            const double akk = A[kk * M + kk].x;
+            if (!(akk > 0.0)) ok = false;
+            const double rq = rsq64(fmax(akk, 1e-300));
+            if (j == kk) {
+                lcol = (i == kk) ? zmk(akk * rq, rq) : zscale(re, rq);
+            } else {
+                const zd aik = A[i * M + kk], ajk = A[j * M + kk];
+                re = zsub(re, zscale(zmulc(aik, ajk), rq * rq));
+                if (i == j) re.y = 0.0;
+            }
+        }
+        wave_lds_fence();
+    }
+    return lcol;
+}
+
+template <int C>
+ZD void write_factor(float* p, const zd lcol, const int i, const int j, const bool in) {
+    typedef ParLayout<C> PL;
+    if (in) {
+        if (i == j) {
+            p[PL::RD + i] = (float)lcol.y;
+        } else if (i > j) {
+            const int e = i * (i - 1) / 2 + j;
+            p[PL::LRE + e] = (float)lcol.x;
+            p[PL::LIM + e] = (float)lcol.y;
+        }
+    }
+}
+
 // ---- the solve of one class by one wave -------------------------------------------------
+// exact: reproduce the reference's absolute max(w_max, eps) (initial covariance; bins with
+// near-silent frames).  Otherwise the matrix may carry an arbitrary scale (fast passes drop
+// it) and only relative quantities are used -- equal to the reference's because there
+// lambda_max(R) >= M eps holds by construction (trace(R_eff^-1 R) = M^2, R_eff^-1 <= I / eps).
 template <int C, int NT>
-__device__ __noinline__ void solve_class(BinSmem<C, NT>& sm, const int k, const int lane, const int mode, const int T,
-                    const int update_alpha) {
+__device__ __noinline__ void solve_class(BinSmem<C, NT>& sm, const int k, const int lane,
+                                         const int mode, const int T, const int update_alpha) {
     typedef BinSmem<C, NT> S;
     typedef ParLayout<C> PL;
     constexpr int M = S::M, NP = S::NP, NPO = S::NPO, NV = S::NV;
@@ -233,55 +305,123 @@ __device__ __noinline__ void solve_class(BinSmem<C, NT>& sm, const int k, const 
     zd* A = sm.A[k];
     zd* V = sm.V[k];
     zd* W = sm.W[k];
+    float* par = sm.par[k];
+    const bool exact = (mode != kModeEm) || sm.tiny;
 
-    // --- R_ij from the row sums (float64) ---
-    zd a = zmk(0.0, 0.0);
-    double sumg = 0.0;
-    {
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        const int e = in ? pair_index(lo, hi, C) : 0;
-        const int eo = (in && lo != hi) ? (lo * C - lo * (lo + 1) / 2 + (hi - lo - 1)) : 0;
-        double re = 0.0, im = 0.0;
-        for (int r = 0; r < S::NW * 4; ++r) {
-            const float* row = sm.red[r] + k * NV;
-            re += (double)row[e];
-            im += (double)row[NP + eo];
-            sumg += (double)row[NP + NPO];
-        }
-        if (mode == kModeInitId) {
-            if (k == 0) {
-                const double rt = 1.0 / (double)T;
-                a = zmk(re * rt, (lo != hi) ? (i < j ? im : -im) * rt : 0.0);
-            } else {
-                a = zmk(i == j ? 1.0 : 0.0, 0.0);
+    if (mode == kModeInitId && k == 1) {
+        // R = I (cluster.py:423): L = I, log det = 0, eigenvectors = I
+        if (in) {
+            if (i == j) par[PL::RD + i] = 1.0f;
+            if (i > j) {
+                par[PL::LRE + i * (i - 1) / 2 + j] = 0.f;
+                par[PL::LIM + i * (i - 1) / 2 + j] = 0.f;
             }
-        } else {
-            const double rd = 1.0 / fmax(sumg, kEpsD);
-            a = zmk(re * rd, (lo != hi) ? (i < j ? im : -im) * rd : 0.0);
         }
-        if (!in) a = zmk(0.0, 0.0);
+        if (act) V[lane] = zmk(i == j ? 1.0 : 0.0, 0.0);
+        if (lane == 0) {
+            par[PL::LD] = 0.f;
+            par[PL::ALPHA] = 0.5f;
+            sm.hasV[k] = 1;
+        }
+        return;
     }
-    if (update_alpha && mode == kModeEm && lane == 0) sm.par[k][PL::ALPHA] = (float)(sumg / (double)T);
-    if (mode != kModeEm && lane == 0) sm.par[k][PL::ALPHA] = 0.5f;
 
-    // --- power-of-two scale so that trace ~ 1 (float32 angle arithmetic stays in range) ---
+    // --- float64 sums of the row partials ---
+    for (int v = lane; v < NV; v += 64) {
+        double t = 0.0;
+#pragma unroll 4
+        for (int r = 0; r < S::NW; ++r) t += (double)sm.red[r][k * NV + v];
+        sm.tot[k][v] = t;
+    }
+    wave_lds_fence();
+    zd a = zmk(0.0, 0.0);
+    const double sumg = sm.tot[k][NV - 1];
+    if (in) {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const int e = pair_index(lo, hi, C);
+        const double re = sm.tot[k][e];
+        double im = 0.0;
+        if (lo != hi) {
+            im = sm.tot[k][NP + lo * C - lo * (lo + 1) / 2 + (hi - lo - 1)];
+            if (i > j) im = -im;
+        }
+        const double rd = (mode == kModeInitId) ? 1.0 / (double)T : 1.0 / fmax(sumg, kEpsD);
+        a = zmk(re * rd, im * rd);
+    }
+    if (lane == 0) {
+        if (mode != kModeEm) par[PL::ALPHA] = 0.5f;
+        else if (update_alpha) par[PL::ALPHA] = (float)(sumg / (double)T);
+    }
+
+    // --- power-of-two scale: trace in [0.5, 1) ---
     if (act) A[lane] = a;
     wave_lds_fence();
     double tr = 0.0;
 #pragma unroll
     for (int d = 0; d < C; ++d) tr += A[d * M + d].x;
     int ex = 0;
-    if (tr > 0.0 && tr < 1e300) (void)frexp(tr, &ex);
-    const double scl = ldexp(1.0, ex), rscl = ldexp(1.0, -ex);
+    if (tr > 0.0 && tr < 1e300) ex = __builtin_amdgcn_frexp_exp(tr);
+    const double scl = __builtin_amdgcn_ldexp(1.0, ex), rscl = __builtin_amdgcn_ldexp(1.0, -ex);
     a = zscale(a, rscl);
     tr *= rscl;
-    const double fl = fmax(kEpsD * tr / (double)C, 1e-290);  // <= eps * w_max
     wave_lds_fence();
 
+    // --- fast path: Cholesky of R itself when the eigenvalue floor provably rests ---
+    if (!exact) {
+        bool ok;
+        const zd lcol = chol_lanes<C, M>(A, a, i, j, lane, in, ok);
+        // A now holds garbage of the elimination; publish L for the bound
+        if (in && i >= j) W[lane] = (i == j) ? zmk(lcol.x, lcol.y) : lcol;
+        wave_lds_fence();
+        // column `lane` of L^-1 by forward substitution (float32 is plenty for a bound)
+        float n2 = 0.f;
+        if (lane < C) {
+            float yr[C], yi[C];
+#pragma unroll
+            for (int r = 0; r < C; ++r) {
+                float sr = (r == lane) ? 1.f : 0.f, si = 0.f;
+#pragma unroll
+                for (int c2 = 0; c2 < r; ++c2) {
+                    const zd l = W[r * M + c2];
+                    const float lr = (float)l.x, li = (float)l.y;
+                    sr -= lr * yr[c2] - li * yi[c2];
+                    si -= lr * yi[c2] + li * yr[c2];
+                }
+                const float rdg = (float)W[r * M + r].y;
+                yr[r] = (r < lane) ? 0.f : sr * rdg;
+                yi[r] = (r < lane) ? 0.f : si * rdg;
+                n2 += yr[r] * yr[r] + yi[r] * yi[r];
+            }
+            sm.cert[k][lane] = n2;
+        }
+        wave_lds_fence();
+        float tinv = 0.f;
+#pragma unroll
+        for (int d = 0; d < C; ++d) tinv += sm.cert[k][d];
+        // lambda_min >= 1 / trace(R^-1); lambda_max <= trace(R)
+        const bool certified = __all(ok) && (tinv * (float)tr * (1.1f * kEpsF) < 1.0f) && tinv > 0.f;
+        if (certified) {
+            write_factor<C>(par, lcol, i, j, in);
+            // log det R = -2 sum log(1 / L_ii)
+            if (lane < C) sm.cert[k][lane] = __logf((float)W[lane * M + lane].y);
+            wave_lds_fence();
+            float ld = 0.f;
+#pragma unroll
+            for (int d = 0; d < C; ++d) ld += sm.cert[k][d];
+            if (lane == 0) {
+                par[PL::LD] = -2.0f * ld;
+                sm.hasV[k] = 0;  // the eigenvectors are stale now
+                sm.nfast[k] += 1;
+            }
+            return;
+        }
+        wave_lds_fence();
+    }
+
+    const double fl = fmax(kEpsD * tr / (double)C, 1e-290);  // <= eps * w_max
     // --- warm start: A <- V^H R V with the previous eigenvectors ---
     zd v = zmk(i == j ? 1.0 : 0.0, 0.0);
-    const int warm = sm.hasV[k];
-    if (warm) {
+    if (sm.hasV[k]) {
         if (act) A[lane] = a;
         wave_lds_fence();
         v = act ? V[lane] : zmk(0.0, 0.0);
@@ -372,12 +512,17 @@ __device__ __noinline__ void solve_class(BinSmem<C, NT>& sm, const int k, const 
     double wmax = -1e300;
 #pragma unroll
     for (int d = 0; d < C; ++d) wmax = fmax(wmax, A[d * M + d].x);
-    const double rs = 1.0 / fmax(wmax * scl, kEpsD);
-    if (act && i == j && i < C) sm.wv[k][i] = fmax(a.x * scl * rs, kEpsD);
+    const double sabs = exact ? scl : 1.0;
+    const double rs = exact ? 1.0 / fmax(wmax * scl, kEpsD) : rcp64(fmax(wmax, 1e-300));
+    if (act && i == j && i < C) {
+        const double wp = fmax(a.x * sabs * rs, kEpsD);
+        sm.wv[k][i] = wp;
+        sm.cert[k][i] = __logf((float)wp);
+    }
     wave_lds_fence();
     float ld = 0.f;
 #pragma unroll
-    for (int d = 0; d < C; ++d) ld += logf((float)sm.wv[k][d]);
+    for (int d = 0; d < C; ++d) ld += sm.cert[k][d];
 
     // --- R_eff = V diag(w') V^H, then its Cholesky factor ---
     zd re = zmk(0.0, 0.0);
@@ -388,157 +533,196 @@ __device__ __noinline__ void solve_class(BinSmem<C, NT>& sm, const int k, const 
     }
     if (i == j) re.y = 0.0;
     wave_lds_fence();
-    // right-looking Cholesky on the lower triangle; lane (i, j), i >= j, owns a_ij
-    zd lcol = zmk(0.0, 0.0);  // final L_ij of this lane
-#pragma unroll
-    for (int kk = 0; kk < C; ++kk) {
-        if (in) A[lane] = re;
-        wave_lds_fence();
-        if (in && i >= j && j >= kk) {
-            const double akk = A[kk * M + kk].x;
-            if (j == kk) {
-                const double rq = rsq64(fmax(akk, 1e-300));
-                lcol = (i == kk) ? zmk(akk * rq, rq) : zscale(re, rq);  // diagonal lane: (L_kk, 1 / L_kk)
-            } else {
-                const zd aik = A[i * M + kk], ajk = A[j * M + kk];
-                re = zsub(re, zscale(zmulc(aik, ajk), rcp64(fmax(akk, 1e-300))));
-                if (i == j) re.y = 0.0;
-            }
-        }
-        wave_lds_fence();
-    }
-    if (in) {
-        float* p = sm.par[k];
-        if (i == j) {
-            p[PL::RD + i] = (float)lcol.y;
-        } else if (i > j) {
-            const int e = i * (i - 1) / 2 + j;
-            p[PL::LRE + e] = (float)lcol.x;
-            p[PL::LIM + e] = (float)lcol.y;
-        }
-    }
+    bool ok;
+    const zd lcol = chol_lanes<C, M>(A, re, i, j, lane, in, ok);
+    write_factor<C>(par, lcol, i, j, in);
     if (lane == 0) {
-        sm.par[k][PL::LD] = ld;
+        par[PL::LD] = ld;
         sm.hasV[k] = 1;
     }
 }
 
-// ---- the passes over the thread's frames -------------------------------------------------
-// Frames are walked in chunks of NT x U (thread tid owns frames base + tid + NT u); per
-// chunk the quadratic forms of class 0, then of class 1 (only ONE class's Cholesky factor
-// sits in SGPRs at a time), then posterior + accumulation.  The first RF frames of
-// chunk 0 live in registers (xr), everything else in the LDS tile Xs[C][Tlp].
-template <int C, int NT, int RF, int U, bool FIRST, int MODE>
-ZD void chunk_pass(const int base, const int tid, const int T, const cf (&xr)[RF > 0 ? RF : 1][C],
-                   const cf* Xs, const int Tlp, const float* par0, const float* par1, Acc<C>& acc,
-                   const CgmmBinArgs& a, const int f) {
+// ---- one pass over the thread's frames -----------------------------------------------------
+// Thread tid owns frames t_u = tid + NT u, u < U (one chunk: T <= NT U); frames u < RF live
+// in registers, the others in Xs[c][tid + NT (u - RF)].
+template <int C, int NT, int U, int RF, int MODE>
+ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&xr)[RF > 0 ? RF : 1][C],
+                    const cf* Xs, const int Tlp, const CgmmBinArgs& a, const int f) {
+    typedef BinSmem<C, NT> S;
     typedef ParLayout<C> PL;
-    auto getx = [&](int u, int t, cf (&x)[C]) {
-        if (FIRST && u < RF) {
+    constexpr int NP = S::NP, NPO = S::NPO, NV = S::NV;
+    auto getx = [&](auto uc, cf (&x)[C]) {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (u < RF) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) x[c] = xr[u < RF ? u : 0][c];
+            for (int c = 0; c < C; ++c) x[c] = xr[u][c];
         } else {
 #pragma unroll
-            for (int c = 0; c < C; ++c) x[c] = Xs[c * Tlp + (t - NT * RF)];
+            for (int c = 0; c < C; ++c) x[c] = Xs[c * Tlp + tid + NT * (u - RF)];
         }
     };
-    if (MODE == kModeInitId || MODE == kModeInitMask) {
+    float w0[U], w1[U];
+    float sg0 = 0.f, sg1 = 0.f;
+    if constexpr (MODE == kModeInitId) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = base + tid + NT * u;
+            w0[u] = 1.0f;
+            w1[u] = 0.f;
+        }
+    } else if constexpr (MODE == kModeInitMask) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tid + NT * u;
+            const float g0 = (t < T) ? a.init_mask[(size_t)t * a.F + f] : 0.f;
+            w0[u] = g0;
+            w1[u] = 1.0f - g0;
             if (t < T) {
-                cf x[C];
-                getx(u, t, x);
-                if (MODE == kModeInitId) {
-                    accumulate<C, false>(x, 1.0f, 0.f, acc);
-                } else {
-                    const float g0 = a.init_mask[(size_t)t * a.F + f], g1 = 1.0f - g0;
-                    acc.sg[0] += g0;
-                    acc.sg[1] += g1;
-                    accumulate<C, true>(x, g0, g1, acc);
+                sg0 += g0;
+                sg1 += 1.0f - g0;
+            }
+        }
+    } else {
+        float q0[U], q1[U];
+        {
+            ClassPar<C> p;
+            load_par<C>(sm.par[0], p);
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                q0[u] = 1.f;
+                if (tid + NT * u < T) {
+                    cf x[C];
+                    getx(uc, x);
+                    q0[u] = quad_form<C>(x, p);
                 }
-            }
-            reload_fence();
-        }
-        return;
-    }
-    float q0[U], q1[U];
-    {
-        ClassPar<C> p;
-        load_par<C>(par0, p);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int t = base + tid + NT * u;
-            q0[u] = 1.f;
-            if (t < T) {
-                cf x[C];
-                getx(u, t, x);
-                q0[u] = quad_form<C>(x, p);
-            }
-            reload_fence();
-        }
-    }
-    {
-        ClassPar<C> p;
-        load_par<C>(par1, p);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int t = base + tid + NT * u;
-            q1[u] = 1.f;
-            if (t < T) {
-                cf x[C];
-                getx(u, t, x);
-                q1[u] = quad_form<C>(x, p);
-            }
-            reload_fence();
-        }
-    }
-    const float ld0 = sgpr(par0[PL::LD]), ld1 = sgpr(par1[PL::LD]);
-    const float al0 = sgpr(par0[PL::ALPHA]), al1 = sgpr(par1[PL::ALPHA]);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int t = base + tid + NT * u;
-        if (t < T) {
-            // cluster.py:207-235, 261-287
-            const float ph0 = fmaxf(q0[u], kEpsF) * (1.0f / C), ph1 = fmaxf(q1[u], kEpsF) * (1.0f / C);
-            const float l0 = fmaf(-(float)C, __logf(ph0), -ld0);
-            const float l1 = fmaf(-(float)C, __logf(ph1), -ld1);
-            const float mx = fmaxf(l0, l1);
-            const float n0 = al0 * __expf(l0 - mx), n1 = al1 * __expf(l1 - mx);
-            const float rden = __frcp_rn(fmaxf(n0 + n1, kEpsF));
-            const float g0 = n0 * rden, g1 = n1 * rden;
-            if (MODE == kModeEm) {
-                cf x[C];
-                getx(u, t, x);
-                acc.sg[0] += g0;
-                acc.sg[1] += g1;
-                accumulate<C, true>(x, g0 * __frcp_rn(ph0) * (float)C, g1 * __frcp_rn(ph1) * (float)C,
-                                    acc);
-            } else {
-                a.gamma_bm[(size_t)f * a.Tp + t] = g0;
-                if (a.nout > 1) a.gamma_bm[((size_t)a.F + f) * a.Tp + t] = g1;
-            }
+                reload_fence();
+            });
         }
         reload_fence();
+        {
+            ClassPar<C> p;
+            load_par<C>(sm.par[1], p);
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                q1[u] = 1.f;
+                if (tid + NT * u < T) {
+                    cf x[C];
+                    getx(uc, x);
+                    q1[u] = quad_form<C>(x, p);
+                }
+                reload_fence();
+            });
+        }
+        reload_fence();
+        constexpr float kLog2e = 1.4426950408889634f;
+        const float ld0 = sgpr(sm.par[0][PL::LD]) * kLog2e, ld1 = sgpr(sm.par[1][PL::LD]) * kLog2e;
+        const float al0 = sgpr(sm.par[0][PL::ALPHA]), al1 = sgpr(sm.par[1][PL::ALPHA]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tid + NT * u;
+            // cluster.py:207-235, 261-287, in base 2 on the hardware log2 / exp2 / rcp
+            // (1 ulp each; phi >= eps / M is far from the subnormal range)
+            const float ph0 = fmaxf(q0[u], kEpsF) * (1.0f / C), ph1 = fmaxf(q1[u], kEpsF) * (1.0f / C);
+            const float l0 = fmaf(-(float)C, __builtin_amdgcn_logf(ph0), -ld0);
+            const float l1 = fmaf(-(float)C, __builtin_amdgcn_logf(ph1), -ld1);
+            const float mx = fmaxf(l0, l1);
+            const float n0 = al0 * __builtin_amdgcn_exp2f(l0 - mx), n1 = al1 * __builtin_amdgcn_exp2f(l1 - mx);
+            const float rden = __builtin_amdgcn_rcpf(fmaxf(n0 + n1, kEpsF));
+            const float g0 = n0 * rden, g1 = n1 * rden;
+            if constexpr (MODE == kModeEm) {
+                w0[u] = g0 * __builtin_amdgcn_rcpf(ph0) * (float)C;
+                w1[u] = g1 * __builtin_amdgcn_rcpf(ph1) * (float)C;
+                if (t < T) {
+                    sg0 += g0;
+                    sg1 += g1;
+                }
+            } else {
+                if (t < T) {
+                    a.gamma_bm[(size_t)f * a.Tp + t] = g0;
+                    if (a.nout > 1) a.gamma_bm[((size_t)a.F + f) * a.Tp + t] = g1;
+                }
+            }
+        }
+        if constexpr (MODE == kModeFinal) return;
+    }
+
+    const int wave = tid >> 6, lane = tid & 63;
+    float* row = sm.red[wave];
+    const bool wr = lane == 63;
+    // ---- real parts: sum_t w_k Re(x_i conj x_j), i <= j ----
+    {
+        float acc[2][NP];
+#pragma unroll
+        for (int e = 0; e < NP; ++e) acc[0][e] = acc[1][e] = 0.f;
+        static_for<U>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if (tid + NT * u < T) {
+                cf x[C];
+                getx(uc, x);
+                int e = 0;
+#pragma unroll
+                for (int i = 0; i < C; ++i)
+#pragma unroll
+                    for (int j = i; j < C; ++j) {
+                        const float pr = fmaf(x[i].x, x[j].x, x[i].y * x[j].y);
+                        acc[0][e] = fmaf(w0[u], pr, acc[0][e]);
+                        acc[1][e] = fmaf(w1[u], pr, acc[1][e]);
+                        ++e;
+                    }
+            }
+            reload_fence();
+        });
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < NP; ++e) {
+                const float s = wave_sum(acc[k][e]);
+                if (wr) row[k * NV + e] = s;
+            }
+    }
+    reload_fence();
+    // ---- imaginary parts, i < j, and the posterior sums ----
+    {
+        float acc[2][NPO > 0 ? NPO : 1];
+#pragma unroll
+        for (int e = 0; e < (NPO > 0 ? NPO : 1); ++e) acc[0][e] = acc[1][e] = 0.f;
+        static_for<U>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if (tid + NT * u < T) {
+                cf x[C];
+                getx(uc, x);
+                int e = 0;
+#pragma unroll
+                for (int i = 0; i < C; ++i)
+#pragma unroll
+                    for (int j = i + 1; j < C; ++j) {
+                        const float pi = fmaf(x[i].y, x[j].x, -x[i].x * x[j].y);
+                        acc[0][e] = fmaf(w0[u], pi, acc[0][e]);
+                        acc[1][e] = fmaf(w1[u], pi, acc[1][e]);
+                        ++e;
+                    }
+            }
+            reload_fence();
+        });
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < NPO; ++e) {
+                const float s = wave_sum(acc[k][e]);
+                if (wr) row[k * NV + NP + e] = s;
+            }
+        const float s0 = wave_sum(sg0), s1 = wave_sum(sg1);
+        if (wr) {
+            row[NV - 1] = s0;
+            row[2 * NV - 1] = s1;
+        }
     }
 }
 
-template <int C, int NT, int RF, int U, int MODE>
-ZD void frames_pass(const int tid, const int T, const cf (&xr)[RF > 0 ? RF : 1][C], const cf* Xs,
-                    const int Tlp, const float* par0, const float* par1, Acc<C>& acc,
-                    const CgmmBinArgs& a, const int f) {
-    chunk_pass<C, NT, RF, U, true, MODE>(0, tid, T, xr, Xs, Tlp, par0, par1, acc, a, f);
-    for (int base = NT * U; base < T; base += NT * U)
-        chunk_pass<C, NT, RF, U, false, MODE>(base, tid, T, xr, Xs, Tlp, par0, par1, acc, a, f);
-}
-
-template <int C, int NT, int RF, int WPS>
+template <int C, int NT, int U, int RF, int WPS>
 __global__ __launch_bounds__(NT, WPS) void cgmm_bin_em_kernel(const CgmmBinArgs* __restrict__ tbl,
-                                                              int num_iters) {
+                                                              int num_iters, int Tlp) {
     typedef BinSmem<C, NT> S;
-    constexpr int NP = S::NP, NPO = S::NPO, NV = S::NV;
-    constexpr int U = 4;
-    static_assert(RF <= U, "register frames belong to chunk 0");
+    static_assert(RF <= U, "register frames are frames of the one chunk");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     S& sm = *reinterpret_cast<S*>(smem_raw);
     cf* Xs = reinterpret_cast<cf*>(smem_raw + ((sizeof(S) + 15) & ~(size_t)15));  // [C][Tlp]
@@ -548,69 +732,63 @@ __global__ __launch_bounds__(NT, WPS) void cgmm_bin_em_kernel(const CgmmBinArgs*
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int T = a.T, Tp = a.Tp;
-    const int Tl = max(T - NT * RF, 0);          // frames kept in LDS
-    const int Tlp = (Tl + 1) & ~1;               // row pitch of Xs
 
-    // ---- load the bin: frames tid + NT i; i < RF in registers, the rest in LDS ----
+    // ---- load the bin; flag bins that hold a near-silent frame ----
     const cf* xg = a.xb + (size_t)f * C * Tp;
     cf xr[RF > 0 ? RF : 1][C];
+    float nmin = 1e30f;
 #pragma unroll
-    for (int i = 0; i < RF; ++i) {
-        const int t = tid + NT * i;
+    for (int u = 0; u < U; ++u) {
+        const int t = tid + NT * u;
+        float n2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) xr[i][c] = (t < T) ? xg[(size_t)c * Tp + t] : make_float2(0.f, 0.f);
+        for (int c = 0; c < C; ++c) {
+            const cf x = (t < T) ? xg[(size_t)c * Tp + t] : make_float2(0.f, 0.f);
+            n2 = fmaf(x.x, x.x, fmaf(x.y, x.y, n2));
+            if (u < RF) xr[u < RF ? u : 0][c] = x;
+            else if (t < T) Xs[c * Tlp + tid + NT * (u - RF)] = x;
+        }
+        if (t < T) nmin = fminf(nmin, n2);
     }
-    for (int t = NT * RF + tid; t < T; t += NT) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) Xs[c * Tlp + (t - NT * RF)] = xg[(size_t)c * Tp + t];
+    if (tid < 2) {
+        sm.hasV[tid] = 0;
+        sm.nfast[tid] = 0;
     }
-    if (tid < 2) sm.hasV[tid] = 0;
+    if (tid == 0) sm.tiny = 0;
+    __syncthreads();
+    if (nmin < 1.5f * kEpsF) sm.tiny = 1;
     __syncthreads();
 
     const int npass = num_iters + 2;
     for (int pass = 0; pass < npass; ++pass) {
         const int mode = pass == 0 ? (a.init_mask ? kModeInitMask : kModeInitId)
                                    : (pass == npass - 1 ? kModeFinal : kModeEm);
-        Acc<C> acc;
-#pragma unroll
-        for (int e = 0; e < NP; ++e) acc.re[0][e] = acc.re[1][e] = 0.f;
-#pragma unroll
-        for (int e = 0; e < (NPO > 0 ? NPO : 1); ++e) acc.im[0][e] = acc.im[1][e] = 0.f;
-        acc.sg[0] = acc.sg[1] = 0.f;
-
+        const long long tc0 = a.timing ? (long long)__builtin_readcyclecounter() : 0;
         if (mode == kModeEm)
-            frames_pass<C, NT, RF, U, kModeEm>(tid, T, xr, Xs, Tlp, sm.par[0], sm.par[1], acc, a, f);
+            frames_pass<C, NT, U, RF, kModeEm>(sm, tid, T, xr, Xs, Tlp, a, f);
         else if (mode == kModeFinal)
-            frames_pass<C, NT, RF, U, kModeFinal>(tid, T, xr, Xs, Tlp, sm.par[0], sm.par[1], acc, a, f);
+            frames_pass<C, NT, U, RF, kModeFinal>(sm, tid, T, xr, Xs, Tlp, a, f);
         else if (mode == kModeInitId)
-            frames_pass<C, NT, RF, U, kModeInitId>(tid, T, xr, Xs, Tlp, sm.par[0], sm.par[1], acc, a, f);
+            frames_pass<C, NT, U, RF, kModeInitId>(sm, tid, T, xr, Xs, Tlp, a, f);
         else
-            frames_pass<C, NT, RF, U, kModeInitMask>(tid, T, xr, Xs, Tlp, sm.par[0], sm.par[1], acc, a, f);
+            frames_pass<C, NT, U, RF, kModeInitMask>(sm, tid, T, xr, Xs, Tlp, a, f);
         if (mode == kModeFinal) break;
-
-        // ---- row sums -> LDS ----
-        {
-            float* row = sm.red[wave * 4 + (lane >> 4)];
-            const bool wr = (lane & 15) == 15;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-#pragma unroll
-                for (int e = 0; e < NP; ++e) {
-                    const float s = row_sum16(acc.re[k][e]);
-                    if (wr) row[k * NV + e] = s;
-                }
-#pragma unroll
-                for (int e = 0; e < NPO; ++e) {
-                    const float s = row_sum16(acc.im[k][e]);
-                    if (wr) row[k * NV + NP + e] = s;
-                }
-                const float s = row_sum16(acc.sg[k]);
-                if (wr) row[k * NV + NP + NPO] = s;
-            }
-        }
+        const long long tc2 = a.timing ? (long long)__builtin_readcyclecounter() : 0;
         __syncthreads();
+        const long long tc3 = a.timing ? (long long)__builtin_readcyclecounter() : 0;
         if (wave < 2) solve_class<C, NT>(sm, wave, lane, mode, T, a.update_alpha);
+        const long long tc4 = a.timing ? (long long)__builtin_readcyclecounter() : 0;
         __syncthreads();
+        if (a.timing && tid == 0) {
+            long long* tm = a.timing + (size_t)f * 8;
+            tm[0] += tc2 - tc0;   // frames + row sums
+            tm[2] += tc3 - tc2;   // barrier wait (wave 0)
+            tm[3] += tc4 - tc3;   // solve (wave 0 = class 0)
+            tm[4] += (long long)__builtin_readcyclecounter() - tc4;
+            tm[5] += 1;
+            tm[6] = sm.nfast[0];
+            tm[7] = sm.nfast[1];
+        }
     }
 }
 
@@ -674,20 +852,37 @@ __global__ __launch_bounds__(256) void binmajor_to_tf_kernel(const CgmmBinArgs* 
     }
 }
 
-template <int C, int NT, int RF>
-size_t bin_lds_bytes(int max_frames) {
-    const int Tl = std::max(max_frames - NT * RF, 0);
-    const int Tlp = (Tl + 1) & ~1;
-    return ((sizeof(BinSmem<C, NT>) + 15) & ~(size_t)15) + (size_t)C * Tlp * sizeof(cf);
-}
-
+struct BinCfg {
+    int nt, u, rf, wps;
+};
+// frames per thread U, of which RF in registers; WPS = waves per SIMD the register budget
+// is cut for (4: 128 VGPRs, 3: 168)
+constexpr BinCfg kCfgs[] = {
+    {256, 2, 1, 4},   // T <=  512
+    {256, 4, 2, 4},   // T <= 1024
+    {512, 4, 1, 4},   // T <= 2048, two workgroups per CU
+    {256, 8, 4, 3},   // T <= 2048, three workgroups per CU (spills: slower, kept for A/B)
+    {512, 8, 2, 4},   // T <= 4096
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr size_t kLdsLimit = 160 * 1024;
 
-template <int C, int NT, int RF, int WPS>
-hipError_t launch_bin_t(const CgmmBinArgs* d_tbl, int n_utts, int F, int max_frames, int num_iters,
-                        hipStream_t s) {
-    const size_t lds = bin_lds_bytes<C, NT, RF>(max_frames);
-    auto kern = cgmm_bin_em_kernel<C, NT, RF, WPS>;
+// row pitch of the LDS tile: the frames of the longest utterance that are not in registers
+inline int lds_frames(int max_frames, int nt, int rf) { return (std::max(max_frames - nt * rf, 0) + 1) & ~1; }
+
+template <int C, int NT>
+size_t bin_lds_bytes(int tlp) {
+    return ((sizeof(BinSmem<C, NT>) + 15) & ~(size_t)15) + (size_t)C * tlp * sizeof(cf);
+}
+
+template <int C, int I>
+hipError_t launch_cfg(const CgmmBinArgs* d_tbl, int n_utts, int F, int max_frames, int num_iters,
+                      hipStream_t s) {
+    constexpr BinCfg c = kCfgs[I];
+    const int tlp = lds_frames(max_frames, c.nt, c.rf);
+    const size_t lds = bin_lds_bytes<C, c.nt>(tlp);
+    if (lds > kLdsLimit) return hipErrorInvalidValue;
+    auto kern = cgmm_bin_em_kernel<C, c.nt, c.u, c.rf, c.wps>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -695,34 +890,42 @@ hipError_t launch_bin_t(const CgmmBinArgs* d_tbl, int n_utts, int F, int max_fra
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(F, n_utts), dim3(NT), lds, s, d_tbl, num_iters);
+    hipLaunchKernelGGL(kern, dim3(F, n_utts), dim3(c.nt), lds, s, d_tbl, num_iters, tlp);
     return hipGetLastError();
 }
 
 template <int C>
 hipError_t launch_bin_c(const CgmmBinArgs* d_tbl, int n_utts, int F, int max_frames, int num_iters,
-                        int nt, hipStream_t s) {
-    if (nt == 256) return launch_bin_t<C, 256, 1, 4>(d_tbl, n_utts, F, max_frames, num_iters, s);
-    return launch_bin_t<C, 512, 1, 4>(d_tbl, n_utts, F, max_frames, num_iters, s);
+                        int cfg, hipStream_t s) {
+    switch (cfg) {
+        case 0: return launch_cfg<C, 0>(d_tbl, n_utts, F, max_frames, num_iters, s);
+        case 1: return launch_cfg<C, 1>(d_tbl, n_utts, F, max_frames, num_iters, s);
+        case 2: return launch_cfg<C, 2>(d_tbl, n_utts, F, max_frames, num_iters, s);
+        case 3: return launch_cfg<C, 3>(d_tbl, n_utts, F, max_frames, num_iters, s);
+        case 4: return launch_cfg<C, 4>(d_tbl, n_utts, F, max_frames, num_iters, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int C>
-size_t lds_need_c(int max_frames, int nt) {
-    return nt == 256 ? bin_lds_bytes<C, 256, 1>(max_frames) : bin_lds_bytes<C, 512, 1>(max_frames);
+bool cfg_fits(int cfg, int max_frames) {
+    const BinCfg c = kCfgs[cfg];
+    const int tlp = lds_frames(max_frames, c.nt, c.rf);
+    return (c.nt == 256 ? bin_lds_bytes<C, 256>(tlp) : bin_lds_bytes<C, 512>(tlp)) <= kLdsLimit;
 }
 
-size_t lds_need(int C, int max_frames, int nt) {
+bool cfg_fits_c(int C, int cfg, int max_frames) {
     switch (C) {
-        case 1: return lds_need_c<1>(max_frames, nt);
-        case 2: return lds_need_c<2>(max_frames, nt);
-        case 3: return lds_need_c<3>(max_frames, nt);
-        case 4: return lds_need_c<4>(max_frames, nt);
-        case 5: return lds_need_c<5>(max_frames, nt);
-        case 6: return lds_need_c<6>(max_frames, nt);
-        case 7: return lds_need_c<7>(max_frames, nt);
-        case 8: return lds_need_c<8>(max_frames, nt);
+        case 1: return cfg_fits<1>(cfg, max_frames);
+        case 2: return cfg_fits<2>(cfg, max_frames);
+        case 3: return cfg_fits<3>(cfg, max_frames);
+        case 4: return cfg_fits<4>(cfg, max_frames);
+        case 5: return cfg_fits<5>(cfg, max_frames);
+        case 6: return cfg_fits<6>(cfg, max_frames);
+        case 7: return cfg_fits<7>(cfg, max_frames);
+        case 8: return cfg_fits<8>(cfg, max_frames);
     }
-    return (size_t)-1;
+    return false;
 }
 
 }  // namespace
@@ -732,18 +935,30 @@ size_t cgmm_bin_args_bytes() { return sizeof(CgmmBinArgs); }
 // frames pitch of the bin-major arrays
 int cgmm_bin_pitch(int T) { return (T + 3) & ~3; }
 
-// threads per workgroup for a batch whose longest utterance has max_frames frames;
-// 0 when the bin does not fit the CU (caller then uses the streaming kernels of cgmm.hip)
+// configuration (index into kCfgs) for a batch whose longest utterance has max_frames
+// frames; -1 when the bin does not fit a CU (the caller then uses the streaming kernels of
+// cgmm.hip).  SETK_CGMM_CFG=<index> forces one (A/B measurements).
+int cgmm_bin_config(int C, int max_frames) {
+    if (C < 1 || C > kMaxChannels) return -1;
+    static const int forced = [] {
+        const char* e = getenv("SETK_CGMM_CFG");
+        return (e && *e) ? atoi(e) : -1;
+    }();
+    if (forced >= 0 && forced < kNumCfgs && kCfgs[forced].nt * kCfgs[forced].u >= max_frames &&
+        cfg_fits_c(C, forced, max_frames))
+        return forced;
+    for (int i = 0; i < kNumCfgs; ++i)
+        if (kCfgs[i].nt * kCfgs[i].u >= max_frames && cfg_fits_c(C, i, max_frames)) return i;
+    return -1;
+}
+
 int cgmm_bin_threads(int C, int max_frames) {
-    if (C < 1 || C > kMaxChannels) return 0;
-    const int nt = max_frames > 1024 ? 512 : 256;
-    if (lds_need(C, max_frames, nt) <= kLdsLimit) return nt;
-    if (nt == 256 && lds_need(C, max_frames, 512) <= kLdsLimit) return 512;
-    return 0;
+    const int c = cgmm_bin_config(C, max_frames);
+    return c < 0 ? 0 : kCfgs[c].nt;
 }
 
 void cgmm_bin_fill_args(void* out, const float* xb, const float* init_mask, float* gamma_bm, int T,
-                        int F, int update_alpha, int nout) {
+                        int F, int update_alpha, int nout, void* timing) {
     CgmmBinArgs a;
     std::memset(&a, 0, sizeof(a));
     a.xb = reinterpret_cast<const cf*>(xb);
@@ -754,6 +969,7 @@ void cgmm_bin_fill_args(void* out, const float* xb, const float* init_mask, floa
     a.F = F;
     a.update_alpha = update_alpha;
     a.nout = nout;
+    a.timing = static_cast<long long*>(timing);
     std::memcpy(out, &a, sizeof(a));
 }
 
@@ -761,8 +977,8 @@ hipError_t launch_cgmm_bin(int C, const void* d_tbl, const float* const* d_spec_
                            float* const* d_mask_ptrs, float* const* d_gamma_ptrs, int n_utts, int F,
                            int max_frames, int num_iters, int nout, hipStream_t s) {
     const CgmmBinArgs* t = static_cast<const CgmmBinArgs*>(d_tbl);
-    const int nt = cgmm_bin_threads(C, max_frames);
-    if (!nt) return hipErrorInvalidValue;
+    const int cfg = cgmm_bin_config(C, max_frames);
+    if (cfg < 0) return hipErrorInvalidValue;
     {
         const int ntt = (max_frames + 31) / 32;
         dim3 g(ntt * C, (F + 31) / 32, n_utts);
@@ -771,14 +987,14 @@ hipError_t launch_cgmm_bin(int C, const void* d_tbl, const float* const* d_spec_
     }
     hipError_t e = hipErrorInvalidValue;
     switch (C) {
-        case 1: e = launch_bin_c<1>(t, n_utts, F, max_frames, num_iters, nt, s); break;
-        case 2: e = launch_bin_c<2>(t, n_utts, F, max_frames, num_iters, nt, s); break;
-        case 3: e = launch_bin_c<3>(t, n_utts, F, max_frames, num_iters, nt, s); break;
-        case 4: e = launch_bin_c<4>(t, n_utts, F, max_frames, num_iters, nt, s); break;
-        case 5: e = launch_bin_c<5>(t, n_utts, F, max_frames, num_iters, nt, s); break;
-        case 6: e = launch_bin_c<6>(t, n_utts, F, max_frames, num_iters, nt, s); break;
-        case 7: e = launch_bin_c<7>(t, n_utts, F, max_frames, num_iters, nt, s); break;
-        case 8: e = launch_bin_c<8>(t, n_utts, F, max_frames, num_iters, nt, s); break;
+        case 1: e = launch_bin_c<1>(t, n_utts, F, max_frames, num_iters, cfg, s); break;
+        case 2: e = launch_bin_c<2>(t, n_utts, F, max_frames, num_iters, cfg, s); break;
+        case 3: e = launch_bin_c<3>(t, n_utts, F, max_frames, num_iters, cfg, s); break;
+        case 4: e = launch_bin_c<4>(t, n_utts, F, max_frames, num_iters, cfg, s); break;
+        case 5: e = launch_bin_c<5>(t, n_utts, F, max_frames, num_iters, cfg, s); break;
+        case 6: e = launch_bin_c<6>(t, n_utts, F, max_frames, num_iters, cfg, s); break;
+        case 7: e = launch_bin_c<7>(t, n_utts, F, max_frames, num_iters, cfg, s); break;
+        case 8: e = launch_bin_c<8>(t, n_utts, F, max_frames, num_iters, cfg, s); break;
     }
     if (e != hipSuccess) return e;
     {

@@ -171,7 +171,7 @@ size_t cgmm_bin_args_bytes();
 int cgmm_bin_pitch(int T);
 int cgmm_bin_threads(int C, int max_frames);
 void cgmm_bin_fill_args(void* out, const float* xb, const float* init_mask, float* gamma_bm, int T,
-                        int F, int update_alpha, int nout);
+                        int F, int update_alpha, int nout, void* timing);
 hipError_t launch_cgmm_bin(int C, const void* d_tbl, const float* const* d_spec_ptrs, int spec_pitch,
                            float* const* d_mask_ptrs, float* const* d_gamma_ptrs, int n_utts, int F,
                            int max_frames, int num_iters, int nout, hipStream_t s);

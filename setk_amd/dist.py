@@ -26,7 +26,11 @@ class Shard:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
+            if "MASTER_PORT" not in os.environ:
+                # the ranks can only agree on a port through their launcher
+                raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: start the ranks with "
+                                   "`python -m torch.distributed.run --master-addr 127.0.0.1 "
+                                   "--master-port <free port> ...` (or export MASTER_PORT)")
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             if not dist.is_initialized():

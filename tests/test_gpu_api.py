@@ -311,6 +311,20 @@ def test_bench_contract_single_and_two_ranks():
     # whole-job aggregate: audio of both ranks over the slower rank's time
     audio = 2 * 6 * 4.0 * 2
     assert abs(two["value"] * two["ms_per_step"] * 2 / 1e3 - audio) / audio < 1e-3
+    assert len(two["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in two["per_rank_ms_per_step"])
+
+    # `python bench.py --gpus 2` with no launcher around it starts its two ranks itself
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"] + small, capture_output=True,
+                       text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert json.loads(lines[0])["n_gpus"] == 2
+    assert "[bench rank 0/2]" in r.stderr and "[bench rank 1/2]" in r.stderr
+    # a launcher whose world size disagrees with --gpus is refused
+    bad = subprocess.run(cmd[:-len(small) - 1] + ["3"] + small, capture_output=True, text=True,
+                         timeout=900, cwd=root, env=env)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
 
 
 def test_pcm16_device_ingest_is_bit_identical(tmp_path):
