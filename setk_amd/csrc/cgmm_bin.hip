@@ -106,15 +106,38 @@ ZD float dppf(float v) {
     return __builtin_bit_cast(
         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RM, 0xf, true));
 }
-// sum over the wavefront (pairwise tree), result in lane 63
-ZD float wave_sum(float v) {
-    v += dppf<0x111>(v);        // row_shr:1
-    v += dppf<0x112>(v);        // row_shr:2
-    v += dppf<0x114>(v);        // row_shr:4
-    v += dppf<0x118>(v);        // row_shr:8   -> lane 15 of each row
-    v += dppf<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v += dppf<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63
-    return v;
+// Sums over the wavefront (pairwise tree in float32), results in lane 63: six DPP adds
+// per value, hand-interleaved over groups of values so that no step waits out the two
+// DPP wait states behind its producer (the compiler serialises the chains and cannot fold
+// the row_mask'ed broadcast steps into the add).
+#define SETK_DPP_STEP6(CTRL)                         \
+    "v_add_f32_dpp %0, %0, %0 " CTRL "\n"            \
+    "v_add_f32_dpp %1, %1, %1 " CTRL "\n"            \
+    "v_add_f32_dpp %2, %2, %2 " CTRL "\n"            \
+    "v_add_f32_dpp %3, %3, %3 " CTRL "\n"            \
+    "v_add_f32_dpp %4, %4, %4 " CTRL "\n"            \
+    "v_add_f32_dpp %5, %5, %5 " CTRL "\n"
+ZD void wave_sum6(float& a, float& b, float& c, float& d, float& e, float& f) {
+    asm volatile(
+        "s_nop 1\n"
+        SETK_DPP_STEP6("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SETK_DPP_STEP6("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SETK_DPP_STEP6("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SETK_DPP_STEP6("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SETK_DPP_STEP6("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        SETK_DPP_STEP6("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
+// in place over an array (N padded up to a multiple of 6 with dummies)
+template <int N>
+ZD void wave_sum_array(float (&v)[N]) {
+    float pad[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < N; g += 6) {
+        wave_sum6(v[g], g + 1 < N ? v[g + 1] : pad[1], g + 2 < N ? v[g + 2] : pad[2],
+                  g + 3 < N ? v[g + 3] : pad[3], g + 4 < N ? v[g + 4] : pad[4],
+                  g + 5 < N ? v[g + 5] : pad[5]);
+    }
 }
 
 template <int N, typename Fn, int I = 0>
@@ -671,13 +694,14 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
             }
             reload_fence();
         });
+        wave_sum_array(acc[0]);
+        wave_sum_array(acc[1]);
+        if (wr) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int e = 0; e < NP; ++e) {
-                const float s = wave_sum(acc[k][e]);
-                if (wr) row[k * NV + e] = s;
-            }
+                for (int e = 0; e < NP; ++e) row[k * NV + e] = acc[k][e];
+        }
     }
     reload_fence();
     // ---- imaginary parts, i < j, and the posterior sums ----
@@ -703,17 +727,17 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
             }
             reload_fence();
         });
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int e = 0; e < NPO; ++e) {
-                const float s = wave_sum(acc[k][e]);
-                if (wr) row[k * NV + NP + e] = s;
-            }
-        const float s0 = wave_sum(sg0), s1 = wave_sum(sg1);
+        float tail[6] = {sg0, sg1, 0.f, 0.f, 0.f, 0.f};
+        wave_sum_array(acc[0]);
+        wave_sum_array(acc[1]);
+        wave_sum_array(tail);
         if (wr) {
-            row[NV - 1] = s0;
-            row[2 * NV - 1] = s1;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int e = 0; e < NPO; ++e) row[k * NV + NP + e] = acc[k][e];
+            row[NV - 1] = tail[0];
+            row[2 * NV - 1] = tail[1];
         }
     }
 }
@@ -776,7 +800,13 @@ __global__ __launch_bounds__(NT, WPS) void cgmm_bin_em_kernel(const CgmmBinArgs*
         const long long tc2 = a.timing ? (long long)__builtin_readcyclecounter() : 0;
         __syncthreads();
         const long long tc3 = a.timing ? (long long)__builtin_readcyclecounter() : 0;
-        if (wave < 2) solve_class<C, NT>(sm, wave, lane, mode, T, a.update_alpha);
+        if (wave < 2) {
+            // the two solving waves are this workgroup's critical path while the CU's
+            // other workgroup streams frames: let them issue first
+            __builtin_amdgcn_s_setprio(3);
+            solve_class<C, NT>(sm, wave, lane, mode, T, a.update_alpha);
+            __builtin_amdgcn_s_setprio(0);
+        }
         const long long tc4 = a.timing ? (long long)__builtin_readcyclecounter() : 0;
         __syncthreads();
         if (a.timing && tid == 0) {
@@ -861,7 +891,8 @@ constexpr BinCfg kCfgs[] = {
     {256, 2, 1, 4},   // T <=  512
     {256, 4, 2, 4},   // T <= 1024
     {512, 4, 1, 4},   // T <= 2048, two workgroups per CU
-    {256, 8, 4, 3},   // T <= 2048, three workgroups per CU (spills: slower, kept for A/B)
+    {256, 8, 4, 3},   // T <= 2048, three workgroups per CU (spills at 168 VGPRs: 1.9 x slower;
+                      // six-wave workgroups {384, 5, 2, 3} only get one workgroup per CU placed)
     {512, 8, 2, 4},   // T <= 4096
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
