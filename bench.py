@@ -77,7 +77,11 @@ def parse():
                          "report them in `other_configs` (0 = skip)")
     ap.add_argument("--e2e-utts", type=int, default=192,
                     help="N=1 only: utterances of the end-to-end CLI leg (0 = skip)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    ap.add_argument("--pmc", type=int, default=1,
+                    help="N=1 only: collect HBM traffic and VALU instruction counts of the two "
+                         "streaming kernels IN THIS RUN by re-running three timed steps under "
+                         "`rocprofv3 --pmc` (separate passes, counters only; 0 = skip)")
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -207,6 +211,11 @@ def main():
     audio_sec = world * U * (N / SR) * args.steps
     value = audio_sec / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
+    if args.pmc_child:
+        # profiled child of pmc_leg(): the launches above are all it is for
+        print(json.dumps({"pmc_child": True, "ms_per_step": round(ms_per_step, 4),
+                          "stage_ms": [round(x, 4) for x in stage_ms]}), flush=True)
+        return
 
     # ---- outside the contract's timed region ---------------------------------
     # (a) sustained stepping: the K timed steps last ~40 ms, invisible to a GPU-busy
@@ -255,17 +264,12 @@ def main():
         full_batch = time_full_batch(args, ctx, opts, torch, audio, masks, C, N, L)
 
     if rank == 0:
-        b_k1 = U * (4.0 * C * N + 4.0 * T * F)            # algorithmic bytes / launch
-        k1_ms = stage_ms[0]
+        b_k1 = U * (4.0 * C * N + 4.0 * T * F)            # algorithmic bytes / launch, pass 1
+        b_k2 = U * (4.0 * C * N + 4.0 * L)                # pass 2: audio again + the wave
+        k1_ms, k2_ms = stage_ms[0], stage_ms[2]
         achieved = b_k1 / (k1_ms * 1e-3) / 1e9
-        traffic = None
-        try:
-            with open(args.traffic_json) as f:
-                tj = json.load(f)
-            if tj.get("utts") == U and tj.get("channels") == C and tj.get("samples") == N:
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+        pmc = pmc_leg(args) if (world == 1 and args.pmc) else None
+        roof = build_roofline(C, b_k1, b_k2, k1_ms, k2_ms, pmc)
         out = {
             "metric": "real-time-factor (audio-sec/wall-sec), 8-ch 16 kHz MVDR",
             "value": round(value, 1),
@@ -294,19 +298,8 @@ def main():
                          "reduce_solve": round(stage_ms[1], 4),
                          "beamform_istft": round(stage_ms[2], 4),
                          "renorm": round(stage_ms[3], 4)},
-            "roofline": {
-                "kernel": f"stft_covar_kernel<{C}, false>",
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "alg_bytes_per_launch": b_k1,
-                "kernel_ms": round(k1_ms, 4),
-                "pipeline_achieved": round(
-                    U * (4.0 * C * N + 4.0 * T * F + 4.0 * L) / (ms_per_step * 1e-3) / 1e9, 1),
-            },
+            "roofline": dict(roof, pipeline_achieved=round(
+                U * (4.0 * C * N + 4.0 * T * F + 4.0 * L) / (ms_per_step * 1e-3) / 1e9, 1)),
         }
         if sustained is not None:
             out["sustained"] = sustained
@@ -330,6 +323,118 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+SIMDS = 256 * 4            # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
+VALU_CYCLES_PER_INST = 2   # a wave64 VALU instruction occupies its SIMD-32 for two cycles
+KERNELS = {"pass1": "stft_covar_kernel", "pass2": "beamform_istft_kernel"}
+
+
+def pmc_leg(args):
+    """Counters of THIS run's workload: three timed steps of the same configuration
+    re-run as a child under `rocprofv3 --pmc`, one pass per counter group (counters
+    only -- never mixed with API tracing), parsed from the counter_collection csv.
+    HBM bytes follow MI355X_MICROARCH.md (HBM section): read = 2 x FETCH_SIZE KB (gfx950
+    tallies the 128-byte requests of a coalesced stream at 64 bytes), write = WRITE_SIZE KB.
+    The effective clock of the profiled launches is GRBM_GUI_ACTIVE / kernel time."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "1", "--gpus", "1",
+             "--steps", "3", "--warmup", "1", "--utts", str(args.utts), "--channels", str(args.channels),
+             "--seconds", str(args.seconds), "--beamformer", args.beamformer,
+             "--distinct", str(args.distinct)]
+    groups = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE"]]
+    acc = {}
+    td = tempfile.mkdtemp(prefix="setk_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    try:
+        for gi, g in enumerate(groups):
+            out_dir = os.path.join(td, f"g{gi}")
+            cmd = [exe, "--pmc"] + g + ["--output-format", "csv", "-d", out_dir, "--"] + child
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd="/tmp", env=env)
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": f"rocprofv3 --pmc {' '.join(g)} failed (rc {r.returncode}): "
+                                 + (r.stderr or r.stdout)[-300:]}
+            for fn in files:
+                for row in csv.DictReader(open(fn)):
+                    for key, kname in KERNELS.items():
+                        if kname in row["Kernel_Name"] and ", true>" not in row["Kernel_Name"]:
+                            d = acc.setdefault(key, {}).setdefault(row["Counter_Name"], [])
+                            d.append((float(row["Counter_Value"]),
+                                      int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    res = {"method": "in-run: this workload re-run for 3 steps under rocprofv3 --pmc, one pass per "
+                     "counter group; read = 2 x FETCH_SIZE KB, write = WRITE_SIZE KB "
+                     "(MI355X_MICROARCH.md HBM section); clock = GRBM_GUI_ACTIVE / kernel time",
+           "seconds_spent": round(time.perf_counter() - t0, 1)}
+    for key in KERNELS:
+        c = acc.get(key, {})
+        mean = lambda name: (sum(v for v, _ in c[name]) / len(c[name])) if c.get(name) else None
+        dur = lambda name: (sum(d for _, d in c[name]) / len(c[name])) if c.get(name) else None
+        rd, wr = mean("FETCH_SIZE"), mean("WRITE_SIZE")
+        insts, gui, dns = mean("SQ_INSTS_VALU"), mean("GRBM_GUI_ACTIVE"), dur("GRBM_GUI_ACTIVE")
+        res[key] = {
+            "hbm_read_bytes": None if rd is None else 2.0 * rd * 1024.0,
+            "hbm_write_bytes": None if wr is None else wr * 1024.0,
+            "valu_insts": insts, "waves": mean("SQ_WAVES"),
+            "profiled_kernel_ms": None if dns is None else round(dns / 1e6, 4),
+            "clock_ghz": None if not (gui and dns) else round(gui / dns, 3),
+            "launches": len(c.get("SQ_INSTS_VALU", [])),
+        }
+    return res
+
+
+def build_roofline(C, b_k1, b_k2, k1_ms, k2_ms, pmc):
+    """The `roofline` object: the HBM numbers of the contract for the STFT+covariance
+    kernel, and for BOTH streaming kernels the VALU-issue roofline they actually sit
+    under: floor = wave-instructions / 1024 SIMDs x 2 cycles / clock.
+    `bound` names the tighter of the two for pass 1."""
+    achieved = b_k1 / (k1_ms * 1e-3) / 1e9
+    roof = {"kernel": f"stft_covar_kernel<{C}, false>", "bound": "hbm",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "alg_bytes_per_launch": b_k1, "kernel_ms": round(k1_ms, 4)}
+    if not pmc or "error" in pmc:
+        roof["pmc"] = pmc
+        return roof
+    roof["pmc_method"] = pmc["method"]
+    for key, alg, kms in (("pass1", b_k1, k1_ms), ("pass2", b_k2, k2_ms)):
+        p = pmc.get(key) or {}
+        ent = {"kernel": KERNELS[key], "kernel_ms": round(kms, 4), "alg_bytes_per_launch": alg,
+               "hbm": {"achieved": round(alg / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                       "frac": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+        if p.get("hbm_read_bytes") is not None and p.get("hbm_write_bytes") is not None:
+            ent["hbm"]["traffic"] = round(p["hbm_read_bytes"] + p["hbm_write_bytes"])
+            ent["hbm"]["traffic_over_algorithmic"] = round(ent["hbm"]["traffic"] / alg, 3)
+        if p.get("valu_insts") and p.get("clock_ghz"):
+            floor_ms = p["valu_insts"] / SIMDS * VALU_CYCLES_PER_INST / (p["clock_ghz"] * 1e9) * 1e3
+            ent["valu_issue"] = {"insts": round(p["valu_insts"]), "simds": SIMDS,
+                                 "cycles_per_inst": VALU_CYCLES_PER_INST,
+                                 "clock_ghz": p["clock_ghz"], "floor_ms": round(floor_ms, 4),
+                                 "profiled_kernel_ms": p["profiled_kernel_ms"],
+                                 "frac": round(floor_ms / p["profiled_kernel_ms"], 4)
+                                 if p.get("profiled_kernel_ms") else None,
+                                 "frac_unprofiled": round(floor_ms / kms, 4)}
+        roof[key] = ent
+    p1 = roof.get("pass1", {})
+    if "traffic" in p1.get("hbm", {}):
+        roof["traffic"] = p1["hbm"]["traffic"]
+    vi = p1.get("valu_issue")
+    if vi and vi.get("frac") and vi["frac"] > roof["frac"]:
+        # closer to its VALU-issue ceiling than to the HBM ceiling: that is the binding one
+        roof["bound"] = "valu_issue"
+        roof["bound_note"] = ("`achieved`/`peak`/`frac` stay the contract's HBM figures; the kernel "
+                              "is nearer its VALU-issue floor (pass1.valu_issue.frac)")
+    return roof
 
 
 def other_configs(torch, _ffi, synth, dev):
@@ -566,6 +671,15 @@ def cpu_baseline(args, C, N, first_index, wave0):
         "ratio_to_reference_probe": round(one / (30.0 / 0.59), 2) if C == 8 and N == 480000 else None,
         "parity_check": parity,
     }
+    out["reference"] = reference_leg(args, C, N)
+    if out["reference"].get("present"):
+        # the reference itself was timed in this run: it is the baseline, the port a second entry
+        ref1 = out["reference"]["one_core"]
+        out["port"] = {"value": out["value"], "cores": 1, "sample": out["sample"]}
+        out.update(value=ref1["value"], kind="reference",
+                   sample=f"{ref1['utts']} utterances of the same {C}-ch {N / SR:g} s workload through "
+                          "the UNMODIFIED reference CLI (oracle/ref_harness.py), first scp read to "
+                          f"last wav close, 1 thread, {ref1['wall_s']} s wall")
     if args.cpu_allcore_per_proc > 0:
         allc = cpu_allcore(args, C, N)
         if allc:
@@ -575,6 +689,29 @@ def cpu_baseline(args, C, N, first_index, wave0):
                               "compute only, common start line")
             out["all_cores"] = allc
     return out
+
+
+def reference_leg(args, C, N):
+    """the unmodified reference CLI on this host's cores, when the reference
+    tree is on this box (the build container); on the GPU box /root/reference does not
+    exist, and the record says so and quotes the committed measurement."""
+    from oracle import ref_cpu_leg, ref_harness
+    if ref_harness.available():
+        try:
+            rec = ref_cpu_leg.measure(utts=max(4, min(args.cpu_sample, 16)), channels=C,
+                                      seconds=N / SR, kind=args.beamformer)
+            rec["present"] = True
+            return rec
+        except Exception as e:  # pragma: no cover
+            return {"present": False, "note": f"reference leg failed: {e}"}
+    rec = {"present": False, "note": "reference absent on this box (/root/reference is not shipped "
+                                     "to the GPU box); cpu_baseline.kind stays 'port'"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_ref_cpu_leg.json")) as f:
+            rec["recorded_in_build_container"] = json.load(f)
+    except Exception:
+        pass
+    return rec
 
 
 def host_copy_rate(threads=(1, 8), nbytes=64 << 20, reps=4):

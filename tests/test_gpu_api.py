@@ -291,7 +291,16 @@ def test_bench_contract_single_and_two_ranks():
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in one, k
     assert one["n_gpus"] == 1 and one["steps"] == 2 and one["scaling"] == "weak"
-    assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1
+    roof = one["roofline"]
+    assert roof["bound"] in ("hbm", "valu_issue") and 0 < roof["frac"] < 1
+    # counters collected in this very run (rocprofv3 --pmc on a child of the same workload)
+    assert "pmc_method" in roof, roof.get("pmc")
+    for key in ("pass1", "pass2"):
+        ent = roof[key]
+        assert ent["hbm"]["traffic"] > 0.5 * ent["alg_bytes_per_launch"]
+        vi = ent["valu_issue"]
+        assert vi["insts"] > 0 and 0.5 < vi["clock_ghz"] < 2.6 and 0 < vi["frac"] <= 1.05
+    assert roof["traffic"] == roof["pass1"]["hbm"]["traffic"]
     # the legs outside the timed steps
     assert one["sustained"]["steps"] >= 50 and one["full_batch"]["utts"] == 12
     assert one["uncached_call"]["ms_per_step"] > 0
