@@ -146,7 +146,8 @@ int setk_istft(setk_handle_t h, const float* spec, int batch, int num_frames,
 
 /* compute_covar (libs/beamformer.py:87-103):
  * covar[f] = sum_t m[t][f] x x^H / max(sum_t m[t][f], 1e-6).
- * spec[C][T][F], mask[T][F] -> covar[F][C][C] complex64.  1 <= C <= 8. */
+ * spec[C][T][F], mask[T][F] -> covar[F][C][C] complex64.  1 <= C <= 16 (the wide
+ * kernel serves 9 - 16 channels). */
 int setk_covar(setk_handle_t h, const float* spec, const float* mask,
                int num_channels, int num_frames, int num_bins, float* covar,
                void* stream);
@@ -256,11 +257,22 @@ int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
  * float32 [T][F] array: passed to setk_covar as the mask it yields the
  * power-weighted covariance of facted_wpd (:160-162, up to a per-bin scale that
  * cancels in the MVDR weight).  status[F] (may be NULL) receives SETK_NUM_*;
- * SETK_NUM_SINGULAR is numpy's LinAlgError.  num_channels * taps <= 96. */
+ * SETK_NUM_SINGULAR is numpy's LinAlgError.  Limits: channels <= 16, channels * taps <= 96
+ * and the LDS-resident correlation (NK^2 + NK N + 16 (NK + N) complex128 <= 160 KB:
+ * 8 channels x 10 taps, 16 x 4); beyond them SETK_ERR_UNSUPPORTED names the bound. */
 int setk_wpe(setk_handle_t h, const float* spec, int num_channels, int num_frames,
              int num_bins, int taps, int delay, int context, int num_iters,
              const float* lambda_enh, float* out, float* inv_lambda_out,
              int* status, void* stream);
+
+/* One wpe_step (scripts/sptk/libs/wpe.py:58-81) with the caller's variances used AS
+ * GIVEN: lambda_ft is float64 [F][T] (the reference's F x T), no floor, no
+ * re-estimation.  spec / out [C][T][F] complex64; taps / delay describe the tap
+ * matrix compute_tap_mat(reverb, taps, delay) (:13-29) that the kernel indexes in
+ * place.  status as setk_wpe. */
+int setk_wpe_step(setk_handle_t h, const float* spec, int num_channels, int num_frames,
+                  int num_bins, int taps, int delay, const double* lambda_ft, float* out,
+                  int* status, void* stream);
 
 /* ---- fused hot path ------------------------------------------------------
  * The compute body of apply_adaptive_beamformer.py:130-178 for a batch of

@@ -55,7 +55,7 @@ def exported_symbols():
         "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
         "setk_cgmm_masks_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
-        "setk_directional_feats", "setk_wpe", "setk_set_profiling",
+        "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_set_profiling",
         "setk_last_stage_ms"
     ]
 
@@ -116,6 +116,7 @@ def load_library():
         POINTER(BatchTaps), c_void_p]
     lib.setk_wpe.argtypes = [H, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, fp, fp, fp,
                              fp, c_void_p]
+    lib.setk_wpe_step.argtypes = [H, fp, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, c_void_p]
     lib.setk_directional_feats.argtypes = [H, fp, fp, POINTER(c_int), c_int, c_int, c_int, c_int,
                                            fp, c_void_p]
     lib.setk_apply_weights_batch.argtypes = [
@@ -395,6 +396,13 @@ class Context:
                                int(context), int(num_iters), _ptr(lambda_enh), _ptr(out),
                                _ptr(inv_lambda_out), _ptr(status),
                                current_stream_ptr() if stream is None else stream))
+
+    def wpe_step(self, spec, C, T, F, taps, delay, lambda_ft, out, status=None, stream=None):
+        """One wpe_step with the caller's variances (float64 F x T) used as given."""
+        self.check(
+            self._lib.setk_wpe_step(self._h, _ptr(spec), int(C), int(T), int(F), int(taps), int(delay),
+                                    _ptr(lambda_ft), _ptr(out), _ptr(status),
+                                    current_stream_ptr() if stream is None else stream))
 
     def set_profiling(self, on):
         self.check(self._lib.setk_set_profiling(self._h, 1 if on else 0))

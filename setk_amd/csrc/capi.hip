@@ -1333,16 +1333,37 @@ int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
 // wpe_step (libs/wpe.py:58-81) `num_iters` times.  lambda of iteration 0 comes from
 // `lambda_enh` (facted_wpd: |previous enhanced|^2) when given, else from
 // compute_lambda(spec); later iterations use compute_lambda(dereverb).
+namespace {
+int wpe_impl(setk_handle_t h, const float* spec, int num_channels, int num_frames, int num_bins,
+             int taps, int delay, int context, int num_iters, const float* lambda_enh,
+             const double* lambda_ft, float* out, float* inv_lambda_out, int* status, void* stream);
+}
+
 int setk_wpe(setk_handle_t h, const float* spec, int num_channels, int num_frames, int num_bins,
              int taps, int delay, int context, int num_iters, const float* lambda_enh,
              float* out, float* inv_lambda_out, int* status, void* stream) {
+    return wpe_impl(h, spec, num_channels, num_frames, num_bins, taps, delay, context, num_iters,
+                    lambda_enh, nullptr, out, inv_lambda_out, status, stream);
+}
+
+int setk_wpe_step(setk_handle_t h, const float* spec, int num_channels, int num_frames,
+                  int num_bins, int taps, int delay, const double* lambda_ft, float* out,
+                  int* status, void* stream) {
+    if (!lambda_ft) return fail(h, SETK_ERR_INVALID, "setk_wpe_step needs lambda");
+    return wpe_impl(h, spec, num_channels, num_frames, num_bins, taps, delay, 0, 1, nullptr,
+                    lambda_ft, out, nullptr, status, stream);
+}
+
+namespace {
+int wpe_impl(setk_handle_t h, const float* spec, int num_channels, int num_frames, int num_bins,
+             int taps, int delay, int context, int num_iters, const float* lambda_enh,
+             const double* lambda_ft, float* out, float* inv_lambda_out, int* status, void* stream) {
     if (!h || !spec || !out || num_frames <= 0 || num_bins <= 0 || num_iters <= 0 || delay < 0 ||
         context < 0)
         return fail(h, SETK_ERR_INVALID, "bad args");
     const int C = num_channels, T = num_frames, F = num_bins;
     if (!wpe_supported(C, taps))
-        return fail(h, SETK_ERR_UNSUPPORTED,
-                    "WPE needs num_channels * taps <= 96 (R is factored in LDS)");
+        return fail(h, SETK_ERR_UNSUPPORTED, wpe_limit_message(C, taps));
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
     arena_reset(h, s);
@@ -1353,6 +1374,11 @@ int setk_wpe(setk_handle_t h, const float* spec, int num_channels, int num_frame
     const float* d_enh = nullptr;
     if (lambda_enh) {
         rc = stage_in(h, lambda_enh, (size_t)T * F * 2, s, &d_enh);
+        if (rc) return rc;
+    }
+    const double* d_lam_in = nullptr;
+    if (lambda_ft) {
+        rc = stage_in(h, lambda_ft, (size_t)T * F, s, &d_lam_in);
         if (rc) return rc;
     }
     OutBuf ob, ob_il;
@@ -1372,7 +1398,11 @@ int setk_wpe(setk_handle_t h, const float* spec, int num_channels, int num_frame
     const float* cur = x_fct;
     float* bufs[2] = {d_a, d_b};
     for (int it = 0; it < num_iters; ++it) {
-        if (it == 0 && d_enh)
+        if (it == 0 && d_lam_in)
+            // wpe_step (libs/wpe.py:58-81): the caller's variances as given, F x T float64
+            HIP_TRY(h, hipMemcpyAsync(lam, d_lam_in, (size_t)T * F * sizeof(double),
+                                      hipMemcpyDeviceToDevice, s));
+        else if (it == 0 && d_enh)
             HIP_TRY(h, launch_wpe_lambda_from_enh(d_enh, T, F, lam, s));
         else
             HIP_TRY(h, launch_wpe_lambda(cur, C, T, F, context, lam, s));
@@ -1407,6 +1437,7 @@ int setk_wpe(setk_handle_t h, const float* spec, int num_channels, int num_frame
     if (sync) HIP_TRY(h, hipStreamSynchronize(s));
     return SETK_OK;
 }
+}  // namespace
 
 int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, int num_channels,
                        const float* const* audio, const int* num_samples,

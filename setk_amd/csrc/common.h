@@ -194,6 +194,7 @@ hipError_t launch_beamform_spec(const float* w_fc, const float* spec, int C, int
 
 // WPE (wpe.hip)
 bool wpe_supported(int N, int taps);
+const char* wpe_limit_message(int N, int taps);
 hipError_t launch_wpe_transpose(const float* in, int C, int T, int F, float* out, bool to_fct,
                                 hipStream_t s);
 hipError_t launch_wpe_lambda(const float* d_fct, int C, int T, int F, int ctx, double* lam,

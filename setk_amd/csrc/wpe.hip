@@ -20,6 +20,7 @@
 // reports SETK_NUM_SINGULAR, the reference's LinAlgError), G is solved for by
 // substitution and the filter is applied in a second sweep over the frames.
 // Layout: spectrograms [F][N][T] (frames contiguous), lambda [F][T] float64.
+#include <cstdio>
 #include "common.h"
 #include "../../include/setk_hip.h"
 
@@ -309,6 +310,19 @@ bool wpe_supported(int N, int taps) {
     const int NK = N * taps;
     return N >= 1 && N <= 16 && taps >= 1 && NK <= kWpeMaxNK && NK + N <= 16 * kWpeCols &&
            wpe_lds_bytes(N, taps) <= 160 * 1024;
+}
+
+// what exactly a shape is refused for (the LDS bound is the tighter one from 8 channels up:
+// C = 8 allows 10 taps, C = 16 allows 4)
+const char* wpe_limit_message(int N, int taps) {
+    static thread_local char buf[256];
+    const int NK = N * taps;
+    snprintf(buf, sizeof(buf),
+             "WPE on the device needs 1 <= channels <= 16, channels * taps <= %d and "
+             "(NK^2 + NK N + %d (NK + N)) complex128 entries <= 160 KB of LDS "
+             "(channels = %d, taps = %d: NK = %d, %zu bytes)",
+             kWpeMaxNK, kWpeTC, N, taps, NK, wpe_lds_bytes(N, taps));
+    return buf;
 }
 
 hipError_t launch_wpe_transpose(const float* in, int C, int T, int F, float* out, bool to_fct,

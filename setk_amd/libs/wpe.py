@@ -68,18 +68,47 @@ def _run(spec_ctf, taps, delay, context, num_iters, lambda_enh=None, want_inv_la
     return out, inv
 
 
-def wpe_step(reverb, yt, lambda_):
-    """One WPE step with caller-supplied variances.  reverb F x N x T, yt F x NK x T
-    (only its shape is used: taps = NK / N, delay from the first non-zero column is
-    not recoverable, so yt must come from compute_tap_mat and the delay is inferred
-    from its leading zero frames), lambda_ F x T."""
+def wpe_step(reverb, yt, lambda_, taps=None, delay=None):
+    """One WPE step with caller-supplied variances (libs/wpe.py:58-81).  reverb
+    F x N x T, yt F x NK x T, lambda_ F x T -- used as given (float64, no floor).
+
+    The device kernel indexes the delayed frames in place instead of reading a tap
+    matrix, so yt must BE compute_tap_mat(reverb, taps, delay): pass taps / delay, or
+    they are recovered from yt (taps = NK / N; delay = the shift under which yt's first
+    block reproduces reverb, checked on the whole matrix).  A yt that is no tap matrix
+    of reverb is refused -- there is no host fallback."""
+    reverb = np.asarray(reverb)
+    yt = np.asarray(yt)
     F, N, T = reverb.shape
-    taps = yt.shape[1] // N
-    # delay = number of leading all-zero frames of the first tap block
-    nz = np.flatnonzero(np.any(yt[:, :N, :] != 0, axis=(0, 1)))
-    delay = int(nz[0]) if nz.size else 0
-    enh = np.ascontiguousarray(np.sqrt(np.asarray(lambda_, dtype=np.float64)).T.astype(np.complex64))
-    out, _ = _run(_to_ctf(reverb), taps, delay, 0, 1, lambda_enh=enh)
+    if yt.ndim != 3 or yt.shape[0] != F or yt.shape[2] != T or yt.shape[1] % N:
+        raise ValueError(f"yt {yt.shape} does not stack taps of reverb {reverb.shape}")
+    if taps is None:
+        taps = yt.shape[1] // N
+    if taps * N != yt.shape[1]:
+        raise ValueError(f"taps = {taps} but yt has {yt.shape[1]} rows for {N} channels")
+    if delay is None:
+        # candidates: at most the number of leading all-zero frames of the first block
+        # (a signal that itself starts with zero frames makes that an over-estimate)
+        nz = np.flatnonzero(np.any(yt[:, :N, :] != 0, axis=(0, 1)))
+        lead = int(nz[0]) if nz.size else T
+        delay = next((d for d in range(min(lead, T - 1), -1, -1)
+                      if np.array_equal(yt[:, :N, d:], reverb[:, :, :T - d].astype(yt.dtype))
+                      and np.array_equal(yt, compute_tap_mat(reverb, taps, d).astype(yt.dtype))),
+                     None)
+        if delay is None:
+            raise ValueError("yt is not compute_tap_mat(reverb, taps, delay) for any delay")
+    elif not np.array_equal(yt, compute_tap_mat(reverb, taps, delay).astype(yt.dtype)):
+        raise ValueError("yt differs from compute_tap_mat(reverb, taps, delay)")
+    lam = np.ascontiguousarray(lambda_, dtype=np.float64)
+    if lam.shape != (F, T):
+        raise ValueError(f"lambda_ {lam.shape}, expected {(F, T)}")
+    spec = _to_ctf(reverb)
+    out = np.empty_like(spec)
+    status = np.zeros(F, dtype=np.int32)
+    _ffi.default_context().wpe_step(spec, N, T, F, taps, delay, lam, out, status=status)
+    if status.any():
+        raise np.linalg.LinAlgError(
+            f"Singular matrix (tap correlation, {int(np.count_nonzero(status))} bins)")
     return np.transpose(out, (2, 0, 1))
 
 

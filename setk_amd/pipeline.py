@@ -348,7 +348,8 @@ class StreamPipeline(object):
             self._dispatch()
         self.group = g
         self.pending.append(job)
-        self.stats["t_plan"] += time.perf_counter() - t0
+        with self.lock:
+            self.stats["t_plan"] += time.perf_counter() - t0
         if len(self.pending) >= self.batch_utts:
             self._dispatch()
 
@@ -367,7 +368,8 @@ class StreamPipeline(object):
         try:
             return self._get_slot_inner(in_cap, f32_cap, out_cap)
         finally:
-            self.stats["t_slot_wait"] += time.perf_counter() - t0
+            with self.lock:
+                self.stats["t_slot_wait"] += time.perf_counter() - t0
 
     def _get_slot_inner(self, in_cap, f32_cap, out_cap):
         if self.slots_made < self.depth and self.free_slots.empty():
@@ -376,7 +378,8 @@ class StreamPipeline(object):
             t0 = time.perf_counter()
             slot = _Slot(self.torch, self.dev, max(int(in_cap * grow), self.min_in),
                          int(f32_cap * grow), int(out_cap * grow))
-            self.stats["t_alloc"] += time.perf_counter() - t0
+            with self.lock:
+                self.stats["t_alloc"] += time.perf_counter() - t0
         else:
             while True:
                 try:
@@ -528,52 +531,68 @@ class StreamPipeline(object):
 
     # ---- completion: wait for D2H, hand the samples to the writers ------------------
     def _complete_loop(self):
-        try:
-            self.torch.cuda.set_device(self.dev)
-            while True:
-                item = self.done_q.get()
-                if item is None:
-                    return
-                batch, slot, off_status, off_power, launched = item
-                t0 = time.perf_counter()
-                if launched:
-                    slot.e_out.synchronize()
-                t1 = time.perf_counter()
-                good = [j for j in batch if j.error is None]
-                status = np.frombuffer(slot.np_out[off_status:off_status + 4 * len(good)],
-                                       dtype=np.int32)
-                power = np.frombuffer(slot.np_out[off_power:off_power + 8 * len(good)],
-                                      dtype=np.float64)
-                futs = []
-                gi = 0
-                for j in batch:
-                    if j.error is not None:
-                        futs.append(self.writers.submit(self.sink, j.key, None, -1, j.error))
-                        continue
-                    if self.announce is not None:
-                        self.announce(j.key, float(power[j.pw_idx]) / max(j.N, 1)
-                                      if j.pcm16 else j.power)
-                    pcm = np.frombuffer(slot.np_out[j.off_out:j.off_out + 2 * j.L], dtype=np.int16)
-                    futs.append(self.writers.submit(self.sink, j.key, pcm, int(status[gi]), None))
-                    gi += 1
-                ok = 0
-                for f in futs:
-                    ok += 1 if f.result() else 0
-                t2 = time.perf_counter()
-                with self.lock:
-                    self.num_done += ok
-                    self.stats["batches"] += 1
-                    self.stats["utts"] += len(batch)
-                    self.stats["t_d2h_wait"] += t1 - t0
-                    self.stats["t_write"] += t2 - t1
-                if not launched:
-                    self.s_in.synchronize()  # copies of a batch that never launched
-                for m in slot.maps:
-                    m.close(self.ctx)
+        """Drains done_q until the launcher's sentinel WHATEVER happens to a batch: a
+        writer / sink failure is remembered (self.exc, raised by submit() / close()),
+        the batch's slot still returns to the pool and the following batches are still
+        consumed -- the launcher can always finish and close() can always join,
+        independently of how depth and the queue sizes are chosen."""
+        self.torch.cuda.set_device(self.dev)
+        while True:
+            item = self.done_q.get()
+            if item is None:
+                return
+            batch, slot, off_status, off_power, launched = item
+            try:
+                self._complete_batch(batch, slot, off_status, off_power, launched)
+            except BaseException as e:
+                if self.exc is None:
+                    self.exc = e
+            finally:
+                try:
+                    if not launched:
+                        self.s_in.synchronize()  # copies of a batch that never launched
+                    for m in slot.maps:
+                        m.close(self.ctx)
+                except BaseException as e:  # pragma: no cover
+                    if self.exc is None:
+                        self.exc = e
                 slot.maps = []
                 self.free_slots.put(slot)
-        except BaseException as e:
-            self.exc = e
+
+    def _complete_batch(self, batch, slot, off_status, off_power, launched):
+        t0 = time.perf_counter()
+        if launched:
+            slot.e_out.synchronize()
+        t1 = time.perf_counter()
+        good = [j for j in batch if j.error is None]
+        status = np.frombuffer(slot.np_out[off_status:off_status + 4 * len(good)], dtype=np.int32)
+        power = np.frombuffer(slot.np_out[off_power:off_power + 8 * len(good)], dtype=np.float64)
+        futs = []
+        gi = 0
+        for j in batch:
+            if j.error is not None:
+                futs.append(self.writers.submit(self.sink, j.key, None, -1, j.error))
+                continue
+            if self.announce is not None:
+                self.announce(j.key, float(power[j.pw_idx]) / max(j.N, 1) if j.pcm16 else j.power)
+            pcm = np.frombuffer(slot.np_out[j.off_out:j.off_out + 2 * j.L], dtype=np.int16)
+            futs.append(self.writers.submit(self.sink, j.key, pcm, int(status[gi]), None))
+            gi += 1
+        ok, first = 0, None
+        for f in futs:  # wait for EVERY writer before the slot's memory is reused
+            try:
+                ok += 1 if f.result() else 0
+            except BaseException as e:
+                first = first or e
+        t2 = time.perf_counter()
+        with self.lock:
+            self.num_done += ok
+            self.stats["batches"] += 1
+            self.stats["utts"] += len(batch)
+            self.stats["t_d2h_wait"] += t1 - t0
+            self.stats["t_write"] += t2 - t1
+        if first is not None:
+            raise first
 
     def close(self):
         """Flush, wait for everything in flight, return (num_done, stats)."""

@@ -11,6 +11,7 @@ import argparse
 
 import numpy as np
 
+from .._ffi import SetkUnsupported
 from setk_amd.dist import Shard
 from setk_amd.libs.data_handler import SpectrogramReader, WaveWriter
 from setk_amd.libs.opts import StftParser, strtobool
@@ -46,6 +47,11 @@ def run(args):
                                               delay=args.delay)
             except np.linalg.LinAlgError:
                 logger.warning(f"{key}: Failed cause LinAlgError in wpd")
+                continue
+            except SetkUnsupported as e:
+                # a shape beyond the device kernels' limits (channels x taps): skip the
+                # utterance like a numerical failure instead of ending the run
+                logger.warning(f"{key}: skipped, {e}")
                 continue
             norm = reader.maxabs(key)
             samps = inverse_stft(wpd_enh, norm=norm, **stft_kwargs)

@@ -12,6 +12,7 @@ import argparse
 
 import numpy as np
 
+from .._ffi import SetkUnsupported
 from setk_amd.dist import Shard
 from setk_amd.libs.data_handler import SpectrogramReader, WaveWriter
 from setk_amd.libs.opts import StftParser, strtobool
@@ -47,6 +48,11 @@ def run(args):
                                taps=args.taps, delay=args.delay)
             except np.linalg.LinAlgError:
                 logger.warning(f"{key}: Failed cause LinAlgError in wpe")
+                continue
+            except SetkUnsupported as e:
+                # a shape beyond the device kernels' limits (channels x taps): skip the
+                # utterance like a numerical failure instead of ending the run
+                logger.warning(f"{key}: skipped, {e}")
                 continue
             dereverb = np.transpose(dereverb, (1, 2, 0))  # F x N x T => N x T x F
             samps = np.stack([inverse_stft(spectra, **stft_kwargs) for spectra in dereverb])

@@ -31,6 +31,19 @@ def test_wpe_small_known_answer():
     lam = o.compute_lambda(rev, ctx=1)
     yt = o.compute_tap_mat(rev, 4, 2)
     assert rel_rms(W.wpe_step(rev, yt, lam), o.wpe_step(rev, yt, lam)) < 1e-5
+    # an observation that itself STARTS with exactly-zero frames (digital silence): the delay
+    # must not be read off the zero prefix of yt; variances far below eps are used as given
+    rev0 = rev.copy()
+    rev0[:, :, :5] = 0
+    yt0 = o.compute_tap_mat(rev0, 4, 2)
+    lam0 = np.maximum(o.compute_lambda(rev0, ctx=1) * 1e-9, 1e-16)
+    ref0 = o.wpe_step(rev0, yt0, lam0)
+    assert rel_rms(W.wpe_step(rev0, yt0, lam0), ref0) < 1e-5
+    assert rel_rms(W.wpe_step(rev0, yt0, lam0, taps=4, delay=2), ref0) < 1e-5
+    with pytest.raises(ValueError):
+        W.wpe_step(rev0, yt0 * 2, lam0)
+    with pytest.raises(ValueError):
+        W.wpe_step(rev0, yt0, lam0, taps=4, delay=3)
 
 
 @pytest.mark.parametrize("C,taps,N", [(8, 10, 40000), (2, 12, 20000), (6, 5, 30000), (1, 10, 16000)])
