@@ -213,12 +213,21 @@ __global__ __launch_bounds__(256) void wpe_step_kernel(WpeArgs a) {
     __syncthreads();
 
     // ---- Cholesky R = L L^H (lower triangle in place), right-looking ----
+    // Pivots are floored at eps64 * NK * max diag (as chol_lds in solve.hip does with
+    // eps32): a numerically semi-definite R (fewer frames than N * taps, a duplicated
+    // or silent channel) is factored with noise-level pivots, the way LAPACK's pivoted LU
+    // behind numpy.linalg.solve goes through on such input (libs/wpe.py:76); only an
+    // all-zero or non-finite R is "singular" (LinAlgError).
+    double dmax = 0.0;
+    for (int k = 0; k < NK; ++k) dmax = fmax(dmax, R[(size_t)k * NK + k].x);
+    const double pfloor = dmax * 2.220446049250313e-16 * (double)NK;
     for (int k = 0; k < NK; ++k) {
-        const double dkk = R[(size_t)k * NK + k].x;
-        if (!(dkk > 0.0) || !isfinite(dkk)) {
+        double dkk = R[(size_t)k * NK + k].x;
+        if (!(dmax > 0.0) || !isfinite(dkk) || !isfinite(dmax)) {
             if (tid == 0) *flag = SETK_NUM_SINGULAR;
             break;  // uniform: every thread reads the same pivot
         }
+        dkk = fmax(dkk, pfloor);
         const double lkk = sqrt(dkk), inv = 1.0 / lkk;
         __syncthreads();
         for (int i = k + tid; i < NK; i += 256) {

@@ -19,6 +19,7 @@ Differences, all deliberate (DESIGN.md "Reference bugs"):
     keep the reference behaviour)
 """
 import argparse
+import os
 import math
 import sys
 
@@ -81,6 +82,9 @@ _OPTIONS = (
                                  help="[setk_amd] batches in flight in the host pipeline")),
     (("--read-threads",), dict(default=0, type=int,
                                help="[setk_amd] file reader threads (0: half the cores, <= 12)")),
+    (("--skip-existing",), dict(default=False, type=lambda v: str(v).lower() in ("true", "1", "yes"),
+                                help="[setk_amd] resume: utterances whose {dst_dir}/{key}.wav already "
+                                     "exists (non-empty) are not enhanced again")),
     (("--profile",), dict(default="", type=str,
                           help="[setk_amd] write a JSON run summary (wall clock from the first "
                                "scp read to the last wav close, stage times, bytes) here")),
@@ -114,6 +118,27 @@ def do_online_beamform(beamformer, speech_mask, interf_mask, stft_mat, args):
     return np.hstack(out)
 
 
+def _drop_existing(args, keys):
+    """--skip-existing: a re-run after an interruption (or a re-queued shard of a failed
+    rank) only does what is missing.  The sharding above is computed on the full table, so
+    every rank keeps the utterances it had."""
+    if not getattr(args, "skip_existing", False):
+        return keys
+    left = []
+    for k in keys:
+        path = os.path.join(args.dst_dir, f"{k}.wav")
+        try:
+            done = os.path.getsize(path) > 44
+        except OSError:
+            done = False
+        if not done:
+            left.append(k)
+    if len(left) != len(keys):
+        logger.info(f"--skip-existing: {len(keys) - len(left)} of {len(keys)} utterances already "
+                    f"in {args.dst_dir}")
+    return left
+
+
 def run_online(args, shard):
     stft_kwargs = dict(frame_len=args.frame_len, frame_hop=args.frame_hop, window=args.window,
                        center=args.center, transpose=False)
@@ -129,7 +154,7 @@ def run_online(args, shard):
     beamformer = cls(num_bins, args.channels, args.alpha)
     logger.info(f"Using online {args.beamformer} beamformer, chunk size = {args.chunk_size:d}")
     num_done = 0
-    keys = shard.assign_by_duration(reader)
+    keys = _drop_existing(args, shard.assign_by_duration(reader))
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
         for key in keys:
             if key not in tgt:
@@ -200,7 +225,7 @@ def run_offline(args, shard):
                            ban=bool(args.ban), pmwf_ref=args.pmwf_ref,
                            rank1_appro=args.rank1_appro, post_mask=bool(args.mask),
                            vad_proportion=args.vad_proportion, pcm16=True, device=device)
-    keys = shard.assign_by_duration(wav_reader)
+    keys = _drop_existing(args, shard.assign_by_duration(wav_reader))
     summary = dict(mode="batch", utts=0, rank=shard.rank, world=shard.world,
                    assigned_samples=shard.assigned_weight)
     num_done = 0

@@ -197,6 +197,19 @@ def test_cli_end_to_end_against_reference_cli(tmp_path, fmt):
                 b = o.enhance_utterance(samps, g[f"{k}.mask"], kind=bf, gauge=True)
                 b = np.rint(b.astype(np.float64) * 32767) / 32768
             assert rms(a, b) / rms(b) < 1e-3, (bf, k)
+    # --skip-existing: with one output removed, a re-run writes that one and leaves the other
+    dst = os.path.join(td, "mvdr")
+    os.remove(os.path.join(dst, keys[0] + ".wav"))
+    kept = os.path.join(dst, keys[1] + ".wav")
+    before = (os.stat(kept).st_mtime_ns, open(kept, "rb").read())
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py"),
+           "--mask-format", fmt, "--skip-existing", "true", os.path.join(td, "wav.scp"),
+           os.path.join(td, "mask.scp"), dst]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "--skip-existing: 1 of 2 utterances already" in r.stderr
+    assert os.path.getsize(os.path.join(dst, keys[0] + ".wav")) > 44
+    assert (os.stat(kept).st_mtime_ns, open(kept, "rb").read()) == before
 
 
 def test_cli_options_vad_postmask_itf_online(tmp_path):

@@ -82,6 +82,17 @@ def test_wpe_singular_is_linalg_error():
         W.wpe(fnt, taps=3, delay=1)
 
 
+def test_wpe_rank_deficient_goes_through_like_lu():
+    """Fewer frames than channels x taps: R is semi-definite.  numpy's pivoted LU (the
+    reference) returns a finite result without raising; the device Cholesky floors its
+    pivots relative to the largest diagonal entry and must not drop the utterance."""
+    from setk_amd.libs import wpe as W
+    rng = np.random.default_rng(12)
+    fnt = (rng.standard_normal((5, 4, 10)) + 1j * rng.standard_normal((5, 4, 10))).astype(np.complex64)
+    out = W.wpe(fnt, taps=5, delay=1, context=0, num_iters=1)
+    assert out.shape == fnt.shape and np.all(np.isfinite(out))
+
+
 def test_facted_wpd_matches_oracle():
     from setk_amd.libs import wpe as W
     _, mix = mg.wpe_small_case()

@@ -22,7 +22,7 @@ from conftest import GOLDEN, ROOT, load_golden
 @pytest.fixture(scope="module")
 def built_lib():
     import __graft_entry__ as g
-    return g.build()
+    return g.build(force=False)
 
 
 def test_library_exports_header_symbols(built_lib):
