@@ -77,6 +77,7 @@ extern "C" {
 #define SETK_FLAG_POST_MASK 0x4  /* enh <- enh * mask^T           (:174-175)  */
 #define SETK_FLAG_NO_GAUGE 0x8   /* leave eigenvector phase as computed       */
 #define SETK_FLAG_OUT_PCM16 0x10 /* enhance_batch writes int16 PCM, not f32   */
+#define SETK_FLAG_NO_RENORM 0x20 /* apply_weights_batch: inverse_stft(norm=None) */
 
 typedef struct setk_context* setk_handle_t;
 
@@ -240,7 +241,9 @@ int setk_directional_feats(setk_handle_t h, const float* spec, const float* stee
  * filters in the reference layout [set][F = 257][C] complex64 (host or device);
  * weight_index[u] (host, may be NULL = set 0) picks the beam of utterance u.
  * audio / wave: device pointers as for setk_enhance_batch; flags:
- * SETK_FLAG_OUT_PCM16.  Needs the n_fft = 512 plan. */
+ * SETK_FLAG_OUT_PCM16, SETK_FLAG_NO_RENORM (the wave as inverse_stft(norm=None)
+ * leaves it: apply_classic_beamformer.py:109-110 without --normalize).  Needs the
+ * n_fft = 512 plan. */
 int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
                              const float* const* audio, const int* num_samples,
                              const float* weights, int n_sets, const int* weight_index,

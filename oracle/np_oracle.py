@@ -335,6 +335,69 @@ def beamform(weight, obs):
     return np.einsum("...n,...nt->...t", weight.conj(), obs)
 
 
+# ---- geometry beamformers (libs/beamformer.py:133-212, 343-512) ----
+def classic_weight(kind, geometry, doa, num_bins, c=340, sr=16000, linear_topo=(),
+                   radius=0.05, num_arounded=6, circular_center=False, diag_eps=None):
+    """Delay-and-sum ("ds") or superdirective ("sd") weights F x N of a linear /
+    circular array for one direction of arrival (degrees).
+    linear: dist_n = cos(doa) topo_n (:182); circular: dist_n = -r cos(2 pi n / N - doa),
+    a centre microphone first at distance 0 (:207-212); steer vector
+    exp(-j omega dist / c), omega_f = pi f sr / (F - 1) (:163-164); DS = sv / N (:396, 427);
+    SD = Rn^-1 d / (d^H Rn^-1 d) with d the DS weight and Rn the diffuse coherence
+    sinc(omega D / c) + diag_eps I, diag_eps 0.1 linear / 1e-5 circular (:133-151,
+    438-460, 488-511)."""
+    omega = np.pi * np.arange(num_bins) * sr / (num_bins - 1)
+    if geometry == "linear":
+        topo = np.asarray(linear_topo, dtype=np.float64)
+        dist = np.cos(doa * np.pi / 180) * topo
+        n = len(topo)
+        mat = np.tile(topo, (n, 1))
+        dmat = np.abs(mat - mat.T)
+        eps = 0.1 if diag_eps is None else diag_eps
+    else:
+        dirc = np.arange(num_arounded) * 2 * np.pi / num_arounded
+        dist = -np.cos(dirc - doa * np.pi / 180) * radius
+        if circular_center:
+            dist = np.concatenate([[0.0], dist])
+        n = len(dist)
+        dmat = np.zeros((n, n))
+        raw = 0
+        if circular_center:
+            dmat[0, 1:] = radius
+            raw = 1
+        ang = np.pi / num_arounded
+        for r in range(raw, n):
+            for q in range(r + 1, n):
+                dmat[r, q] = np.abs(np.sin((q - r) * ang) * 2 * radius)
+        dmat += dmat.T
+        eps = 1e-5 if diag_eps is None else diag_eps
+    ds = np.exp(-1j * np.outer(omega, dist / c)) / n
+    if kind == "ds":
+        return ds
+    Rn = np.sinc(dmat[None] * omega[:, None, None] / c) + np.eye(n) * eps
+    num = np.linalg.solve(Rn, ds[..., None])[..., 0]
+    den = np.einsum("...d,...d->...", ds.conj(), num)
+    return num / den[..., None]
+
+
+def classic_enhance(samps, kind, geometry, doa, normalize=False, chunk_len=-1, c=343, sr=16000,
+                    frame_len=512, frame_hop=256, window="hann", center=True, **geo):
+    """apply_classic_beamformer.py:88-112 for one utterance: STFT -> DS / SD beamformer
+    (one DoA, or one per chunk of chunk_len frames) -> inverse STFT, rescaled to
+    max |samps| only with normalize."""
+    kw = dict(frame_len=frame_len, frame_hop=frame_hop, window=window, center=center)
+    obs = multichannel_stft(samps, transpose=False, **kw)
+    F = obs.shape[1]
+    if chunk_len > 0:
+        enh = np.hstack([beamform(classic_weight(kind, geometry, d, F, c=c, sr=sr, **geo),
+                                  obs[:, :, k * chunk_len:(k + 1) * chunk_len])
+                         for k, d in enumerate(doa)])
+    else:
+        enh = beamform(classic_weight(kind, geometry, doa, F, c=c, sr=sr, **geo), obs)
+    norm = float(np.max(np.abs(samps))) if normalize else None
+    return inverse_stft(enh, norm=norm, transpose=False, **kw)
+
+
 BEAMFORMERS = ("mvdr", "mpdr", "mpdr-whiten", "gevd", "pmwf-0", "pmwf-1")
 
 

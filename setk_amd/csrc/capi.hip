@@ -1300,7 +1300,9 @@ int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
     unsigned* d_omax = d_norm + n_utts;
     HIP_TRY(h, hipMemsetAsync(d_norm, 0, (size_t)2 * n_utts * sizeof(unsigned), s));
     const UttDesc* d_uds = static_cast<const UttDesc*>(d_uds_v);
-    HIP_TRY(h, launch_maxabs(d_uds, C, d_norm, n_utts, max_samples, s));
+    // norm stays 0 with SETK_FLAG_NO_RENORM: scale_kernel then only converts the sample type
+    if (!(flags & SETK_FLAG_NO_RENORM))
+        HIP_TRY(h, launch_maxabs(d_uds, C, d_norm, n_utts, max_samples, s));
     HIP_TRY(h, launch_pack_fixed_weights(d_sets, static_cast<const int*>(d_idx_v), n_utts, C, d_w, s));
 
     Pass2Args p2;

@@ -213,7 +213,7 @@ class BatchEnhancer(object):
                 enh = (enh * ms).contiguous()
             L = ctx.istft_num_samples(T)
             wave = torch.empty((1, L), dtype=torch.float32, device=dev)
-            norm = a.abs().max().reshape(1).contiguous()
+            norm = a.abs().max().reshape(1).contiguous() if self.renorm else None
             ctx.istft(enh.reshape(1, T, F), 1, T, None, norm, wave)
             out = wave[0]
             if self.pcm16:
@@ -286,13 +286,15 @@ class FixedBatchBeamformer(object):
 
     def __init__(self, weights, frame_len=512, frame_hop=256, center=True,
                  round_power_of_two=True, window="hann", pcm16=False, device=None,
-                 max_batch_samples=1 << 29):
+                 max_batch_samples=1 << 29, renorm=True):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
             raise _ffi.SetkError("setk_amd needs an MI355X GPU (no CPU fallback)")
         self.ctx = _ffi.default_context(device)
         self.dev = torch.device("cuda", self.ctx.device)
+        # renorm=False: inverse_stft(norm=None), apply_classic_beamformer.py:109-110
+        self.renorm = bool(renorm)
         weights = np.asarray(weights)
         if weights.ndim == 2:
             weights = weights[None]
@@ -365,7 +367,8 @@ class FixedBatchBeamformer(object):
             beams.append(int(beam))
         ctx.apply_weights_batch(C, [t.data_ptr() for t in audio], ns, self._d_weights,
                                 self.weights.shape[0], beams, [t.data_ptr() for t in waves],
-                                flags=_ffi.FLAG_OUT_PCM16 if self.pcm16 else 0)
+                                flags=(_ffi.FLAG_OUT_PCM16 if self.pcm16 else 0) |
+                                (0 if self.renorm else _ffi.FLAG_NO_RENORM))
         for j, i in enumerate(batch):
             results[i] = waves[j].cpu().numpy()
 

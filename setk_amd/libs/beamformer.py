@@ -16,7 +16,14 @@ numpy.linalg.LinAlgError exactly where the reference's LAPACK calls would.
 Eigenvector gauge: the reference inherits a LAPACK dependent per-bin sign from
 eigh / eigh(A, B).  Here every principal eigenvector has component 0 real and
 non-negative (for the pencil the rule applies to L^H v with Rn = L L^H), see
-DESIGN.md "Gauge".  Geometry based (DS/SD) beamformers are out of scope.
+DESIGN.md "Gauge".
+
+Geometry based beamformers (reference :133-212, 343-512): the delay-and-sum and
+superdirective WEIGHTS are F x N closed forms of the array geometry and the
+direction of arrival (a steer vector, for SD one N x N solve per bin against the
+diffuse-field coherence) -- a few kilobytes of float64 host arithmetic per
+direction, kept on the host in the reference's own formulas; applying them to an
+utterance is the device beamformer (setk_beamform / setk_apply_weights_batch).
 """
 import numpy as np
 
@@ -27,7 +34,9 @@ __all__ = [
     "compute_covar", "solve_pevd", "do_ban", "rank1_constraint", "Beamformer", "FixedBeamformer",
     "SupervisedBeamformer", "MvdrBeamformer", "MpdrBeamformer", "PmwfBeamformer",
     "GevdBeamformer", "OnlineSupervisedBeamformer", "OnlineMvdrBeamformer",
-    "OnlineGevdBeamformer"
+    "OnlineGevdBeamformer", "diffuse_covar", "plane_steer_vector", "linear_steer_vector",
+    "circular_steer_vector", "DSBeamformer", "LinearDSBeamformer", "CircularDSBeamformer",
+    "LinearSDBeamformer", "CircularSDBeamformer"
 ]
 
 _STATUS_TEXT = {
@@ -123,9 +132,7 @@ class Beamformer(object):
 
 
 class FixedBeamformer(Beamformer):
-    """Beamformer with predefined weights F x N (reference :323-340); the
-    geometry that produces such weights (DS / SD steer vectors) is out of scope,
-    the beamforming itself is the device kernel."""
+    """Beamformer with predefined weights F x N (reference :323-340)."""
 
     def __init__(self, weight):
         super(FixedBeamformer, self).__init__()
@@ -133,6 +140,130 @@ class FixedBeamformer(Beamformer):
 
     def run(self, obs):
         return self.beamform(self.weight, obs)
+
+
+# ---- array geometry: steer vectors and the diffuse-field coherence (host, float64) ----
+def diffuse_covar(num_bins, dist_mat, sr=16000, c=340, diag_eps=0.1):
+    """Coherence of the spherically isotropic noise field, F x N x N:
+    sinc(2 f d_ij / c) + diag_eps I (reference :133-151; numpy's normalised sinc)."""
+    dist_mat = np.asarray(dist_mat, dtype=np.float64)
+    N = dist_mat.shape[0]
+    omega = np.pi * np.arange(num_bins) * sr / (num_bins - 1)
+    return np.sinc(dist_mat[None] * omega[:, None, None] / c) + np.eye(N) * diag_eps
+
+
+def plane_steer_vector(distance, num_bins, c=340, sr=16000):
+    """exp(-j omega d_n / c), F x N, for distances projected on the DoA (:154-165)."""
+    omega = np.pi * np.arange(num_bins) * sr / (num_bins - 1)
+    return np.exp(-1j * np.outer(omega, np.asarray(distance, dtype=np.float64) / c))
+
+
+def linear_steer_vector(topo, doa, num_bins, c=340, sr=16000):
+    """Linear array at positions topo (m), DoA in degrees, 0 = end-fire (:168-184)."""
+    dist = np.cos(doa * np.pi / 180) * np.asarray(topo, dtype=np.float64)
+    return plane_steer_vector(dist, num_bins, c=c, sr=sr)
+
+
+def circular_steer_vector(redius, num_arounded, doa, num_bins, c=349, sr=16000, center=False):
+    """Uniform circular array (optionally with a centre microphone first) (:187-212)."""
+    dirc = np.arange(num_arounded) * 2 * np.pi / num_arounded
+    dist = np.cos(dirc - doa * np.pi / 180) * redius
+    if center:
+        dist = np.concatenate([np.array([0]), dist])
+    return plane_steer_vector(-dist, num_bins, c=c, sr=sr)
+
+
+def _superdirective(steer_vector, Rn):
+    """w = Rn^-1 d / (d^H Rn^-1 d) per bin (:454-460, 505-511)."""
+    numerator = np.linalg.solve(Rn, steer_vector[..., None])[..., 0]
+    denominator = np.einsum("...d,...d->...", steer_vector.conj(), numerator)
+    return numerator / denominator[..., None]
+
+
+class DSBeamformer(Beamformer):
+    """Base of the geometry beamformers: weight(doa, num_bins) on the host, the
+    beamforming on the device (reference :343-374)."""
+
+    def __init__(self, num_mics):
+        super(DSBeamformer, self).__init__()
+        self.num_mics = num_mics
+
+    def weight(self, doa, num_bins, c=340, sr=16000):
+        raise NotImplementedError
+
+    def run(self, doa, obs, c=340, sr=16000):
+        if obs.shape[0] != self.num_mics:
+            raise ValueError("Shape of obs do not match with number" +
+                             f"of microphones, {self.num_mics} vs {obs.shape[0]}")
+        weight = self.weight(doa, obs.shape[1], c=c, sr=sr)
+        return self.beamform(weight, obs)
+
+
+class LinearDSBeamformer(DSBeamformer):
+    """Delay and sum, linear array (:377-396)."""
+
+    def __init__(self, linear_topo):
+        super(LinearDSBeamformer, self).__init__(len(linear_topo))
+        self.linear_topo = np.array(linear_topo)
+
+    def weight(self, doa, num_bins, c=340, sr=16000):
+        return linear_steer_vector(self.linear_topo, doa, num_bins, c=c, sr=sr) / self.num_mics
+
+
+class CircularDSBeamformer(DSBeamformer):
+    """Delay and sum, circular array (:399-427)."""
+
+    def __init__(self, radius, num_arounded, center=False):
+        super(CircularDSBeamformer, self).__init__(num_arounded + 1 if center else num_arounded)
+        self.radius = radius
+        self.center = center
+        self.num_arounded = num_arounded
+
+    def weight(self, doa, num_bins, c=340, sr=16000):
+        sv = circular_steer_vector(self.radius, self.num_arounded, doa, num_bins, c=c, sr=sr,
+                                   center=self.center)
+        return sv / self.num_mics
+
+
+class LinearSDBeamformer(LinearDSBeamformer):
+    """Superdirective beamformer in a diffuse noise field, linear array (:430-460)."""
+
+    def __init__(self, linear_topo):
+        super(LinearSDBeamformer, self).__init__(linear_topo)
+        mat = np.tile(self.linear_topo, (self.num_mics, 1))
+        self.distance_mat = np.abs(mat - np.transpose(mat))
+
+    def weight(self, doa, num_bins, c=340, sr=16000, diag_eps=0.1):
+        sv = super(LinearSDBeamformer, self).weight(doa, num_bins, c=c, sr=sr)
+        Rn = diffuse_covar(num_bins, self.distance_mat, sr=sr, c=c, diag_eps=diag_eps)
+        return _superdirective(sv, Rn)
+
+
+class CircularSDBeamformer(CircularDSBeamformer):
+    """Superdirective beamformer, circular array (:463-511)."""
+
+    def __init__(self, radius, num_arounded, center=False):
+        super(CircularSDBeamformer, self).__init__(radius, num_arounded, center=center)
+        self.distance_mat = self._compute_distance_mat()
+
+    def _compute_distance_mat(self):
+        distance_mat = np.zeros((self.num_mics, self.num_mics))
+        if self.center:
+            distance_mat[0, 1:] = self.radius
+            raw = 1
+        else:
+            raw = 0
+        ang = np.pi / self.num_arounded
+        for r in range(raw, self.num_mics):
+            for c in range(r + 1, self.num_mics):
+                distance_mat[r, c] = np.abs(np.sin((c - r) * ang) * 2 * self.radius)
+        distance_mat += distance_mat.T
+        return distance_mat
+
+    def weight(self, doa, num_bins, c=340, sr=16000, diag_eps=1e-5):
+        sv = super(CircularSDBeamformer, self).weight(doa, num_bins, c=c, sr=sr)
+        Rn = diffuse_covar(num_bins, self.distance_mat, sr=sr, c=c, diag_eps=diag_eps)
+        return _superdirective(sv, Rn)
 
 
 class SupervisedBeamformer(Beamformer):

@@ -156,6 +156,19 @@ def inverse_stft(stft_mat,
     return samps
 
 
+def check_doa(geometry, doa, online=False):
+    """DoA in degrees: [0, 180] for a linear array, [0, 360) for a circular one
+    (reference libs/utils.py:248-263); a list of them in the online mode."""
+    for d in (doa if online else [doa]):
+        if d < 0:
+            return False
+        if geometry == "linear" and d > 180:
+            return False
+        if geometry == "circular" and d >= 360:
+            return False
+    return True
+
+
 def filekey(path):
     # reference utils.py:210-221
     fname = os.path.basename(path)

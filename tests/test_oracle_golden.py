@@ -8,7 +8,7 @@ Pins the CPU oracle (oracle/np_oracle.py) against
 import numpy as np
 import pytest
 
-from conftest import load_golden, rms, rel_rms
+from conftest import load_golden, pcm16_rel_rms, rms, rel_rms
 from oracle import np_oracle as o
 from oracle import make_golden as mg
 from oracle import ref_harness as rh
@@ -286,3 +286,43 @@ def test_cgmm_update_alpha_equals_live_reference():
     for ua in (False, True):
         ref = libs.cluster.CgmmTrainer(obs, 2, update_alpha=ua).train(5)
         assert np.max(np.abs(o.cgmm_gamma(obs, 5, update_alpha=ua) - ref)) < 1e-9
+
+
+CLASSIC_RUNS = {
+    "ds.circular": dict(kind="ds", geometry="circular", doa=77.5, num_arounded=4),
+    "sd.circular.norm": dict(kind="sd", geometry="circular", doa=200.0, num_arounded=4, normalize=True),
+    "ds.linear": dict(kind="ds", geometry="linear", doa=60.0, linear_topo=(0.0, 0.04, 0.08, 0.12)),
+    "sd.linear": dict(kind="sd", geometry="linear", doa=135.0, linear_topo=(0.0, 0.05, 0.1, 0.2)),
+    "sd.center.norm": dict(kind="sd", geometry="circular", doa=10.0, num_arounded=3,
+                           circular_center=True, normalize=True),
+    "ds.online": dict(kind="ds", geometry="circular", num_arounded=4, chunk_len=16),
+}
+
+
+def classic_online_doas(num_samples, chunk_len=16):
+    T = 1 + num_samples // 256
+    return [30.0 + 50.0 * k for k in range(-(-T // chunk_len))]
+
+
+def test_classic_beamformer_goldens():
+    """DS / SD: the oracle against the reference's stored doc outputs
+    (doc/fixed_beamformer/asset: ds.wav = DS at 100 degrees with c = 340, sd.wav = SD
+    with --normalize) and against files the unmodified reference CLI wrote."""
+    g = load_golden("ref_classic.npz")
+    egs = (g["doc.egs"].astype(np.float32) / 32768.0).T.copy()
+    for name, kw in (("ds", dict(kind="ds")), ("sd", dict(kind="sd", normalize=True))):
+        y = o.classic_enhance(egs, geometry="circular", doa=100.0, c=340, num_arounded=4,
+                              radius=0.05, **kw)
+        ref = g[f"doc.{name}"]
+        assert y.shape == ref.shape
+        assert pcm16_rel_rms(ref, y) < 1e-3, (name, pcm16_rel_rms(ref, y))
+    for k in ("c0", "c1"):
+        samps = (g[f"{k}.pcm"].astype(np.float32) / 32768.0).T.copy()
+        for name, kw in CLASSIC_RUNS.items():
+            kw = dict(kw)
+            if name == "ds.online":
+                kw["doa"] = classic_online_doas(samps.shape[1])
+            y = o.classic_enhance(samps, c=343, **kw)
+            ref = g[f"{k}.{name}"]
+            assert y.shape == ref.shape, (k, name)
+            assert pcm16_rel_rms(ref, y) < 2e-4, (k, name, pcm16_rel_rms(ref, y))
