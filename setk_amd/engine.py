@@ -213,7 +213,7 @@ class BatchEnhancer(object):
                 enh = (enh * ms).contiguous()
             L = ctx.istft_num_samples(T)
             wave = torch.empty((1, L), dtype=torch.float32, device=dev)
-            norm = a.abs().max().reshape(1).contiguous() if self.renorm else None
+            norm = a.abs().max().reshape(1).contiguous()
             ctx.istft(enh.reshape(1, T, F), 1, T, None, norm, wave)
             out = wave[0]
             if self.pcm16:
@@ -387,7 +387,7 @@ class FixedBatchBeamformer(object):
             ctx.beamform(w, spec, C, T, F, enh)
             L = ctx.istft_num_samples(T)
             wave = torch.empty((1, L), dtype=torch.float32, device=dev)
-            norm = a.abs().max().reshape(1).contiguous()
+            norm = a.abs().max().reshape(1).contiguous() if self.renorm else None
             ctx.istft(enh.reshape(1, T, F), 1, T, None, norm, wave)
             out = wave[0]
             if self.pcm16:
