@@ -168,3 +168,80 @@ def test_cfg4_6ch_cgmm_then_mvdr(ctx):
     print(f"[cfg4] waveform rel rms: same mask {err_same:.2e}, end to end {err_e2e:.2e}")
     assert err_same < WAVE_TOL
     assert err_e2e < WAVE_TOL
+
+
+def test_full_batch_1000_utterances_oracle_spot_checks(ctx):
+    """bench.py's `full_batch` leg: the whole configs[2] batch (1000 x 8-ch x 30 s,
+    19.2 GB of audio) resident on ONE GPU in one setk_enhance_batch call.  Utterances
+    0, 500 and 999 are distinct scenes checked against the oracle; the 997 others are
+    copies of a fourth (also checked) and must equal each other bit for bit."""
+    from setk_amd import _ffi
+    dev = torch.device("cuda:0")
+    C, N, n = 8, 480000, 1000
+    special = {0: 600, 500: 601, 999: 602}
+    src = {i: synth(idx, C, N) for i, idx in special.items()}
+    filler = synth(603, C, N)
+    f_a = torch.from_numpy(filler[0]).to(dev)
+    f_m = torch.from_numpy(np.ascontiguousarray(filler[1], dtype=np.float32)).to(dev)
+    audio, masks = [], []
+    for i in range(n):
+        if i in src:
+            audio.append(torch.from_numpy(src[i][0]).to(dev))
+            masks.append(torch.from_numpy(np.ascontiguousarray(src[i][1], dtype=np.float32)).to(dev))
+        else:
+            audio.append(f_a.clone())
+            masks.append(f_m.clone())
+    L = ctx.istft_num_samples(ctx.num_frames(N))
+    outs = [torch.empty(L, dtype=torch.float32, device=dev) for _ in range(n)]
+    opts = _ffi.BfOpts(kind=_ffi.BF_MVDR, flags=_ffi.FLAG_CLAMP_MASK)
+    st = ctx.enhance_batch(opts, C, [t.data_ptr() for t in audio], [N] * n,
+                           [t.data_ptr() for t in masks], None, [t.data_ptr() for t in outs])
+    torch.cuda.synchronize()
+    assert st == [0] * n
+    worst = 0.0
+    for i, (mix, mask) in list(src.items()) + [(1, filler)]:
+        ref = o.enhance_utterance(mix, mask, kind="mvdr", gauge=True)
+        err = rel_rms(outs[i].cpu().numpy(), ref)
+        worst = max(worst, err)
+        assert err < WAVE_TOL, (i, err)
+    w1 = outs[1]
+    for i in (2, 250, 499, 501, 750, 998):
+        assert torch.equal(outs[i], w1), i
+    print(f"[full batch 1000 x 8ch x 30s] worst waveform rel rms vs oracle {worst:.2e}")
+
+
+def test_pcm16_streaming_pipeline_at_bench_size(tmp_path):
+    """The end-to-end path bench.py times (PCM16 wav + float32 numpy mask files ->
+    scripts/sptk/apply_adaptive_beamformer.py -> PCM16 wav) at 8-ch x 30 s: the files the
+    streaming pipeline wrote against the oracle run on the SAME 16-bit samples."""
+    import subprocess
+    import sys
+    import scipy.io.wavfile
+    from conftest import ROOT, pcm16_rel_rms
+    from setk_amd.libs import wavio
+    td = str(tmp_path)
+    C, N, nd, n = 8, 480000, 2, 6
+    scenes = []
+    for i in range(nd):
+        mix, mask = synth(610 + i, C, N)
+        pcm = wavio.float_to_pcm16(mix.T)
+        wavio.write_pcm16(f"{td}/s{i}.wav", pcm, 16000)
+        np.save(f"{td}/s{i}.npy", mask.astype(np.float32))
+        scenes.append((pcm.astype(np.float32).T / np.float32(32768.0), mask))
+    with open(f"{td}/wav.scp", "w") as ws, open(f"{td}/mask.scp", "w") as ms:
+        for k in range(n):
+            ws.write(f"u{k} {td}/s{k % nd}.wav\n")
+            ms.write(f"u{k} {td}/s{k % nd}.npy\n")
+    r = subprocess.run([sys.executable, f"{ROOT}/scripts/sptk/apply_adaptive_beamformer.py",
+                        "--mask-format", "numpy", "--batch-utts", "4", f"{td}/wav.scp",
+                        f"{td}/mask.scp", f"{td}/enh"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"Processed {n} utterances out of {n}" in r.stderr
+    refs = [o.enhance_utterance(np.ascontiguousarray(s), m, kind="mvdr", gauge=True)
+            for s, m in scenes]
+    for k in range(n):
+        sr, y = scipy.io.wavfile.read(f"{td}/enh/u{k}.wav")
+        assert sr == 16000 and y.dtype == np.int16 and y.shape == refs[k % nd].shape
+        err = pcm16_rel_rms(y, refs[k % nd])
+        assert err < WAVE_TOL, (k, err)
+    print("[pcm16 pipeline 8ch x 30s] ok")
