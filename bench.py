@@ -532,6 +532,15 @@ def other_configs(torch, _ffi, synth, dev):
                     "inputs resident in HBM",
         "ms_per_step": round(1e3 * dt, 3), "value": round(U * 30.0 / dt, 1)}
     ctx.close()
+    del audio, waves
+    torch.cuda.empty_cache()
+    # the paths around the fused hot path (SURVEY 8f-4 consumers, unfused engine)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_consumers
+        res["consumers_and_unfused"] = bench_consumers.run()
+    except Exception as e:  # pragma: no cover
+        res["consumers_and_unfused"] = {"error": repr(e)[:300]}
     return res
 
 

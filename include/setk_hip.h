@@ -277,6 +277,14 @@ int setk_wpe_step(setk_handle_t h, const float* spec, int num_channels, int num_
                   int num_bins, int taps, int delay, const double* lambda_ft, float* out,
                   int* status, void* stream);
 
+/* wpe() (libs/wpe.py:84-110) for n_utts utterances of the same channel count in one
+ * call: every iteration is ONE launch over (bin, utterance) instead of 257 workgroups
+ * per utterance.  spec[u] / out[u] [C][num_frames[u]][F] complex64 (host or device),
+ * status [n_utts][F] or NULL.  Same limits as setk_wpe. */
+int setk_wpe_batch(setk_handle_t h, int n_utts, const float* const* spec, int num_channels,
+                   const int* num_frames, int num_bins, int taps, int delay, int context,
+                   int num_iters, float* const* out, int* status, void* stream);
+
 /* ---- fused hot path ------------------------------------------------------
  * The compute body of apply_adaptive_beamformer.py:130-178 for a batch of
  * utterances that share the channel count, in four kernel stages:

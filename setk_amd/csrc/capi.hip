@@ -1336,110 +1336,143 @@ int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
 // `lambda_enh` (facted_wpd: |previous enhanced|^2) when given, else from
 // compute_lambda(spec); later iterations use compute_lambda(dereverb).
 namespace {
-int wpe_impl(setk_handle_t h, const float* spec, int num_channels, int num_frames, int num_bins,
-             int taps, int delay, int context, int num_iters, const float* lambda_enh,
-             const double* lambda_ft, float* out, float* inv_lambda_out, int* status, void* stream);
+// n_utts utterances of the same channel count per call: one wpe_step launch per
+// iteration covers every (bin, utterance).  lambda_enh / lambda_ft / inv_lambda_out only
+// with n_utts == 1 (facted_wpd, wpe_step).  status: [n_utts][F] (host or device) or NULL.
+int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int num_channels,
+                   const int* num_frames, int num_bins, int taps, int delay, int context,
+                   int num_iters, const float* lambda_enh, const double* lambda_ft,
+                   float* const* out, float* inv_lambda_out, int* status, void* stream) {
+    if (!h || n_utts <= 0 || !spec || !out || !num_frames || num_bins <= 0 || num_iters <= 0 ||
+        delay < 0 || context < 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    if ((lambda_enh || lambda_ft || inv_lambda_out) && n_utts != 1)
+        return fail(h, SETK_ERR_INVALID, "caller-supplied variances need n_utts == 1");
+    const int C = num_channels, F = num_bins;
+    if (!wpe_supported(C, taps))
+        return fail(h, SETK_ERR_UNSUPPORTED, wpe_limit_message(C, taps));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h, s);
+    struct Utt {
+        const float* d_spec;
+        OutBuf ob;
+        float *x_fct, *bufs[2];
+        double* lam;
+        int T;
+    };
+    std::vector<Utt> us(n_utts);
+    int rc;
+    for (int u = 0; u < n_utts; ++u) {
+        Utt& q = us[u];
+        q.T = num_frames[u];
+        if (!spec[u] || !out[u] || q.T <= 0) return fail(h, SETK_ERR_INVALID, "null utterance");
+        const size_t n = (size_t)C * q.T * F;
+        rc = stage_in(h, spec[u], n * 2, s, &q.d_spec);
+        if (rc) return rc;
+        rc = stage_out(h, out[u], n * sizeof(float2), &q.ob);
+        if (rc) return rc;
+        q.x_fct = static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
+        q.bufs[0] = static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
+        q.bufs[1] = static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
+        q.lam = static_cast<double*>(arena_alloc(h, (size_t)q.T * F * sizeof(double)));
+        if (!q.x_fct || !q.bufs[0] || !q.bufs[1] || !q.lam) return fail(h, SETK_ERR_NOMEM, "arena");
+    }
+    const float* d_enh = nullptr;
+    if (lambda_enh) {
+        rc = stage_in(h, lambda_enh, (size_t)us[0].T * F * 2, s, &d_enh);
+        if (rc) return rc;
+    }
+    const double* d_lam_in = nullptr;
+    if (lambda_ft) {
+        rc = stage_in(h, lambda_ft, (size_t)us[0].T * F, s, &d_lam_in);
+        if (rc) return rc;
+    }
+    OutBuf ob_il;
+    if (inv_lambda_out) {
+        rc = stage_out(h, inv_lambda_out, (size_t)us[0].T * F * sizeof(float), &ob_il);
+        if (rc) return rc;
+    }
+    int* d_st = static_cast<int*>(arena_alloc(h, (size_t)n_utts * F * sizeof(int) * (size_t)num_iters));
+    if (!d_st) return fail(h, SETK_ERR_NOMEM, "arena");
+    for (int u = 0; u < n_utts; ++u)
+        HIP_TRY(h, launch_wpe_transpose(us[u].d_spec, C, us[u].T, F, us[u].x_fct, true, s));
+    const size_t ab = wpe_args_bytes();
+    std::vector<char> tbl((size_t)n_utts * ab);
+    for (int it = 0; it < num_iters; ++it) {
+        for (int u = 0; u < n_utts; ++u) {
+            Utt& q = us[u];
+            const float* cur = it == 0 ? q.x_fct : q.bufs[(it - 1) & 1];
+            if (it == 0 && d_lam_in)
+                // wpe_step (libs/wpe.py:58-81): the caller's variances as given, F x T float64
+                HIP_TRY(h, hipMemcpyAsync(q.lam, d_lam_in, (size_t)q.T * F * sizeof(double),
+                                          hipMemcpyDeviceToDevice, s));
+            else if (it == 0 && d_enh)
+                HIP_TRY(h, launch_wpe_lambda_from_enh(d_enh, q.T, F, q.lam, s));
+            else
+                HIP_TRY(h, launch_wpe_lambda(cur, C, q.T, F, context, q.lam, s));
+            wpe_fill_args(tbl.data() + (size_t)u * ab, q.x_fct, q.lam, q.bufs[it & 1],
+                          d_st + ((size_t)it * n_utts + u) * F, C, q.T, taps, delay);
+        }
+        void* d_tbl;
+        rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
+        if (rc) return rc;
+        HIP_TRY(h, launch_wpe_step_batch(d_tbl, n_utts, C, F, taps, s));
+    }
+    for (int u = 0; u < n_utts; ++u) {
+        Utt& q = us[u];
+        HIP_TRY(h, launch_wpe_transpose(q.bufs[(num_iters - 1) & 1], C, q.T, F,
+                                        static_cast<float*>(q.ob.dev), false, s));
+        rc = copy_back(h, q.ob, s);
+        if (rc) return rc;
+    }
+    if (inv_lambda_out) {
+        HIP_TRY(h, launch_wpe_inv_lambda(us[0].lam, us[0].T, F, static_cast<float*>(ob_il.dev), s));
+        rc = copy_back(h, ob_il, s);
+        if (rc) return rc;
+    }
+    if (status) {
+        // worst status over the iterations, per utterance and bin
+        std::vector<int> st((size_t)n_utts * F * num_iters);
+        HIP_TRY(h, hipMemcpyAsync(st.data(), d_st, st.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        std::vector<int> worst((size_t)n_utts * F, 0);
+        for (int it = 0; it < num_iters; ++it)
+            for (size_t i = 0; i < worst.size(); ++i)
+                worst[i] = std::max(worst[i], st[(size_t)it * n_utts * F + i]);
+        if (is_device_ptr(status))
+            HIP_TRY(h, hipMemcpy(status, worst.data(), worst.size() * sizeof(int),
+                                 hipMemcpyHostToDevice));
+        else
+            memcpy(status, worst.data(), worst.size() * sizeof(int));
+    }
+    // descriptors and staged buffers live in the arena: drained before the next call reuses it
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
 }
+}  // namespace
 
 int setk_wpe(setk_handle_t h, const float* spec, int num_channels, int num_frames, int num_bins,
              int taps, int delay, int context, int num_iters, const float* lambda_enh,
              float* out, float* inv_lambda_out, int* status, void* stream) {
-    return wpe_impl(h, spec, num_channels, num_frames, num_bins, taps, delay, context, num_iters,
-                    lambda_enh, nullptr, out, inv_lambda_out, status, stream);
+    return wpe_batch_impl(h, 1, &spec, num_channels, &num_frames, num_bins, taps, delay, context,
+                          num_iters, lambda_enh, nullptr, &out, inv_lambda_out, status, stream);
 }
 
 int setk_wpe_step(setk_handle_t h, const float* spec, int num_channels, int num_frames,
                   int num_bins, int taps, int delay, const double* lambda_ft, float* out,
                   int* status, void* stream) {
     if (!lambda_ft) return fail(h, SETK_ERR_INVALID, "setk_wpe_step needs lambda");
-    return wpe_impl(h, spec, num_channels, num_frames, num_bins, taps, delay, 0, 1, nullptr,
-                    lambda_ft, out, nullptr, status, stream);
+    return wpe_batch_impl(h, 1, &spec, num_channels, &num_frames, num_bins, taps, delay, 0, 1,
+                          nullptr, lambda_ft, &out, nullptr, status, stream);
 }
 
-namespace {
-int wpe_impl(setk_handle_t h, const float* spec, int num_channels, int num_frames, int num_bins,
-             int taps, int delay, int context, int num_iters, const float* lambda_enh,
-             const double* lambda_ft, float* out, float* inv_lambda_out, int* status, void* stream) {
-    if (!h || !spec || !out || num_frames <= 0 || num_bins <= 0 || num_iters <= 0 || delay < 0 ||
-        context < 0)
-        return fail(h, SETK_ERR_INVALID, "bad args");
-    const int C = num_channels, T = num_frames, F = num_bins;
-    if (!wpe_supported(C, taps))
-        return fail(h, SETK_ERR_UNSUPPORTED, wpe_limit_message(C, taps));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(h, hipSetDevice(h->device));
-    arena_reset(h, s);
-    const size_t n = (size_t)C * T * F;
-    const float* d_spec;
-    int rc = stage_in(h, spec, n * 2, s, &d_spec);
-    if (rc) return rc;
-    const float* d_enh = nullptr;
-    if (lambda_enh) {
-        rc = stage_in(h, lambda_enh, (size_t)T * F * 2, s, &d_enh);
-        if (rc) return rc;
-    }
-    const double* d_lam_in = nullptr;
-    if (lambda_ft) {
-        rc = stage_in(h, lambda_ft, (size_t)T * F, s, &d_lam_in);
-        if (rc) return rc;
-    }
-    OutBuf ob, ob_il;
-    rc = stage_out(h, out, n * sizeof(float2), &ob);
-    if (rc) return rc;
-    if (inv_lambda_out) {
-        rc = stage_out(h, inv_lambda_out, (size_t)T * F * sizeof(float), &ob_il);
-        if (rc) return rc;
-    }
-    float* x_fct = static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
-    float* d_a = static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
-    float* d_b = static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
-    double* lam = static_cast<double*>(arena_alloc(h, (size_t)T * F * sizeof(double)));
-    int* d_st = static_cast<int*>(arena_alloc(h, (size_t)F * sizeof(int) * (size_t)num_iters));
-    if (!x_fct || !d_a || !d_b || !lam || !d_st) return fail(h, SETK_ERR_NOMEM, "arena");
-    HIP_TRY(h, launch_wpe_transpose(d_spec, C, T, F, x_fct, true, s));
-    const float* cur = x_fct;
-    float* bufs[2] = {d_a, d_b};
-    for (int it = 0; it < num_iters; ++it) {
-        if (it == 0 && d_lam_in)
-            // wpe_step (libs/wpe.py:58-81): the caller's variances as given, F x T float64
-            HIP_TRY(h, hipMemcpyAsync(lam, d_lam_in, (size_t)T * F * sizeof(double),
-                                      hipMemcpyDeviceToDevice, s));
-        else if (it == 0 && d_enh)
-            HIP_TRY(h, launch_wpe_lambda_from_enh(d_enh, T, F, lam, s));
-        else
-            HIP_TRY(h, launch_wpe_lambda(cur, C, T, F, context, lam, s));
-        float* dst = bufs[it & 1];
-        HIP_TRY(h, launch_wpe_step(x_fct, lam, C, T, F, taps, delay, dst, d_st + (size_t)it * F, s));
-        cur = dst;
-    }
-    HIP_TRY(h, launch_wpe_transpose(cur, C, T, F, static_cast<float*>(ob.dev), false, s));
-    if (inv_lambda_out)
-        HIP_TRY(h, launch_wpe_inv_lambda(lam, T, F, static_cast<float*>(ob_il.dev), s));
-    rc = copy_back(h, ob, s);
-    if (rc) return rc;
-    if (inv_lambda_out) {
-        rc = copy_back(h, ob_il, s);
-        if (rc) return rc;
-    }
-    bool sync = ob.host || (inv_lambda_out && ob_il.host);
-    if (status) {
-        // worst status over the iterations, per bin
-        std::vector<int> st((size_t)F * num_iters);
-        HIP_TRY(h, hipMemcpyAsync(st.data(), d_st, st.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipStreamSynchronize(s));
-        std::vector<int> worst(F, 0);
-        for (int it = 0; it < num_iters; ++it)
-            for (int f = 0; f < F; ++f) worst[f] = std::max(worst[f], st[(size_t)it * F + f]);
-        if (is_device_ptr(status))
-            HIP_TRY(h, hipMemcpy(status, worst.data(), F * sizeof(int), hipMemcpyHostToDevice));
-        else
-            memcpy(status, worst.data(), F * sizeof(int));
-        sync = false;
-    }
-    if (sync) HIP_TRY(h, hipStreamSynchronize(s));
-    return SETK_OK;
+int setk_wpe_batch(setk_handle_t h, int n_utts, const float* const* spec, int num_channels,
+                   const int* num_frames, int num_bins, int taps, int delay, int context,
+                   int num_iters, float* const* out, int* status, void* stream) {
+    return wpe_batch_impl(h, n_utts, spec, num_channels, num_frames, num_bins, taps, delay, context,
+                          num_iters, nullptr, nullptr, out, nullptr, status, stream);
 }
-}  // namespace
 
 int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, int num_channels,
                        const float* const* audio, const int* num_samples,

@@ -202,7 +202,10 @@ hipError_t launch_wpe_lambda(const float* d_fct, int C, int T, int F, int ctx, d
 hipError_t launch_wpe_lambda_from_enh(const float* enh_tf, int T, int F, double* lam,
                                       hipStream_t s);
 hipError_t launch_wpe_inv_lambda(const double* lam, int T, int F, float* out, hipStream_t s);
-hipError_t launch_wpe_step(const float* x_fct, const double* lam, int N, int T, int F, int taps,
-                           int delay, float* out_fct, int* status, hipStream_t s);
+size_t wpe_args_bytes();
+void wpe_fill_args(void* dst, const float* x_fct, const double* lam, float* out_fct, int* status,
+                   int N, int T, int taps, int delay);
+hipError_t launch_wpe_step_batch(const void* d_tbl, int n_utts, int N, int F, int taps,
+                                 hipStream_t s);
 
 }  // namespace setk

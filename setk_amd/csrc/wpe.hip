@@ -21,6 +21,7 @@
 // substitution and the filter is applied in a second sweep over the frames.
 // Layout: spectrograms [F][N][T] (frames contiguous), lambda [F][T] float64.
 #include <cstdio>
+#include <cstring>
 #include "common.h"
 #include "../../include/setk_hip.h"
 
@@ -134,8 +135,10 @@ struct WpeArgs {
     int N, T, taps, delay;
 };
 
-__global__ __launch_bounds__(256) void wpe_step_kernel(WpeArgs a) {
+// one workgroup per (bin, utterance): blockIdx.y indexes the argument table
+__global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict__ tbl) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
+    const WpeArgs a = tbl[blockIdx.y];
     const int N = a.N, T = a.T, taps = a.taps, delay = a.delay;
     const int NK = N * taps, D = NK + N;
     zd* R = reinterpret_cast<zd*>(wsm);          // [NK][NK] row major; L in place (lower)
@@ -370,8 +373,10 @@ hipError_t launch_wpe_inv_lambda(const double* lam, int T, int F, float* out, hi
     return hipGetLastError();
 }
 
-hipError_t launch_wpe_step(const float* x_fct, const double* lam, int N, int T, int F, int taps,
-                           int delay, float* out_fct, int* status, hipStream_t s) {
+size_t wpe_args_bytes() { return sizeof(WpeArgs); }
+
+void wpe_fill_args(void* dst, const float* x_fct, const double* lam, float* out_fct, int* status,
+                   int N, int T, int taps, int delay) {
     WpeArgs a;
     a.x = reinterpret_cast<const float2*>(x_fct);
     a.lam = lam;
@@ -381,11 +386,18 @@ hipError_t launch_wpe_step(const float* x_fct, const double* lam, int N, int T, 
     a.T = T;
     a.taps = taps;
     a.delay = delay;
+    memcpy(dst, &a, sizeof(a));
+}
+
+// d_tbl: n_utts argument blocks (device); every utterance has N channels and `taps` taps
+hipError_t launch_wpe_step_batch(const void* d_tbl, int n_utts, int N, int F, int taps,
+                                 hipStream_t s) {
     const size_t lds = wpe_lds_bytes(N, taps);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wpe_step_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(wpe_step_kernel, dim3(F), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(wpe_step_kernel, dim3(F, n_utts), dim3(256), lds, s,
+                       static_cast<const WpeArgs*>(d_tbl));
     return hipGetLastError();
 }
 

@@ -21,7 +21,7 @@ from .utils import EPSILON, get_logger
 
 logger = get_logger(__name__)
 
-__all__ = ["wpe", "wpe_step", "compute_tap_mat", "compute_lambda", "facted_wpd"]
+__all__ = ["wpe", "wpe_batch", "wpe_step", "compute_tap_mat", "compute_lambda", "facted_wpd"]
 
 
 def compute_tap_mat(obs, taps, delay):
@@ -120,6 +120,25 @@ def wpe(reverb, taps=10, delay=3, context=1, num_iters=3):
     logger.info(f"WPE: F = {F}, N = {N}, T = {T}")
     out, _ = _run(_to_ctf(reverb), taps, delay, context, num_iters)
     return np.transpose(out, (2, 0, 1)).astype(np.complex128)
+
+
+def wpe_batch(reverbs, taps=10, delay=3, context=1, num_iters=3):
+    """wpe() for a list of utterances with the same channel count: one launch per
+    iteration over every (bin, utterance).  reverbs: F x N x T_u arrays -> list of
+    dereverberated F x N x T_u complex128 arrays; an utterance whose tap correlation is
+    singular comes back as None (the CLI skips it like the reference's LinAlgError)."""
+    if not len(reverbs):
+        return []
+    specs = [_to_ctf(r) for r in reverbs]
+    C, _, F = specs[0].shape
+    if any(s.shape[0] != C or s.shape[2] != F for s in specs):
+        raise ValueError("wpe_batch needs the same channel and bin count in every utterance")
+    outs = [np.empty_like(s) for s in specs]
+    status = np.zeros((len(specs), F), dtype=np.int32)
+    _ffi.default_context().wpe_batch(specs, C, [s.shape[1] for s in specs], F, taps, delay, context,
+                                     num_iters, outs, status=status)
+    return [None if status[u].any() else np.transpose(outs[u], (2, 0, 1)).astype(np.complex128)
+            for u in range(len(specs))]
 
 
 def facted_wpd(obs, cgmm_iters=10, wpd_iters=3, taps=10, delay=3, context=1, update_alpha=False):

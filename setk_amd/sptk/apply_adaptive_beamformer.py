@@ -78,6 +78,10 @@ _OPTIONS = (
                                  "cache (mmap + hipHostRegister) instead of staging them through "
                                  "page-locked slabs (measured slower inside the pipeline: "
                                  "profiles/r02l_e2e_zero_copy_sweep.txt)")),
+    (("--h2d",), dict(default="batch", type=str, choices=["payload", "batch"],
+                      help="[setk_amd] host-to-device copies of the pipeline: ONE per batch from "
+                           "the page-locked slab (default: ~15 %% faster on first-read inputs, "
+                           "profiles/r04_e2e_h2d_ab.txt), or one per payload as soon as it is read")),
     (("--pipeline-depth",), dict(default=3, type=int,
                                  help="[setk_amd] batches in flight in the host pipeline")),
     (("--read-threads",), dict(default=0, type=int,
@@ -273,7 +277,7 @@ def _run_pipeline(args, engine, writer, wav_reader, tgt, itf, keys):
 
     pipe = StreamPipeline(engine, sink, announce=announce, batch_utts=args.batch_utts,
                           depth=args.pipeline_depth, read_threads=args.read_threads or None,
-                          zero_copy=args.zero_copy)
+                          zero_copy=args.zero_copy, h2d=args.h2d)
     wide = []  # more than 8 channels: stand-alone operators, after the pipeline drained
     try:
         for key in keys:

@@ -4,8 +4,8 @@ GWPE dereverberation on the MI355X.
 
 Drop-in for funcwj/setk ``scripts/sptk/apply_wpe.py`` (same positional arguments,
 options and defaults, :86-135; multi-channel PCM_16 wav out): STFT, the WPE
-iterations (setk_wpe, fp64) and the inverse STFT of every channel run on the
-GPU.  ``--nara-wpe true`` is refused: that third-party package is not part of
+iterations (setk_wpe_batch, fp64, --batch-utts utterances per launch) and the
+inverse STFT of every channel run on the GPU.  ``--nara-wpe true`` is refused: that third-party package is not part of
 this path.
 """
 import argparse
@@ -17,7 +17,7 @@ from setk_amd.dist import Shard
 from setk_amd.libs.data_handler import SpectrogramReader, WaveWriter
 from setk_amd.libs.opts import StftParser, strtobool
 from setk_amd.libs.utils import get_logger, inverse_stft
-from setk_amd.libs.wpe import wpe
+from setk_amd.libs.wpe import wpe_batch
 
 logger = get_logger(__name__)
 
@@ -37,29 +37,45 @@ def run(args):
                                **stft_kwargs)
     num_done = 0
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
+
+        def flush(pending):
+            """--batch-utts utterances (grouped by channel count) per setk_wpe_batch call:
+            one launch per iteration over every (bin, utterance)."""
+            done = 0
+            groups = {}
+            for key, rev in pending:
+                groups.setdefault(rev.shape[1], []).append((key, rev))
+            for _, items in groups.items():
+                try:
+                    outs = wpe_batch([r for _, r in items], num_iters=args.num_iters,
+                                     context=args.context, taps=args.taps, delay=args.delay)
+                except SetkUnsupported as e:
+                    # a shape beyond the device kernels' limits (channels x taps): skip the
+                    # utterances like a numerical failure instead of ending the run
+                    for key, _ in items:
+                        logger.warning(f"{key}: skipped, {e}")
+                    continue
+                for (key, _), dereverb in zip(items, outs):
+                    if dereverb is None:
+                        logger.warning(f"{key}: Failed cause LinAlgError in wpe")
+                        continue
+                    dereverb = np.transpose(dereverb, (1, 2, 0))  # F x N x T => N x T x F
+                    samps = np.stack([inverse_stft(spectra, **stft_kwargs) for spectra in dereverb])
+                    writer.write(key, samps)
+                    done += 1
+            return done
+
+        pending = []
         for key in shard.assign_by_duration(reader):
             reverbed = reader[key]
             logger.info(f"Processing utt {key}...")
             if reverbed.ndim == 2:
                 reverbed = reverbed[None, ...]
-            reverbed = np.transpose(reverbed, (2, 0, 1))  # N x T x F => F x N x T
-            try:
-                dereverb = wpe(reverbed, num_iters=args.num_iters, context=args.context,
-                               taps=args.taps, delay=args.delay)
-            except np.linalg.LinAlgError:
-                logger.warning(f"{key}: Failed cause LinAlgError in wpe")
-                continue
-            except SetkUnsupported as e:
-                # a shape beyond the device kernels' limits (channels x taps): skip the
-                # utterance like a numerical failure instead of ending the run
-                logger.warning(f"{key}: skipped, {e}")
-                continue
-            dereverb = np.transpose(dereverb, (1, 2, 0))  # F x N x T => N x T x F
-            samps = np.stack([inverse_stft(spectra, **stft_kwargs) for spectra in dereverb])
-            writer.write(key, samps)
-            num_done += 1
-            if not num_done % 100:
-                logger.info(f"Processed {num_done:d} utterances...")
+            pending.append((key, np.transpose(reverbed, (2, 0, 1))))  # N x T x F => F x N x T
+            if len(pending) >= max(1, args.batch_utts):
+                num_done += flush(pending)
+                pending = []
+        num_done += flush(pending)
     shard.barrier()
     if shard.world > 1:
         num_done = int(round(shard.sum_counts([num_done])[0]))
@@ -85,6 +101,8 @@ def build_parser():
     parser.add_argument("--sample-rate", type=int, default=16000, dest="sr",
                         help="Waveform data sample rate")
     parser.add_argument("--nara-wpe", type=strtobool, default=False, help="Use nara-wpe package")
+    parser.add_argument("--batch-utts", type=int, default=16,
+                        help="[setk_amd] utterances per batched WPE call")
     return parser
 
 

@@ -67,6 +67,21 @@ def test_wpe_matches_oracle(C, taps, N):
     assert rel_rms(out, ref) < 1e-4, (C, taps, rel_rms(out, ref))
 
 
+def test_wpe_batch_equals_single_calls():
+    """setk_wpe_batch: ragged lengths in one launch per iteration == one utterance at a
+    time, bit for bit; a singular utterance inside the batch comes back as None."""
+    from setk_amd.libs import wpe as W
+    rng = np.random.default_rng(3)
+    revs = [(rng.standard_normal((257, 3, T)) + 1j * rng.standard_normal((257, 3, T))).astype(np.complex64)
+            for T in (90, 61, 140)]
+    revs.insert(2, np.zeros((257, 3, 50), np.complex64))
+    outs = W.wpe_batch(revs, taps=5, delay=2, context=1, num_iters=2)
+    assert outs[2] is None
+    for k in (0, 1, 3):
+        single = W.wpe(revs[k], taps=5, delay=2, context=1, num_iters=2)
+        assert outs[k].dtype == np.complex128 and np.array_equal(outs[k], single), k
+
+
 def test_wpe_too_many_taps_is_refused():
     from setk_amd import _ffi
     from setk_amd.libs import wpe as W

@@ -1,0 +1,101 @@
+#!/usr/bin/env python
+"""Throughput of the paths AROUND the fused hot path (SURVEY 8f-4 consumers and the
+unfused engine): one JSON line, also embedded in bench.py's `other_configs`.
+
+  wpe_4ch_10taps      GWPE, 4 ch x 10 s, 10 taps, delay 3, 3 iterations (libs/wpe.py:84-110)
+  df_on_mask_4ch      compute_df_on_mask.py per utterance: STFT -> masked covariance ->
+                      principal eigenvector -> directional features
+  mvdr_nfft400_4ch    --frame-len 400 --round-power-of-two false (Bluestein STFT, unfused engine)
+  mvdr_12ch           12 channels (wide covariance / 16-lane solve, unfused engine)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SR = 16000
+
+
+def timed(fn, reps):
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def run(utts=16, seconds=10.0):
+    import torch
+    from setk_amd import _ffi, synth
+    from setk_amd.engine import BatchEnhancer
+    from setk_amd.libs import wpe as W
+    from setk_amd.libs import spatial as S
+    from setk_amd.libs import beamformer as B
+    from setk_amd.libs.utils import device_stft
+    N = int(seconds * SR)
+    res = {}
+    # ---- WPE ----
+    mixes = [synth.synth_utterance(3000 + i, 4, N) for i in range(min(utts, 4))]
+    specs = [np.ascontiguousarray(np.transpose(device_stft(m, 512, 128, True, True, "hann"),
+                                               (2, 0, 1))) for m in mixes]   # F x N x T
+    dt = timed(lambda: [W.wpe(s, taps=10, delay=3, context=1, num_iters=3) for s in specs], 2)
+    res["wpe_4ch_10taps"] = {
+        "workload": f"4-ch {seconds:g} s, hop 128, 10 taps x 3 iterations, numpy in / numpy out, "
+                    f"{len(specs)} utterances one at a time",
+        "ms_per_utt": round(1e3 * dt / len(specs), 2),
+        "value": round(len(specs) * seconds / dt, 1)}
+    if hasattr(W, "wpe_batch"):
+        dtb = timed(lambda: W.wpe_batch(specs * 4, taps=10, delay=3, context=1, num_iters=3), 2)
+        res["wpe_4ch_10taps_batched"] = {
+            "workload": f"the same, {4 * len(specs)} utterances per setk_wpe_batch call",
+            "ms_per_utt": round(1e3 * dtb / (4 * len(specs)), 2),
+            "value": round(4 * len(specs) * seconds / dtb, 1)}
+    # ---- directional features on a mask ----
+    mix, sp, nz = synth.synth_utterance(3100, 4, N, return_parts=True)
+    spec = device_stft(mix, 512, 256, True, True, "hann")          # C x T x F
+    s0 = device_stft(np.stack([sp[0], nz[0]]), 512, 256, True, True, "hann")
+    mask = synth.irm_from_spectra(s0[0], s0[1])
+
+    def df_one():
+        obs = np.transpose(spec, (0, 2, 1))
+        Rs = B.compute_covar(obs, mask)
+        sv = B.solve_pevd(Rs)
+        return S.directional_feats(obs, sv.T)
+    dt = timed(df_one, 5)
+    res["df_on_mask_4ch"] = {"workload": f"4-ch {seconds:g} s, compute_covar -> solve_pevd -> "
+                                         "directional_feats, numpy in / numpy out, one utterance",
+                             "ms_per_utt": round(1e3 * dt, 2), "value": round(seconds / dt, 1)}
+    # ---- unfused engine: n_fft = 400, 12 channels ----
+    for label, C, kw in (("mvdr_nfft400_4ch", 4, dict(frame_len=400, frame_hop=160,
+                                                      round_power_of_two=False)),
+                         ("mvdr_12ch", 12, dict(frame_len=512, frame_hop=256))):
+        eng = BatchEnhancer(beamformer="mvdr", **kw)
+        items = []
+        for i in range(utts):
+            mix, sp, nz = synth.synth_utterance(3200 + (i % 4), C, N, return_parts=True)
+            n_fft = kw["frame_len"] if kw.get("round_power_of_two") is False else 512
+            st = device_stft(np.stack([sp[0], nz[0]]), kw["frame_len"], kw["frame_hop"],
+                             kw.get("round_power_of_two", True), True, "hann")
+            items.append((mix, synth.irm_from_spectra(st[0], st[1]), None))
+        dt = timed(lambda: eng.enhance(items), 2)
+        res[label] = {"workload": f"{C}-ch {seconds:g} s x {utts} utterances, "
+                                  f"STFT {kw['frame_len']}/{kw['frame_hop']}, unfused engine "
+                                  "(stand-alone operators, host arrays in / out)",
+                      "ms_per_utt": round(1e3 * dt / utts, 2),
+                      "value": round(utts * seconds / dt, 1)}
+    return res
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--utts", type=int, default=16)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    a = ap.parse_args()
+    print(json.dumps(run(a.utts, a.seconds)))
