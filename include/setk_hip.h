@@ -227,6 +227,17 @@ int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
                           int num_iters, const float* const* init_mask, float* const* mask_out,
                           int flags, int spec_pitch, void* stream);
 
+/* The compute loop of estimate_cgmm_masks.py:44-64 for a batch, audio in, mask out:
+ * STFT (n_fft = 512 plan) written straight into the bin-major layout of the
+ * bin-resident EM, the EM itself, masks as float32 [T][F].  audio[u] device float32
+ * [C][num_samples[u]]; init_mask / mask_out / flags as setk_cgmm_masks_batch.
+ * SETK_ERR_UNSUPPORTED when one bin of the longest utterance does not fit a CU
+ * (then: setk_stft_batch + setk_cgmm_masks_batch). */
+int setk_cgmm_estimate_batch(setk_handle_t h, int n_utts, int num_channels,
+                             const float* const* audio, const int* num_samples, int num_iters,
+                             const float* const* init_mask, float* const* mask_out, int flags,
+                             void* stream);
+
 /* directional_feats (libs/spatial.py:184-208, compute_df_on_mask.py:40-54):
  * out[t][f] = mean over the n_pairs microphone pairs (i, j) = (pairs[2p],
  * pairs[2p+1], host array) of cos((arg X_i - arg X_j) - (arg v_i - arg v_j)),

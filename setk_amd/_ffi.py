@@ -54,7 +54,7 @@ def exported_symbols():
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_stft_batch", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
         "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
-        "setk_cgmm_masks_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
+        "setk_cgmm_masks_batch", "setk_cgmm_estimate_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
         "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_wpe_batch", "setk_set_profiling",
         "setk_last_stage_ms"
@@ -108,6 +108,9 @@ def load_library():
     lib.setk_cgmm_masks_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int), c_int,
                                           c_int, POINTER(c_void_p), POINTER(c_void_p), c_int,
                                           c_int, c_void_p]
+    lib.setk_cgmm_estimate_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int),
+                                             c_int, POINTER(c_void_p), POINTER(c_void_p), c_int,
+                                             c_void_p]
     lib.setk_enhance_batch.argtypes = [
         H, POINTER(BfOpts), c_int, c_int, POINTER(c_void_p), POINTER(c_int),
         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int),
@@ -336,6 +339,20 @@ class Context:
             self._lib.setk_cgmm_masks_batch(self._h, n, int(C), S, T, int(F), int(num_iters), I, O,
                                             CGMM_UPDATE_ALPHA if update_alpha else 0, int(spec_pitch),
                                             current_stream_ptr() if stream is None else stream))
+
+    def cgmm_estimate_batch(self, C, audio_ptrs, num_samples, num_iters, init_ptrs, out_ptrs,
+                            stream=None, update_alpha=False):
+        """audio in, masks out: STFT straight into the bin-major layout + bin-resident EM.
+        Raises SetkUnsupported when a bin of the longest utterance does not fit a CU."""
+        n = len(audio_ptrs)
+        A = (c_void_p * n)(*audio_ptrs)
+        O = (c_void_p * n)(*out_ptrs)
+        I = (c_void_p * n)(*init_ptrs) if init_ptrs is not None else None
+        NS = (c_int * n)(*[int(v) for v in num_samples])
+        self.check(
+            self._lib.setk_cgmm_estimate_batch(self._h, n, int(C), A, NS, int(num_iters), I, O,
+                                               CGMM_UPDATE_ALPHA if update_alpha else 0,
+                                               current_stream_ptr() if stream is None else stream))
 
     # -- fused hot path ---------------------------------------------------------
     def enhance_batch(self, opts, num_channels, audio_ptrs, num_samples, mask_ptrs,

@@ -1032,13 +1032,16 @@ bool cgmm_use_bin(int C, int max_frames) {
 }
 
 // spec / init / mask / gamma: device pointers per utterance (gamma entries may be null)
+// spec == NULL: `audio` / `num_samples` are given instead and the spectrograms are computed
+// straight into the bin-major layout (stft_binmajor_kernel, n_fft = 512 plan)
 int run_cgmm_bin(setk_handle_t h, int C, int n_utts, const float* const* spec, const int* frames,
                  int F, int num_iters, const float* const* init, float* const* mask,
-                 float* const* gamma, int flags, int spec_pitch, hipStream_t s) {
+                 float* const* gamma, int flags, int spec_pitch, hipStream_t s,
+                 const float* const* audio = nullptr, const int* num_samples = nullptr) {
     const size_t ab = cgmm_bin_args_bytes();
     std::vector<char> tbl((size_t)n_utts * ab);
     std::vector<const float*> sp(n_utts);
-    std::vector<float*> mp(n_utts), gp(n_utts);
+    std::vector<float*> mp(n_utts), gp(n_utts), xbs;
     int max_frames = 0;
     const int nout = gamma ? 2 : 1;
     // diagnostic: SETK_CGMM_TIMING=<file> dumps the per-bin cycle counters of utterance 0
@@ -1056,15 +1059,46 @@ int run_cgmm_bin(setk_handle_t h, int C, int n_utts, const float* const* spec, c
         if (!xb || !gb) return fail(h, SETK_ERR_NOMEM, "arena");
         cgmm_bin_fill_args(tbl.data() + (size_t)u * ab, xb, init ? init[u] : nullptr, gb, T, F,
                            (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0, nout, u == 0 ? d_timing : nullptr);
-        sp[u] = spec[u];
+        sp[u] = spec ? spec[u] : nullptr;
+        xbs.push_back(xb);
         mp[u] = mask[u];
         gp[u] = gamma ? gamma[u] : nullptr;
     }
-    void *d_tbl, *d_sp, *d_mp, *d_gp = nullptr;
+    void *d_tbl, *d_sp = nullptr, *d_mp, *d_gp = nullptr;
     int rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
     if (rc) return rc;
-    rc = upload(h, sp.data(), sp.size() * sizeof(void*), s, &d_sp);
-    if (rc) return rc;
+    if (spec) {
+        rc = upload(h, sp.data(), sp.size() * sizeof(void*), s, &d_sp);
+        if (rc) return rc;
+    } else {
+        // STFT of every utterance into its bin-major array: 64-frame blocks
+        std::vector<UttDesc> uds(n_utts);
+        std::vector<WorkItem> items;
+        for (int u = 0; u < n_utts; ++u) {
+            UttDesc& ud = uds[u];
+            memset(&ud, 0, sizeof(ud));
+            ud.audio = audio[u];
+            ud.num_samples = num_samples[u];
+            ud.num_frames = frames[u];
+            ud.wave_out = xbs[u];
+            for (int t0 = 0; t0 < frames[u]; t0 += 64)
+                items.push_back({u, t0, std::min(t0 + 64, frames[u]), 0, t0 + 64 >= frames[u]});
+        }
+        void *d_ud, *d_items;
+        rc = upload(h, uds.data(), uds.size() * sizeof(UttDesc), s, &d_ud);
+        if (rc) return rc;
+        rc = upload(h, items.data(), items.size() * sizeof(WorkItem), s, &d_items);
+        if (rc) return rc;
+        Pass1Args a;
+        memset(&a, 0, sizeof(a));
+        a.utts = static_cast<const UttDesc*>(d_ud);
+        a.items = static_cast<const WorkItem*>(d_items);
+        a.window = h->d_window;
+        a.tw256 = h->d_tw256;
+        a.tw512 = h->d_tw512;
+        a.g = geom_of(h);
+        HIP_TRY(h, launch_stft_binmajor(C, a, (int)items.size(), s));
+    }
     rc = upload(h, mp.data(), mp.size() * sizeof(void*), s, &d_mp);
     if (rc) return rc;
     if (gamma) {
@@ -1134,6 +1168,38 @@ int setk_cgmm_masks_batch(setk_handle_t h, int n_utts, int num_channels,
     if (rc) return rc;
     HIP_TRY(h, launch_cgmm_batch(C, d_tbl, n_utts, F, max_frames, num_iters, s));
     return SETK_OK;
+}
+
+int setk_cgmm_estimate_batch(setk_handle_t h, int n_utts, int num_channels,
+                             const float* const* audio, const int* num_samples, int num_iters,
+                             const float* const* init_mask, float* const* mask_out, int flags,
+                             void* stream) {
+    if (!h || n_utts <= 0 || !audio || !num_samples || !mask_out || num_iters < 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    int rc = require_plan512(h);
+    if (rc) return rc;
+    const int C = num_channels;
+    if (C < 1 || C > kMaxChannels) return fail(h, SETK_ERR_UNSUPPORTED, "1 <= num_channels <= 8");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h, s);
+    std::vector<int> frames(n_utts);
+    int max_frames = 0;
+    for (int u = 0; u < n_utts; ++u) {
+        if (!audio[u] || !mask_out[u]) return fail(h, SETK_ERR_INVALID, "null utterance pointer");
+        if (!is_device_ptr(audio[u]) || !is_device_ptr(mask_out[u]) ||
+            (init_mask && init_mask[u] && !is_device_ptr(init_mask[u])))
+            return fail(h, SETK_ERR_INVALID, "setk_cgmm_estimate_batch takes device pointers");
+        frames[u] = setk_stft_num_frames(h, num_samples[u]);
+        if (frames[u] < 0) return frames[u];
+        max_frames = std::max(max_frames, frames[u]);
+    }
+    if (!cgmm_use_bin(C, max_frames))
+        return fail(h, SETK_ERR_UNSUPPORTED,
+                    "one bin of the longest utterance does not fit a CU: use setk_stft_batch + "
+                    "setk_cgmm_masks_batch (streaming kernels)");
+    return run_cgmm_bin(h, C, n_utts, nullptr, frames.data(), kBins, num_iters, init_mask, mask_out,
+                        nullptr, flags, 0, s, audio, num_samples);
 }
 
 int setk_directional_feats(setk_handle_t h, const float* spec, const float* steer_vector,

@@ -1010,7 +1010,7 @@ hipError_t launch_cgmm_bin(int C, const void* d_tbl, const float* const* d_spec_
     const CgmmBinArgs* t = static_cast<const CgmmBinArgs*>(d_tbl);
     const int cfg = cgmm_bin_config(C, max_frames);
     if (cfg < 0) return hipErrorInvalidValue;
-    {
+    if (d_spec_ptrs) {  // null: the bin-major arrays were filled by stft_binmajor_kernel
         const int ntt = (max_frames + 31) / 32;
         dim3 g(ntt * C, (F + 31) / 32, n_utts);
         hipLaunchKernelGGL(spec_to_binmajor_kernel, g, dim3(256), 0, s,

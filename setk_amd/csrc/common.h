@@ -125,6 +125,9 @@ struct ScaleArgs {
 
 // launchers (implemented in the kernel TUs)
 hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s);
+// STFT of whole utterances into the bin-major [F][C][Tp] layout of cgmm_bin.hip
+// (items: 64-frame blocks; UttDesc::wave_out = the utterance's output)
+hipError_t launch_stft_binmajor(int C, const Pass1Args& a, int n_items, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs& a, int n_utts, hipStream_t s);
 hipError_t launch_solve(const SolveArgs& a, hipStream_t s);
 hipError_t launch_pmwf_select(const SolveArgs& a, int* ref_out, hipStream_t s);

@@ -372,6 +372,77 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
     }
 }
 
+// ---- STFT straight into the bin-major layout of the bin-resident CGMM (cgmm_bin.hip) ----
+// out[f][c][t] (frames contiguous, pitch Tp = (T + 3) & ~3) per utterance, no [C][T][F]
+// intermediate and no transpose pass.  A 1024-thread workgroup owns 64 consecutive frames
+// of one utterance and walks the channels: its 64 quad-rows transform the 64 frames of
+// channel c into 64 LDS slots (the spectrum ends up as slot[bin]); then every wave writes
+// rows of 64 frames = 512 contiguous bytes per (bin, channel): lane = frame, the slot
+// stride is odd (273 entries) so that the 64 lanes of a ds_read_b64 hit distinct banks.
+constexpr int kBmFrames = 64;
+constexpr int kBmSlot = slot_entries(17) + 1;
+
+__global__ __launch_bounds__(1024, 4) void stft_binmajor_kernel(Pass1Args a, int C) {
+    constexpr int ROW = 17;
+    constexpr int NT = 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* xt = reinterpret_cast<cf*>(smem);                      // [64][kBmSlot]
+    cf* win_l = xt + kBmFrames * kBmSlot;
+    cf* tw_l = win_l + LaneTab<ROW>::size;
+    cf* tw5_l = tw_l + LaneTab<ROW>::size;
+    float* xn = reinterpret_cast<float*>(win_l + table_entries(ROW));  // [64] bin 256 (real)
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int la = tid & 15, grp = tid >> 4;
+    const WorkItem wi = a.items[blockIdx.x];
+    const UttDesc ud = a.utts[wi.utt];
+    const int n_samp = ud.num_samples, T = ud.num_frames;
+    const int Tp = (T + 3) & ~3;
+    cf* out = reinterpret_cast<cf*>(ud.wave_out);
+    fill_lane_tables<ROW>(win_l, tw_l, tw5_l, a.window, a.tw256, a.tw512, tid, NT);
+    const cf* win_row = win_l + la * LaneTab<ROW>::lstride;
+    const cf* tw_row = tw_l + la * LaneTab<ROW>::lstride;
+    const cf* tw5_row = tw5_l + la * LaneTab<ROW>::lstride5;
+    cf* slot = xt + grp * kBmSlot;
+    const int t = wi.t0 + grp;
+    const bool valid = t < wi.t1;
+    const int tw = wi.t0 + lane;            // frame this lane writes
+    const bool wvalid = tw < wi.t1;
+
+    const int s0 = t * a.g.hop - a.g.pad;
+    __syncthreads();  // tables ready
+    // (a prefetch of the next channel's frame across the write-out keeps 32 registers live
+    // over the loop edge and spills ~60 at the 128-VGPR budget of a 1024-thread workgroup;
+    // the loads are issued at the top of each channel step instead)
+    for (int c = 0; c < C; ++c) {
+        cf v[16];
+        load_raw(v, gptr(ud.audio) + (size_t)c * n_samp, n_samp, s0, la, valid);
+        apply_window<ROW>(v, win_row);
+        fft256_stage_a_pad<-1, ROW>(v, slot, tw_row, la);
+        __builtin_amdgcn_wave_barrier();
+        qr_stage23<ROW>(slot, xn + grp, tw5_row, la);
+        __syncthreads();
+        if (wvalid) {
+            for (int f = wave; f < kBins; f += NT / 64) {
+                const cf val = (f < 256) ? xt[lane * kBmSlot + f] : make_float2(xn[lane], 0.f);
+                out[((size_t)f * C + c) * Tp + tw] = val;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_stft_binmajor(int C, const Pass1Args& a, int n_items, hipStream_t s) {
+    const size_t lds = (size_t)kBmFrames * kBmSlot * sizeof(cf) + table_entries(17) * sizeof(cf) +
+                       kBmFrames * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_binmajor_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(stft_binmajor_kernel, dim3(n_items), dim3(1024), lds, s, a, C);
+    return hipGetLastError();
+}
+
 template <int C, bool DUMP>
 static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s) {
     constexpr int NF = pass1_tile_frames(C) * C;

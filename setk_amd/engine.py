@@ -414,6 +414,8 @@ class CgmmEstimator(object):
                          window=stft_window(window, frame_len))
         self.num_bins = n_fft // 2 + 1
         self.num_iters = num_iters
+        import os
+        self.force_streaming = os.environ.get("SETK_CGMM_STREAMING", "") not in ("", "0")
 
     def _plan(self):
         s = self.stft
@@ -425,6 +427,24 @@ class CgmmEstimator(object):
         torch, ctx, dev, F = self.torch, self.ctx, self.dev, self.num_bins
         self._plan()
         C = audio[0].shape[0]
+        if self.stft["n_fft"] == 512 and C <= 8 and not self.force_streaming:
+            # audio -> masks in one call: the spectrograms are written in the layout the
+            # bin-resident EM reads (no [C][T][F] intermediate, no transpose pass)
+            masks = [torch.empty((ctx.num_frames(a.shape[1]), F), dtype=torch.float32, device=dev)
+                     for a in audio]
+            init = None
+            if init_masks is not None:
+                init = [0 if m is None else m.data_ptr() for m in init_masks]
+            try:
+                ctx.cgmm_estimate_batch(C, [a.data_ptr() for a in audio],
+                                        [a.shape[1] for a in audio], self.num_iters, init,
+                                        [t.data_ptr() for t in masks],
+                                        update_alpha=self.update_alpha)
+                # no host synchronisation: the scratch lives in the handle's arena, whose
+                # reuse by the next call is ordered on the stream
+                return masks
+            except _ffi.SetkUnsupported:
+                pass  # a bin of the longest utterance does not fit a CU: streaming kernels
         specs, masks, frames = [], [], []
         # rows padded to 128 bytes: the EM kernels stream 32-bin (256-byte) segments per
         # wavefront and a 2056-byte row pitch makes every segment straddle an extra line
