@@ -377,8 +377,9 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
 // intermediate and no transpose pass.  A 1024-thread workgroup owns 64 consecutive frames
 // of one utterance and walks the channels: its 64 quad-rows transform the 64 frames of
 // channel c into 64 LDS slots (the spectrum ends up as slot[bin]); then every wave writes
-// rows of 64 frames = 512 contiguous bytes per (bin, channel): lane = frame, the slot
-// stride is odd (273 entries) so that the 64 lanes of a ds_read_b64 hit distinct banks.
+// rows of 64 frames = 512 contiguous bytes per (bin, channel) with 16-byte stores (a lane
+// carries two consecutive frames, a wave two bins); the slot stride is odd (273 entries),
+// which spreads the strided LDS reads of a bin column over the banks.
 constexpr int kBmFrames = 64;
 constexpr int kBmSlot = slot_entries(17) + 1;
 
@@ -407,8 +408,6 @@ __global__ __launch_bounds__(1024, 4) void stft_binmajor_kernel(Pass1Args a, int
     cf* slot = xt + grp * kBmSlot;
     const int t = wi.t0 + grp;
     const bool valid = t < wi.t1;
-    const int tw = wi.t0 + lane;            // frame this lane writes
-    const bool wvalid = tw < wi.t1;
 
     const int s0 = t * a.g.hop - a.g.pad;
     __syncthreads();  // tables ready
@@ -423,10 +422,24 @@ __global__ __launch_bounds__(1024, 4) void stft_binmajor_kernel(Pass1Args a, int
         __builtin_amdgcn_wave_barrier();
         qr_stage23<ROW>(slot, xn + grp, tw5_row, la);
         __syncthreads();
-        if (wvalid) {
-            for (int f = wave; f < kBins; f += NT / 64) {
-                const cf val = (f < 256) ? xt[lane * kBmSlot + f] : make_float2(xn[lane], 0.f);
-                out[((size_t)f * C + c) * Tp + tw] = val;
+        // 16-byte stores: a lane writes two consecutive frames of one bin, a wave two bins
+        {
+            const int fr = 2 * (lane & 31), half = lane >> 5;
+            const int t2 = wi.t0 + fr;
+            for (int f = 2 * wave + half; f < kBins; f += 2 * (NT / 64)) {
+                cf v0, v1;
+                if (f < 256) {
+                    v0 = xt[fr * kBmSlot + f];
+                    v1 = xt[(fr + 1) * kBmSlot + f];
+                } else {
+                    v0 = make_float2(xn[fr], 0.f);
+                    v1 = make_float2(xn[fr + 1], 0.f);
+                }
+                cf* dst = out + ((size_t)f * C + c) * Tp + t2;
+                if (t2 + 1 < wi.t1)  // Tp and the block start are even: 16-byte aligned
+                    *reinterpret_cast<float4*>(dst) = make_float4(v0.x, v0.y, v1.x, v1.y);
+                else if (t2 < wi.t1)
+                    *dst = v0;
             }
         }
         __syncthreads();

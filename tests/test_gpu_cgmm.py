@@ -197,3 +197,33 @@ def test_cfg4_bench_shape_batched_masks_and_raw_mask_mvdr():
                      same=max(worst["same"], es), e2e=max(worst["e2e"], ee))
     print(f"[cfg4 30 s x {n}] worst: {worst}")
     ctx.close()
+
+
+def test_streaming_kernels_remain_the_fallback(tmp_path):
+    """Utterances whose bins do not fit a CU (beyond ~4000 frames at 6 channels) go through
+    the streaming kernels of cgmm.hip; SETK_CGMM_STREAMING=1 forces them.  Both paths must
+    agree with the oracle, and with each other to float32 resolution."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import np_oracle as o
+from setk_amd.libs.cluster import CgmmTrainer
+from setk_amd.engine import CgmmEstimator
+mix = o.synth_scene(77, 5, 30000)
+obs = o.multichannel_stft(mix, transpose=False, frame_len=512, frame_hop=256, window="hann", center=True)
+ref = o.cgmm_masks(obs, 8)
+m1 = CgmmTrainer(obs, 2).train(8)[0].T
+m2 = CgmmEstimator(num_iters=8).estimate([mix])[0]
+print(float(np.mean(np.abs(m1 - ref))), float(np.mean(np.abs(m2 - ref))))
+np.save(sys.argv[2], m2)
+'''
+    outs = {}
+    for mode in ("0", "1"):
+        path = str(tmp_path / f"m{mode}.npy")
+        r = subprocess.run([sys.executable, "-c", code, ROOT, path], capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, SETK_CGMM_STREAMING=mode))
+        assert r.returncode == 0, r.stderr[-2000:]
+        e1, e2 = (float(v) for v in r.stdout.strip().splitlines()[-1].split())
+        assert e1 < 2e-4 and e2 < 2e-4, (mode, e1, e2)
+        outs[mode] = np.load(path)
+    assert np.mean(np.abs(outs["0"] - outs["1"])) < 1e-4
