@@ -938,7 +938,11 @@ hipError_t launch_cfg(const CgmmBinArgs* d_tbl, int n_utts, int F, int max_frame
     const int tlp = lds_frames(max_frames, c.nt, c.rf);
     const size_t lds = bin_lds_bytes<C, c.nt>(tlp);
     if (lds > kLdsLimit) return hipErrorInvalidValue;
-    auto kern = cgmm_bin_em_kernel<C, c.nt, c.u, c.rf, c.wps>;
+    // 7 and 8 channels carry 2 x 49 / 2 x 64 + 2 accumulators per half pass: at the 128-VGPR
+    // budget they spill ~100 registers (8 ch: 87 ms per 125 x 30 s against 61 ms for the
+    // streaming kernels); at 256 VGPRs (one 512-thread workgroup per CU) they do not
+    constexpr int wps = (C >= 7 && c.wps > 2) ? 2 : c.wps;
+    auto kern = cgmm_bin_em_kernel<C, c.nt, c.u, c.rf, wps>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -227,3 +227,16 @@ np.save(sys.argv[2], m2)
         assert e1 < 2e-4 and e2 < 2e-4, (mode, e1, e2)
         outs[mode] = np.load(path)
     assert np.mean(np.abs(outs["0"] - outs["1"])) < 1e-4
+
+
+@pytest.mark.parametrize("C,seconds,iters", [(4, 60.0, 6), (3, 20.0, 5), (7, 12.0, 4)])
+def test_bin_resident_configurations(C, seconds, iters):
+    """The other frame-count classes of the bin-resident EM: 60 s (3751 frames: 512 threads x
+    8 frames, two of them in registers), 20 s (1251: 512 x 4), 12 s (751: 256 x 4)."""
+    from setk_amd.engine import CgmmEstimator
+    N = int(seconds * 16000)
+    mix = o.synth_scene(700 + C, C, N)
+    (mask,) = CgmmEstimator(num_iters=iters).estimate([mix])
+    ref = o.cgmm_masks(o.multichannel_stft(mix, transpose=False, **STFT_KW), iters)
+    rep = _mask_report(f"{C}-ch {seconds:g} s", mask, ref)
+    assert rep["mean"] < 1e-4 and rep["max_decided"] < 1e-3, rep
