@@ -13,7 +13,7 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-B="--steps 5 --warmup 1 --cpu-sample 0 --e2e-utts 0 --full-batch 0 --sustain-sec 0 --other-configs 0"
+B="--steps 5 --warmup 1 --cpu-sample 0 --e2e-utts 0 --full-batch 0 --sustain-sec 0 --other-configs 0 --pmc 0"
 run() {  # name, command...
   local name=$1; shift
   mkdir -p "$OUT/$name"

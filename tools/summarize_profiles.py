@@ -36,7 +36,7 @@ def counters(path):
 
 
 def short(name):
-    name = name.replace("void ", "").replace("setk::", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("setk::", "")
     return name.split("(")[0]
 
 
