@@ -451,7 +451,9 @@ class StreamPipeline(object):
         buf = slot.staging()
         view = buf[off:off + payload.nbytes]
         payload.load_into(view)
-        if self.h2d == "payload":
+        if self.h2d == "payload" or self.zero_copy:
+            # (with --zero-copy the slab holds only the payloads that could not be mapped:
+            # they are copied one by one, there is no whole-slab copy)
             ctx.memcpy_h2d_async(dst, view.ctypes.data, payload.nbytes, stream)
         return False
 
