@@ -812,6 +812,13 @@ __global__ __launch_bounds__(NT, WPS) void cgmm_bin_em_kernel(const CgmmBinArgs*
     for (int pass = 0; pass < npass; ++pass) {
         const int mode = pass == 0 ? (a.init_mask ? kModeInitMask : kModeInitId)
                                    : (pass == npass - 1 ? kModeFinal : kModeEm);
+        // the register-resident frames are constant over the passes: without this the compiler
+        // hoists their 21 + 15 outer products per frame out of the pass loop and keeps them in
+        // registers for the whole kernel (RF = 4: 165 spilled registers, RF = 0: none)
+#pragma unroll
+        for (int u = 0; u < RF; ++u)
+#pragma unroll
+            for (int c = 0; c < C; ++c) asm volatile("" : "+v"(xr[u][c].x), "+v"(xr[u][c].y));
         const long long tc0 = a.timing ? (long long)__builtin_readcyclecounter() : 0;
         if (mode == kModeEm)
             frames_pass<C, NT, U, RF, kModeEm>(sm, tid, T, xr, Xs, Tlp, a, f);
@@ -913,13 +920,19 @@ struct BinCfg {
 // frames per thread U, of which RF in registers; WPS = waves per SIMD the register budget
 // is cut for (4: 128 VGPRs, 3: 168)
 constexpr BinCfg kCfgs[] = {
+    {128, 5, 2, 4},   // T <=  640 (10 s): two waves per bin, eight workgroups per CU (500 x 6-ch x
+                      // 10 s: 29.5 ms against 33.1 for 256 x 4; {128, 8, 3, 3} for <= 1024 frames
+                      // loses to 256 x 4: 27.4 against 24.1 ms at 300 x 15 s)
     {256, 2, 1, 4},   // T <=  512
     {256, 4, 2, 4},   // T <= 1024
+    {256, 8, 4, 3},   // T <= 2048, THREE workgroups per CU (6 ch x 30 s: 16.9 ms per 125
+                      // utterances against 21.0 for the next line: half the wave sums per bin
+                      // and two other workgroups to hide a solve behind)
     {512, 4, 1, 4},   // T <= 2048, two workgroups per CU
-    {256, 8, 4, 3},   // T <= 2048, three workgroups per CU (spills at 168 VGPRs: 1.9 x slower;
-                      // six-wave workgroups {384, 5, 2, 3} only get one workgroup per CU placed)
     {512, 8, 2, 4},   // T <= 4096
 };
+// (six-wave workgroups {384, 5, 2, 3} only get one workgroup per CU placed; four
+// workgroups of 256 threads need RF = 5 at 128 VGPRs: 120 spilled registers)
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr size_t kLdsLimit = 160 * 1024;
 
@@ -938,10 +951,10 @@ hipError_t launch_cfg(const CgmmBinArgs* d_tbl, int n_utts, int F, int max_frame
     const int tlp = lds_frames(max_frames, c.nt, c.rf);
     const size_t lds = bin_lds_bytes<C, c.nt>(tlp);
     if (lds > kLdsLimit) return hipErrorInvalidValue;
-    // 7 and 8 channels carry 2 x 49 / 2 x 64 + 2 accumulators per half pass: at the 128-VGPR
-    // budget they spill ~100 registers (8 ch: 87 ms per 125 x 30 s against 61 ms for the
-    // streaming kernels); at 256 VGPRs (one 512-thread workgroup per CU) they do not
-    constexpr int wps = (C >= 7 && c.wps > 2) ? 2 : c.wps;
+    // 7 and 8 channels carry 2 x 49 / 2 x 64 + 2 accumulators per half pass and 98 / 128
+    // SGPR-bound factor entries: they need 140 - 240 VGPRs (8 ch at the 128-VGPR budget:
+    // 87 ms per 125 x 30 s against 61 ms for the streaming kernels, 45 ms without spills)
+    constexpr int wps = C < 7 ? c.wps : ((c.nt <= 256 && c.u <= 5) ? 3 : 2);
     auto kern = cgmm_bin_em_kernel<C, c.nt, c.u, c.rf, wps>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -963,6 +976,7 @@ hipError_t launch_bin_c(const CgmmBinArgs* d_tbl, int n_utts, int F, int max_fra
         case 2: return launch_cfg<C, 2>(d_tbl, n_utts, F, max_frames, num_iters, s);
         case 3: return launch_cfg<C, 3>(d_tbl, n_utts, F, max_frames, num_iters, s);
         case 4: return launch_cfg<C, 4>(d_tbl, n_utts, F, max_frames, num_iters, s);
+        case 5: return launch_cfg<C, 5>(d_tbl, n_utts, F, max_frames, num_iters, s);
     }
     return hipErrorInvalidValue;
 }
@@ -971,7 +985,9 @@ template <int C>
 bool cfg_fits(int cfg, int max_frames) {
     const BinCfg c = kCfgs[cfg];
     const int tlp = lds_frames(max_frames, c.nt, c.rf);
-    return (c.nt == 256 ? bin_lds_bytes<C, 256>(tlp) : bin_lds_bytes<C, 512>(tlp)) <= kLdsLimit;
+    return (c.nt == 128 ? bin_lds_bytes<C, 128>(tlp)
+                        : (c.nt == 256 ? bin_lds_bytes<C, 256>(tlp) : bin_lds_bytes<C, 512>(tlp))) <=
+           kLdsLimit;
 }
 
 bool cfg_fits_c(int C, int cfg, int max_frames) {
