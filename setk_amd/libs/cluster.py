@@ -5,9 +5,12 @@ K = 2 classes, alpha fixed at 1/2 or re-estimated (update_alpha), deterministic
 start or an initial mask.
 The EM iterations run in libsetk_hip.so (setk_cgmm_masks, csrc/cgmm.hip).
 
-Not mirrored (out of this path's scope): K > 2 (random initialisation
-from numpy's unseeded global generator: not reproducible in the reference
-either), the permutation aligner that only matters for K > 2, CACGMM.
+permu_aligner (:48-91, --solve-permu) is host post-processing of the K x T x F
+posteriors, as in the reference: a per-bin assignment of classes to the running
+centroids of overlapping bands (a few milliseconds of numpy per utterance).
+
+Not mirrored (out of this path's scope): K > 2 (the device EM keeps two
+classes' accumulators in registers), CACGMM.
 """
 import numpy as np
 
@@ -16,7 +19,7 @@ from .utils import EPSILON, get_logger
 
 logger = get_logger(__name__)
 
-__all__ = ["CgmmTrainer"]
+__all__ = ["CgmmTrainer", "permu_aligner"]
 
 
 class CgmmTrainer(object):
@@ -49,3 +52,51 @@ class CgmmTrainer(object):
                                           update_alpha=self.update_alpha)
         self.gamma = np.transpose(gamma, (0, 2, 1)).astype(np.float64)
         return self.gamma
+
+
+# bands of the aligner: (sweeps, first bin, last bin + 1), reference cluster.py:28-36
+_ALIGN_PLAN = {
+    257: ((20, 70, 170), (2, 90, 190), (2, 50, 150), (2, 110, 210), (2, 30, 130), (2, 130, 230),
+          (2, 0, 110), (2, 150, 257)),
+    513: ((20, 100, 200), (2, 120, 220), (2, 80, 180), (2, 140, 240), (2, 60, 160),
+          (2, 160, 260), (2, 40, 140), (2, 180, 280), (2, 0, 120), (2, 200, 300), (2, 220, 320),
+          (2, 240, 340), (2, 260, 360), (2, 280, 380), (2, 300, 400), (2, 320, 420),
+          (2, 340, 440), (2, 360, 460), (2, 380, 480), (2, 400, 513)),
+}
+
+
+def _unit(mat, axis):
+    return mat / np.maximum(np.linalg.norm(mat, axis=axis, keepdims=True), EPSILON)
+
+
+def permu_aligner(masks, transpose=False):
+    """Class permutation alignment over frequency (reference :48-91): masks K x T x F
+    (K x F x T with transpose) -> aligned K x T x F.  Within each band of the plan the
+    classes of a bin are re-assigned to the band's mean time profiles (cosine score,
+    optimal assignment) until a sweep changes nothing."""
+    from scipy.optimize import linear_sum_assignment
+    masks = np.asarray(masks)
+    if masks.ndim != 3:
+        raise RuntimeError("Expect 3D TF-masks, K x T x F or K x F x T")
+    if transpose:
+        masks = np.transpose(masks, (0, 2, 1))
+    K, _, F = masks.shape
+    if F not in _ALIGN_PLAN:
+        raise ValueError(f"Unsupported num_bins: {F}")
+    profile = _unit(masks, 1)                       # unit time profiles, K x T x F
+    owner = np.repeat(np.arange(K)[:, None], F, 1)  # class now sitting in slot k of bin f
+    identity = np.arange(K)
+    for sweeps, lo, hi in _ALIGN_PLAN[F]:
+        for _ in range(sweeps):
+            centroid = _unit(profile[..., lo:hi].mean(-1), -1)
+            moved = False
+            for f in range(lo, hi):
+                score = centroid @ _unit(profile[..., f], -1).T
+                _, pick = linear_sum_assignment(score, maximize=True)
+                if np.any(pick != identity):
+                    profile[..., f] = profile[pick, :, f]
+                    owner[:, f] = owner[pick, f]
+                    moved = True
+            if not moved:
+                break
+    return np.take_along_axis(masks, owner[:, None, :], axis=0)

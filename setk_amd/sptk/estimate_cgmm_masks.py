@@ -4,8 +4,9 @@ Speech / noise mask estimation with the CGMM model on the MI355X.
 
 Drop-in for funcwj/setk ``scripts/sptk/estimate_cgmm_masks.py`` (same
 positional arguments, options, defaults, outputs {dst_dir}/{key}.npy float32
-T x F, skip-if-exists behaviour :38).  --num-classes other than 2,
---solve-permu and --update-alpha are outside the implemented path.
+T x F, skip-if-exists behaviour :38).  --num-classes other than 2 is outside the
+implemented path; --solve-permu aligns the two classes over frequency on the host
+(libs/cluster.permu_aligner) and takes the one-utterance-at-a-time path.
 """
 import argparse
 from pathlib import Path
@@ -15,7 +16,7 @@ import numpy as np
 from setk_amd import _ffi
 from setk_amd.dist import Shard
 from setk_amd.engine import CgmmEstimator
-from setk_amd.libs.cluster import CgmmTrainer
+from setk_amd.libs.cluster import CgmmTrainer, permu_aligner
 from setk_amd.libs.data_handler import NumpyReader, NumpyWriter, ScriptReader, SpectrogramReader
 from setk_amd.libs.opts import StftParser, strtobool
 from setk_amd.libs.utils import get_logger
@@ -50,17 +51,12 @@ def run(args):
     if args.num_classes != 2:
         raise _ffi.SetkUnsupported("only --num-classes 2 (the reference draws the K > 2 start "
                                    "from numpy's unseeded generator)")
-    # --solve-permu: with two classes and the deterministic start the aligner has
-    # nothing to permute between bins of the speech / noise pair the trainer keeps apart;
-    # the reference's aligner supports num_bins in its plan table only (cluster.py:40-91)
-    if args.solve_permu:
-        raise _ffi.SetkUnsupported("--solve-permu is not implemented")
     stft_kwargs = dict(frame_len=args.frame_len, frame_hop=args.frame_hop,
                        round_power_of_two=args.round_power_of_two, window=args.window,
                        center=args.center, transpose=False)
     shard = Shard()
     n_fft = 2**int(np.ceil(np.log2(args.frame_len))) if args.round_power_of_two else args.frame_len
-    if n_fft == 512 and not args.init_mask:
+    if n_fft == 512 and not args.init_mask and not args.solve_permu:
         return run_batched(args, shard)
     reader = SpectrogramReader(args.wav_scp, **stft_kwargs)
     MaskReader = {"numpy": NumpyReader, "kaldi": ScriptReader}
@@ -83,6 +79,9 @@ def run(args):
                                   update_alpha=bool(args.update_alpha))
             masks = np.transpose(trainer.train(args.num_iters), (0, 2, 1))  # K x T x F
             num_done += 1
+            if args.solve_permu:
+                masks = permu_aligner(masks)
+                logger.info("Permutation alignment done on each frequency")
             writer.write(key, masks[0].astype(np.float32))
             logger.info(f"Training utterance {key} ... Done")
     shard.barrier()

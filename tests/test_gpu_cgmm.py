@@ -253,3 +253,26 @@ def test_bin_resident_configurations(C, seconds, iters):
     ref = o.cgmm_masks(o.multichannel_stft(mix, transpose=False, **STFT_KW), iters)
     rep = _mask_report(f"{C}-ch {seconds:g} s", mask, ref)
     assert rep["mean"] < 1e-4 and rep["max_decided"] < 1e-3, rep
+
+
+def test_cli_solve_permu(tmp_path):
+    """estimate_cgmm_masks.py --solve-permu true: the device posteriors of both classes go
+    through the aligner (host, as in the reference)."""
+    import scipy.io.wavfile
+    from setk_amd.libs.cluster import permu_aligner
+    td = str(tmp_path)
+    mix = o.synth_scene(90, 4, 24000)
+    pcm = np.rint(mix.T.astype(np.float64) * 32767).astype(np.int16)
+    scipy.io.wavfile.write(os.path.join(td, "u.wav"), 16000, pcm)
+    with open(os.path.join(td, "wav.scp"), "w") as f:
+        f.write(f"u {td}/u.wav\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts/sptk/estimate_cgmm_masks.py"),
+                        "--num-iters", "6", "--solve-permu", "true", os.path.join(td, "wav.scp"),
+                        os.path.join(td, "mask")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Permutation alignment done on each frequency" in r.stderr
+    mask = np.load(os.path.join(td, "mask", "u.npy"))
+    samps = pcm.astype(np.float32).T / np.float32(32768.0)
+    gamma = o.cgmm_gamma(o.multichannel_stft(samps, transpose=False, **STFT_KW), 6)   # K x F x T
+    want = permu_aligner(np.transpose(gamma, (0, 2, 1)))[0]
+    assert mask.shape == want.shape and np.mean(np.abs(mask - want)) < 2e-4

@@ -519,3 +519,34 @@ def test_parallel_jacobi_model_against_lapack():
                 assert w.min() >= jm.EPS * w.max(), "certificate accepted a floored matrix"
     assert worst < 1e-6, worst
     assert max(cold) <= 8 and np.mean(warm) < np.mean(cold)
+
+
+def test_permu_aligner_realigns_flipped_bins():
+    """libs/cluster.permu_aligner (--solve-permu): bins whose two classes were swapped come
+    back aligned with their neighbours; identical to the unmodified reference where its
+    tree is available (build container)."""
+    from setk_amd.libs.cluster import permu_aligner
+    doc = load_golden("doc_adaptive_beamformer.npz")
+    m = doc["cgmm_mask"].astype(np.float64)          # T x F, the reference's own CGMM mask
+    clean = np.stack([m, 1 - m])
+    rng = np.random.default_rng(0)
+    flip = rng.random(257) < 0.3
+    masks = clean.copy()
+    masks[:, :, flip] = masks[::-1][:, :, flip]
+    out = permu_aligner(masks.copy())
+    assert out.shape == masks.shape
+    # every bin comes back in the clean orientation or (globally consistent) its mirror
+    same = np.all(out == clean, axis=(0, 1))
+    mirrored = np.all(out == clean[::-1], axis=(0, 1))
+    assert np.all(same | mirrored) and (same.mean() > 0.95 or mirrored.mean() > 0.95)
+    with pytest.raises(ValueError):
+        permu_aligner(np.zeros((2, 10, 129)))
+    with pytest.raises(RuntimeError):
+        permu_aligner(np.zeros((10, 257)))
+    from oracle import ref_harness as rh
+    if rh.available():
+        ref = rh.load().cluster.permu_aligner(masks.copy())
+        assert np.array_equal(out, ref)
+        m3 = rng.random((3, 40, 257))
+        m3 /= m3.sum(0, keepdims=True)
+        assert np.array_equal(permu_aligner(m3.copy()), rh.load().cluster.permu_aligner(m3.copy()))
