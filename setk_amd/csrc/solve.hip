@@ -550,9 +550,20 @@ hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
     int lds_mats = 2;
     if (a.kind == SETK_BF_MVDR || a.kind == SETK_BF_MPDR) lds_mats = 1;
     if (a.kind == SETK_BF_PMWF) lds_mats = 4;
+    // 16 channels with all four matrices resident (PMWF) pass the 64 KB a kernel gets
+    // without asking
 #define SETK_LAUNCH(c, k)                                                              \
-    hipLaunchKernelGGL((solve_kernel<c, k>), dim3(blocks), dim3(64),                   \
-                       (size_t)lds_mats * pw * c * c * sizeof(cd) + 64, s, a, pitch, lds_mats)
+    do {                                                                               \
+        const size_t lds = (size_t)lds_mats * pw * c * c * sizeof(cd) + 64;            \
+        if (lds > (64u << 10)) {                                                       \
+            hipError_t e = hipFuncSetAttribute(                                        \
+                reinterpret_cast<const void*>(solve_kernel<c, k>),                     \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+            if (e != hipSuccess) return e;                                             \
+        }                                                                              \
+        hipLaunchKernelGGL((solve_kernel<c, k>), dim3(blocks), dim3(64), lds, s, a,    \
+                           pitch, lds_mats);                                           \
+    } while (0)
 #define SETK_CASE(c)                                                                   \
     case c:                                                                            \
         switch (a.kind) {                                                              \

@@ -1,0 +1,230 @@
+"""Drives every entry point of include/setk_hip.h through the sanitizer build of the host side
+(tools/hoststub/build.sh: AddressSanitizer + UBSan, HIP replaced by a host-memory stand-in
+whose kernel launches only validate their configuration).  Run by tests/test_host_asan.py:
+
+    LD_PRELOAD=<libclang_rt.asan> SETK_LIB=_abl/libsetk_hostasan.so python tests/host_asan_driver.py
+
+Outputs are not looked at (no kernel runs); what is checked is the host code: argument
+validation, descriptor tables, arena sizing, staging copies, launch geometry.  Prints one
+JSON line with the stand-in's counters; an ASAN / UBSan report aborts the process."""
+import ctypes
+import json
+import os
+import sys
+from ctypes import byref, c_char, c_int, c_long, c_size_t, c_void_p
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from setk_amd import _ffi  # noqa: E402
+
+lib = _ffi.load_library()
+assert hasattr(lib, "hoststub_report"), "not the host-stub build: set SETK_LIB"
+lib.hipMalloc.argtypes = [ctypes.POINTER(c_void_p), c_size_t]
+lib.hipFree.argtypes = [c_void_p]
+lib.hipMemcpy.argtypes = [c_void_p, c_void_p, c_size_t, c_int]
+F = 257
+rng = np.random.default_rng(0)
+held = []
+
+
+def dmalloc(nbytes):
+    p = c_void_p()
+    assert lib.hipMalloc(byref(p), max(int(nbytes), 16)) == 0
+    held.append(p.value)
+    return p.value
+
+
+def to_dev(a):
+    a = np.ascontiguousarray(a)
+    p = dmalloc(a.nbytes)
+    assert lib.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0
+    return p
+
+
+def release():
+    while held:
+        assert lib.hipFree(held.pop()) == 0
+
+
+def cplx(*shape):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+
+
+def expect(exc, fn, *a, **k):
+    try:
+        fn(*a, **k)
+    except exc:
+        return
+    raise AssertionError(f"{fn.__name__} did not raise {exc.__name__}")
+
+
+def operators(ctx, C, T):
+    spec = cplx(C, T, F)
+    mask = rng.random((T, F)).astype(np.float32)
+    R = np.empty((F, C, C), np.complex64)
+    ctx.covar(spec, mask, C, T, F, R)
+    Rs = cplx(F, C, C)
+    Rn = cplx(F, C, C)
+    st = np.zeros(F, np.int32)
+    sv = np.empty((F, C), np.complex64)
+    ctx.pevd(Rs, Rn, F, C, 0, sv, st)
+    ctx.pevd(Rs, None, F, C, 0, sv, st)
+    for kind in range(4):
+        opts = _ffi.BfOpts()
+        opts.kind = kind
+        opts.pmwf_ref = -1
+        w = np.empty((F, C), np.complex64)
+        try:
+            ctx.weights(opts, Rs, Rn, Rs, F, C, w, st)
+        except (ValueError, NotImplementedError):
+            pass
+    w = cplx(F, C)
+    ctx.ban(w, Rn, F, C, np.empty((F, C), np.complex64))
+    ctx.rank1(Rs, Rn, F, C, np.empty((F, C, C), np.complex64), st)
+    ctx.beamform(w, spec, C, T, F, np.empty((T, F), np.complex64))
+    if C >= 2:
+        pairs = [(i, j) for i in range(C) for j in range(i + 1, C)]
+        ctx.directional_feats(spec, w, pairs, C, T, F, np.empty((T, F), np.float32))
+    # the same through device pointers
+    d_spec, d_mask, d_R = to_dev(spec), to_dev(mask), dmalloc(R.nbytes)
+    ctx.covar(d_spec, d_mask, C, T, F, d_R)
+    ctx.beamform(to_dev(w), d_spec, C, T, F, dmalloc(T * F * 8))
+    release()
+
+
+def stft_paths(ctx, C):
+    for (fl, hop, nfft, center) in ((512, 256, 512, True), (512, 128, 512, False), (400, 160, 512, True),
+                                    (400, 160, 400, True), (1024, 256, 1024, True)):
+        ctx.stft_plan(fl, hop, nfft, center)
+        N = 5 * fl + 37
+        T = ctx.num_frames(N)
+        nb = nfft // 2 + 1
+        audio = rng.standard_normal((C, N)).astype(np.float32)
+        spec = np.empty((C, T, nb), np.complex64)
+        ctx.stft(audio, spec)
+        ns = ctx.istft_num_samples(T, N)
+        ctx.istft(spec, C, T, N, None, np.empty((C, ns), np.float32))
+        ctx.istft(spec, C, T, N, np.ones(C, np.float32), np.empty((C, ns), np.float32))
+    ctx.stft_plan(512, 256, 512, True)
+    expect(ValueError, ctx.stft, np.zeros((C, 10), np.float32)[:, :0].copy(), np.empty((C, 0, F), np.complex64))
+
+
+def fused(ctx, C, lens, kind):
+    ctx.stft_plan(512, 256, 512, True)
+    n = len(lens)
+    audio = [to_dev(rng.standard_normal((C, N)).astype(np.float32)) for N in lens]
+    frames = [ctx.num_frames(N) for N in lens]
+    masks = [to_dev(rng.random((t, F)).astype(np.float32)) for t in frames]
+    waves = [dmalloc(N * 4) for N in lens]
+    opts = _ffi.BfOpts()
+    opts.kind = kind
+    opts.pmwf_ref = -1
+    try:
+        ctx.enhance_batch(opts, C, audio, lens, masks, None, waves)
+        taps = {"Rs": np.empty((n, F, C, C), np.complex64), "Rn": np.empty((n, F, C, C), np.complex64),
+                "weight": np.empty((n, F, C), np.complex64), "maxabs": np.empty(n, np.float32)}
+        ctx.enhance_batch(opts, C, audio, lens, masks, masks, waves, taps=taps)
+    except NotImplementedError:
+        pass
+    wts = cplx(2, F, C)
+    try:
+        for flags in (0, _ffi.FLAG_NO_RENORM):
+            ctx.apply_weights_batch(C, audio, lens, wts, 2, [u % 2 for u in range(n)], waves, flags=flags)
+        ctx.apply_weights_batch(C, audio, lens, to_dev(wts), 2, None, waves)
+    except NotImplementedError:
+        assert C > 8
+    pcm = [to_dev(rng.integers(-3000, 3000, (N, C)).astype(np.int16)) for N in lens]
+    ctx.pcm16_to_float_batch(C, pcm, lens, audio, power0=dmalloc(4 * n * F * max(frames)))
+    ctx.pcm16_to_float(rng.integers(-9, 9, (lens[0], C)).astype(np.int16), C, lens[0],
+                       np.empty((C, lens[0]), np.float32))
+    specs = [dmalloc(C * t * F * 8) for t in frames]
+    try:
+        ctx.stft_batch(C, audio, lens, specs)
+    except NotImplementedError:
+        assert C > 8
+    release()
+
+
+def cgmm(ctx, C, lens, init, alpha):
+    ctx.stft_plan(512, 256, 512, True)
+    n = len(lens)
+    frames = [ctx.num_frames(N) for N in lens]
+    audio = [to_dev(rng.standard_normal((C, N)).astype(np.float32)) for N in lens]
+    specs = [to_dev(cplx(C, t, F)) for t in frames]
+    inits = [to_dev(rng.random((t, F)).astype(np.float32)) for t in frames] if init else None
+    outs = [dmalloc(t * F * 4) for t in frames]
+    for env in ("", "1"):
+        os.environ["SETK_CGMM_STREAMING"] = env
+        if not env:
+            del os.environ["SETK_CGMM_STREAMING"]
+        ctx.cgmm_masks_batch(C, specs, frames, F, 3, inits, outs, update_alpha=alpha)
+    try:
+        ctx.cgmm_estimate_batch(C, audio, lens, 3, inits, outs, update_alpha=alpha)
+    except NotImplementedError:
+        pass
+    t = frames[0]
+    ctx.cgmm_masks(cplx(C, t, F), C, t, F, 2, None, np.empty((2, t, F), np.float32),
+                   np.empty((t, F), np.float32), update_alpha=alpha)
+    release()
+
+
+def wpe(ctx, C, T, taps, delay):
+    spec = cplx(C, T, F)
+    out = np.empty_like(spec)
+    st = np.zeros(F, np.int32)
+    try:
+        ctx.wpe(spec, C, T, F, taps, delay, 1, 2, out, status=st)
+        ctx.wpe(spec, C, T, F, taps, delay, 0, 1, out, lambda_enh=cplx(T, F),
+                inv_lambda_out=np.empty((F, T), np.float32), status=st)
+        ctx.wpe_step(spec, C, T, F, taps, delay, rng.random((F, T)) + 0.1, out, status=st)
+        ctx.wpe_batch([spec, spec[:, :T // 2].copy()], C, [T, T // 2], F, taps, delay, 1, 2,
+                      [out, np.empty((C, T // 2, F), np.complex64)], status=np.zeros((2, F), np.int32))
+    except NotImplementedError:
+        pass
+
+
+def main():
+    ctx = _ffi.Context(0)
+    if "--selftest-overflow" in sys.argv:
+        # the sanitizer must be live: an output buffer one matrix short -> heap-buffer-overflow
+        ctx.covar(cplx(2, 8, F), np.ones((8, F), np.float32), 2, 8, F, np.empty((F - 1, 2, 2), np.complex64))
+        return 0
+    if "--selftest-device-deref" in sys.argv:
+        # host code touching "device" memory is a report too (the stand-in keeps it poisoned)
+        p = dmalloc(64)
+        return int(ctypes.cast(p, ctypes.POINTER(c_int))[0] == 0) * 0 + int(ctypes.string_at(p, 4) == b"x")
+    ctx.stft_plan(512, 256, 512, True)
+    for C in (1, 2, 3, 4, 6, 8, 12, 16):
+        operators(ctx, C, 40 + C)
+        stft_paths(ctx, min(C, 4))
+    for C, lens, kind in ((8, [480000] * 2, 0), (4, [160000, 1000, 64000, 777], 1), (1, [4096], 0),
+                          (6, [48000, 31999, 52001], 2), (2, [600], 3), (12, [20000, 30000], 0),
+                          (16, [16000], 1), (8, [16000 + 977 * u for u in range(300)], 0)):
+        fused(ctx, C, lens, kind)
+    for C, lens, init, alpha in ((6, [480000, 320000], False, False), (2, [16000, 9000, 48000], True, True),
+                                 (8, [480000], True, False), (4, [160000] * 3, False, True),
+                                 (3, [1200000], False, False), (5, [700], False, False),
+                                 (7, [100000], False, False), (6, [4000000], False, False)):
+        cgmm(ctx, C, lens, init, alpha)
+    for C, T, taps, delay in ((2, 200, 10, 3), (6, 300, 10, 3), (8, 120, 5, 1), (1, 64, 3, 0), (4, 50, 20, 3)):
+        wpe(ctx, C, T, taps, delay)
+    # argument errors must come back as error codes, not crashes
+    expect((ValueError, NotImplementedError), ctx.covar, cplx(2, 4, F), np.ones((4, F), np.float32), 0, 4, F,
+           np.empty((F, 2, 2), np.complex64))
+    expect((ValueError, NotImplementedError), ctx.covar, cplx(2, 4, F), np.ones((4, F), np.float32), 40, 4, F,
+           np.empty((F, 2, 2), np.complex64))
+    expect(ValueError, ctx.stft_plan, 512, 0, 512, True)
+    expect((ValueError, NotImplementedError), ctx.stft_plan, 512, 256, 256, True)
+    ctx.close()
+    vals = [c_long() for _ in range(4)]
+    first = (c_char * 512)()
+    lib.hoststub_report(*[byref(v) for v in vals], first, 512)
+    rec = dict(zip(("launches", "violations", "copies", "live_allocations"), [v.value for v in vals]))
+    rec["first_violation"] = first.value.decode()
+    print(json.dumps(rec))
+    return 1 if rec["violations"] else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
