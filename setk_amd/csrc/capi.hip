@@ -1465,6 +1465,14 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
         HIP_TRY(h, launch_wpe_transpose(us[u].d_spec, C, us[u].T, F, us[u].x_fct, true, s));
     const size_t ab = wpe_args_bytes();
     std::vector<char> tbl((size_t)n_utts * ab);
+    // SETK_WPE_TIMING=<file>: in-kernel cycle counters of the LAST iteration, [n_utts][F][4]
+    // int64 (correlation, factorisation, back substitution, filter)
+    const char* timing_path = getenv("SETK_WPE_TIMING");
+    long long* d_timing = nullptr;
+    if (timing_path && *timing_path) {
+        d_timing = static_cast<long long*>(arena_alloc(h, (size_t)n_utts * F * 4 * sizeof(long long)));
+        if (!d_timing) return fail(h, SETK_ERR_NOMEM, "arena");
+    }
     for (int it = 0; it < num_iters; ++it) {
         for (int u = 0; u < n_utts; ++u) {
             Utt& q = us[u];
@@ -1478,7 +1486,8 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
             else
                 HIP_TRY(h, launch_wpe_lambda(cur, C, q.T, F, context, q.lam, s));
             wpe_fill_args(tbl.data() + (size_t)u * ab, q.x_fct, q.lam, q.bufs[it & 1],
-                          d_st + ((size_t)it * n_utts + u) * F, C, q.T, taps, delay);
+                          d_st + ((size_t)it * n_utts + u) * F, C, q.T, taps, delay,
+                          d_timing ? d_timing + (size_t)u * F * 4 : nullptr);
         }
         void* d_tbl;
         rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
@@ -1514,6 +1523,14 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
     }
     // descriptors and staged buffers live in the arena: drained before the next call reuses it
     HIP_TRY(h, hipStreamSynchronize(s));
+    if (d_timing) {
+        std::vector<long long> tm((size_t)n_utts * F * 4);
+        HIP_TRY(h, hipMemcpy(tm.data(), d_timing, tm.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        if (FILE* fp = fopen(timing_path, "wb")) {
+            fwrite(tm.data(), sizeof(long long), tm.size(), fp);
+            fclose(fp);
+        }
+    }
     return SETK_OK;
 }
 }  // namespace

@@ -13,12 +13,13 @@
 // example (cond(R) ~ 5e10), so correlation, factorisation and filter run in fp64
 // here and only the spectrograms are complex64.
 //
-// One workgroup owns one bin: a 16 x 16 thread grid accumulates [R | r] in
-// registers (thread (ty, tx) holds rows ty + 16 i, columns tx + 16 j) from a
-// chunk of tap vectors staged in LDS, the sums go to LDS, R is Cholesky
-// factored in place (it is Hermitian positive definite; a non-positive pivot
-// reports SETK_NUM_SINGULAR, the reference's LinAlgError), G is solved for by
-// substitution and the filter is applied in a second sweep over the frames.
+// One workgroup owns one bin: a 16 x 16 thread grid accumulates the lower 16 x 16 tiles
+// of R and r in registers (thread (ty, tx) holds rows ty + 16 i, columns tx + 16 j <= i;
+// the kernel is instantiated per tile count) from a chunk of tap vectors staged in LDS, the
+// sums go to LDS, R is Cholesky factored in place with r carried along (it is Hermitian
+// positive definite; an all-zero or non-finite R reports SETK_NUM_SINGULAR, the
+// reference's LinAlgError), the back substitution runs one right-hand side per wavefront
+// and the filter is applied in a second sweep over the frames.
 // Layout: spectrograms [F][N][T] (frames contiguous), lambda [F][T] float64.
 #include <cstdio>
 #include <cstring>
@@ -41,9 +42,7 @@ WD void zfmac(zd& acc, zd a, zd b) {
 }
 
 constexpr int kWpeMaxNK = 96;  // LDS: NK^2 * 16 B <= 147 KB
-constexpr int kWpeTC = 16;     // frames per staged chunk
-constexpr int kWpeRows = 6;    // ceil(96 / 16) rows / thread
-constexpr int kWpeCols = 7;    // ceil((96 + 16) / 16) columns / thread
+constexpr int kWpeTC = 16;     // smallest chunk of frames staged at a time
 
 // [C][T][F] (the library's spectrogram layout) <-> [F][C][T]
 __global__ __launch_bounds__(256) void wpe_to_fct_kernel(const float2* __restrict__ spec, int C,
@@ -132,95 +131,163 @@ struct WpeArgs {
     const double* lam;  // [F][T]
     float2* out;        // [F][N][T]
     int* status;        // [F]
+    long long* timing;  // SETK_WPE_TIMING: [F][4] cycles (correlation, factor, back-solve, filter)
     int N, T, taps, delay;
 };
 
-// one workgroup per (bin, utterance): blockIdx.y indexes the argument table
-__global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict__ tbl) {
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// one workgroup per (bin, utterance): blockIdx.y indexes the argument table.
+//
+// The correlation runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64; same peak as the
+// vector pipe, but one LDS read per 1024 multiply-adds instead of one per 4).  A complex
+// outer product is a real one of the stacked parts: with z[(m, p)] = Re / Im of yt[m],
+//     S[(m, p)][(n, q)] = sum_t z[(m, p)] z[(n, q)] / lambda,
+//     R[m][n] = (S[m0][n0] + S[m1][n1]) + i (S[m1][n0] - S[m0][n1]),
+// so a 16 x 16 real tile is an 8 x 8 block of R (or of r, with x in place of yt on the column
+// side).  Within a tile row i = 4 (2 h + p) + g is (m = 8 I + 4 h + g, part p) and column j is
+// (n = 8 J + j / 2, part j & 1): in the instruction's result layout (lane = j + 16 (i % 4),
+// register = i / 4; tools/ubench/mfma_f64_layout.hip) a lane then holds both parts of its two
+// rows and its neighbour the other column part, one lane swap away.  Only the tiles J <= I of R
+// are computed; the NT = RT (RT + 1) / 2 + RT XT tiles (RT = ceil(NK / 8), XT = ceil(N / 8)) are
+// dealt round-robin to the four wavefronts, NTW = ceil(NT / 4) accumulators each.
+template <int NTW>
+__global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict__ tbl, int TC) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     const WpeArgs a = tbl[blockIdx.y];
     const int N = a.N, T = a.T, taps = a.taps, delay = a.delay;
-    const int NK = N * taps, D = NK + N;
-    zd* R = reinterpret_cast<zd*>(wsm);          // [NK][NK] row major; L in place (lower)
-    zd* G = R + (size_t)NK * NK;                 // [NK][N]  r, then G
-    zd* V = G + (size_t)NK * N;                  // [kWpeTC][D] staged vectors (yt | x)
-    double* ilam = reinterpret_cast<double*>(V + (size_t)kWpeTC * D);  // [kWpeTC]
-    int* flag = reinterpret_cast<int*>(ilam + kWpeTC);
+    const int NK = N * taps;
+    // per chunk of TC frames: the source frames the tap vectors reach, x[n][t0 - delay -
+    // taps + 1 .. t0 + TC - 1 - delay] (W per channel; yt[k N + n][t] is the entry tl + taps - 1
+    // - k of channel n), the chunk's own frames x[n][t0 .. t0 + TC) for r, and a strip of zeros
+    // that the rows / columns past NK (partial tiles) and the channels past N point at
+    const int W = TC + taps - 1;
+    zd* R = reinterpret_cast<zd*>(wsm);          // [NK][NK] row major; L in place (strictly lower)
+    zd* G = R + (size_t)NK * NK;                 // [NK][N]  r, then y, then G
+    zd* XS = G + (size_t)NK * N;                 // [N][W] | [N][TC] | zeros [TC]
+    double* ilam = reinterpret_cast<double*>(XS + (size_t)N * (W + TC) + TC);  // [TC]
+    double* idiag = ilam + TC;                   // [NK] 1 / L[k][k]
+    int* flag = reinterpret_cast<int*>(idiag + NK);
 
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int f = blockIdx.x;
     const float2* xf = a.x + (size_t)f * N * T;
     const double* lf = a.lam + (size_t)f * T;
     if (tid == 0) *flag = 0;
+    long long clk0 = 0;
+    if (a.timing && tid == 0) clk0 = (long long)__builtin_amdgcn_s_memtime();
 
-    // ---- [R | r] = sum_t (yt / lambda) [yt ; x]^H ----
-    zd acc[kWpeRows][kWpeCols];
+    // ---- [R | r] = sum_t (yt / lambda) [yt ; x]^H, lower tiles of R only ----
+    const int lane = tid & 63, wv = tid >> 6;
+    const int RT = (NK + 7) >> 3, XT = (N + 7) >> 3;
+    const int NTR = RT * (RT + 1) / 2, NTT = NTR + RT * XT;
+    const int zoff = N * (W + TC);
+    const double* XSd = reinterpret_cast<const double*>(XS);
+    // operand addresses (in doubles, without the frame): A = row (m, p) of the lane's tile
+    // row, frame lane / 16 of the step; B = column (n, q)
+    const int ai = lane & 15, ag = ai & 3, av = ai >> 2;
+    const int kq = lane >> 4;
+    v4d acc[NTW];
+    int baseA[NTW], baseB[NTW];
 #pragma unroll
-    for (int i = 0; i < kWpeRows; ++i)
-#pragma unroll
-        for (int j = 0; j < kWpeCols; ++j) acc[i][j] = zmk(0.0, 0.0);
-    for (int t0 = 0; t0 < T; t0 += kWpeTC) {
-        __syncthreads();
-        for (int i = tid; i < kWpeTC * D; i += 256) {
-            const int tl = i / D, n = i - tl * D;
-            const int t = t0 + tl;
-            zd v = zmk(0.0, 0.0);
-            if (t < T) {
-                int c, src;
-                if (n < NK) {
-                    const int k = n / N;
-                    c = n - k * N;
-                    src = t - k - delay;
-                } else {
-                    c = n - NK;
-                    src = t;
-                }
-                if (src >= 0) {
-                    const float2 s = xf[(size_t)c * T + src];
-                    v = zmk((double)s.x, (double)s.y);
-                }
-            }
-            V[i] = v;
+    for (int q = 0; q < NTW; ++q) {
+        acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+        const int t = wv + 4 * q;
+        int I = 0, J = 0;
+        bool isx = false;
+        if (t < NTR) {
+            while ((I + 1) * (I + 2) / 2 <= t) ++I;
+            J = t - I * (I + 1) / 2;
+        } else if (t < NTT) {
+            isx = true;
+            I = (t - NTR) / XT;
+            J = (t - NTR) - I * XT;
         }
-        if (tid < kWpeTC) ilam[tid] = (t0 + tid < T) ? 1.0 / lf[t0 + tid] : 0.0;
+        const int m = 8 * I + 4 * (av >> 1) + ag, n = 8 * J + (ai >> 1);
+        int ea = zoff, eb = zoff;
+        if (t < NTT && m < NK) ea = (m % N) * W + taps - 1 - m / N;
+        if (t < NTT && !isx && n < NK) eb = (n % N) * W + taps - 1 - n / N;
+        if (t < NTT && isx && n < N) eb = N * W + n * TC;
+        baseA[q] = 2 * (ea + kq) + (av & 1);
+        baseB[q] = 2 * (eb + kq) + (ai & 1);
+    }
+    for (int i = tid; i < TC; i += 256) XS[zoff + i] = zmk(0.0, 0.0);
+    for (int t0 = 0; t0 < T; t0 += TC) {
         __syncthreads();
-        for (int tl = 0; tl < kWpeTC; ++tl) {
-            const zd* v = V + (size_t)tl * D;
-            const double il = ilam[tl];
-            zd col[kWpeCols];
-#pragma unroll
-            for (int j = 0; j < kWpeCols; ++j) {
-                const int n = tx + 16 * j;
-                col[j] = (n < D) ? v[n] : zmk(0.0, 0.0);
+        for (int i = tid; i < N * (W + TC); i += 256) {
+            int n, src;
+            if (i < N * W) {
+                n = i / W;
+                src = t0 - delay - (taps - 1) + (i - n * W);
+            } else {
+                const int e = i - N * W;
+                n = e / TC;
+                src = t0 + (e - n * TC);
             }
+            zd v = zmk(0.0, 0.0);
+            if (src >= 0 && src < T) {
+                const float2 sv = xf[(size_t)n * T + src];
+                v = zmk((double)sv.x, (double)sv.y);
+            }
+            XS[i] = v;
+        }
+        for (int i = tid; i < TC; i += 256) ilam[i] = (t0 + i < T) ? 1.0 / lf[t0 + i] : 0.0;
+        __syncthreads();
+#pragma unroll 2
+        for (int s4 = 0; s4 < TC; s4 += 4) {
+            const double il = ilam[s4 + kq];
 #pragma unroll
-            for (int i = 0; i < kWpeRows; ++i) {
-                const int m = ty + 16 * i;
-                if (m < NK) {
-                    const zd row = zmk(v[m].x * il, v[m].y * il);
-#pragma unroll
-                    for (int j = 0; j < kWpeCols; ++j) zfmac(acc[i][j], row, col[j]);
-                }
+            for (int q = 0; q < NTW; ++q) {
+                const double av_ = XSd[baseA[q] + 2 * s4] * il;
+                const double bv_ = XSd[baseB[q] + 2 * s4];
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av_, bv_, acc[q], 0, 0, 0);
             }
         }
     }
     __syncthreads();
+    // complex entries out of the real tiles: even lanes hold column part 0, their neighbours
+    // part 1
 #pragma unroll
-    for (int i = 0; i < kWpeRows; ++i)
+    for (int q = 0; q < NTW; ++q) {
+        const int t = wv + 4 * q;
+        double nb[4];
 #pragma unroll
-        for (int j = 0; j < kWpeCols; ++j) {
-            const int m = ty + 16 * i, n = tx + 16 * j;
-            if (m < NK && n < NK) R[(size_t)m * NK + n] = acc[i][j];
-            if (m < NK && n >= NK && n < D) G[(size_t)m * N + (n - NK)] = acc[i][j];
+        for (int v = 0; v < 4; ++v) nb[v] = __shfl_xor(acc[q][v], 1);
+        if (t < NTT && !(lane & 1)) {
+            int I = 0, J = 0;
+            bool isx = false;
+            if (t < NTR) {
+                while ((I + 1) * (I + 2) / 2 <= t) ++I;
+                J = t - I * (I + 1) / 2;
+            } else {
+                isx = true;
+                I = (t - NTR) / XT;
+                J = (t - NTR) - I * XT;
+            }
+            const int n = 8 * J + ((lane & 15) >> 1);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int m = 8 * I + 4 * hh + (lane >> 4);
+                const zd val = zmk(acc[q][2 * hh] + nb[2 * hh + 1], acc[q][2 * hh + 1] - nb[2 * hh]);
+                if (!isx && m < NK && n <= m) R[(size_t)m * NK + n] = val;
+                if (isx && m < NK && n < N) G[(size_t)m * N + n] = val;
+            }
         }
+    }
     __syncthreads();
 
-    // ---- Cholesky R = L L^H (lower triangle in place), right-looking ----
-    // Pivots are floored at eps64 * NK * max diag (as chol_lds in solve.hip does with
-    // eps32): a numerically semi-definite R (fewer frames than N * taps, a duplicated
-    // or silent channel) is factored with noise-level pivots, the way LAPACK's pivoted LU
-    // behind numpy.linalg.solve goes through on such input (libs/wpe.py:76); only an
-    // all-zero or non-finite R is "singular" (LinAlgError).
+    // ---- Cholesky R = L L^H (strictly lower triangle in place, 1 / L[k][k] aside), right-
+    // looking, with r carried along as extra columns: the forward substitution L y = r comes
+    // out of the same sweep ----
+    // Pivots at or below eps64 * NK * max diag count as zero: a numerically semi-definite R
+    // (fewer frames than N * taps, a duplicated or silent channel) is solved in the subspace
+    // it spans -- what is left of such a column after elimination is rounding noise, and
+    // dividing by a floored pivot instead lets that noise grow quadratically from column to
+    // column until it overflows.  LAPACK's pivoted LU behind numpy.linalg.solve
+    // (libs/wpe.py:76) also goes through on such input, with a noise-determined filter; only
+    // an all-zero or non-finite R is "singular" (LinAlgError).
+    long long clk1 = 0;
+    if (a.timing && tid == 0) clk1 = (long long)__builtin_amdgcn_s_memtime();
     double dmax = 0.0;
     for (int k = 0; k < NK; ++k) dmax = fmax(dmax, R[(size_t)k * NK + k].x);
     const double pfloor = dmax * 2.220446049250313e-16 * (double)NK;
@@ -230,21 +297,32 @@ __global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict
             if (tid == 0) *flag = SETK_NUM_SINGULAR;
             break;  // uniform: every thread reads the same pivot
         }
-        dkk = fmax(dkk, pfloor);
-        const double lkk = sqrt(dkk), inv = 1.0 / lkk;
-        __syncthreads();
-        for (int i = k + tid; i < NK; i += 256) {
-            zd v = R[(size_t)i * NK + k];
-            R[(size_t)i * NK + k] = (i == k) ? zmk(lkk, 0.0) : zmk(v.x * inv, v.y * inv);
+        // a pivot at the noise level is a direction R does not span: its column is dropped
+        // (L[.][k] = 0, y[k] = 0, G[k] = 0) instead of being divided by noise
+        const double inv = (dkk > pfloor) ? 1.0 / sqrt(dkk) : 0.0;
+        // column k below the diagonal (the diagonal entry itself stays: others may still be
+        // reading it as their pivot) and row k of r
+        for (int i = k + 1 + tid; i < NK; i += 256) {
+            const zd v = R[(size_t)i * NK + k];
+            R[(size_t)i * NK + k] = zmk(v.x * inv, v.y * inv);
         }
+        if (tid >= 256 - N) {
+            zd& g = G[(size_t)k * N + (255 - tid)];
+            g = zmk(g.x * inv, g.y * inv);
+        }
+        if (tid == 128) idiag[k] = inv;
         __syncthreads();
-        const int rem = NK - k - 1;
-        // trailing update of the lower triangle: R[i][j] -= L[i][k] conj(L[j][k]), j <= i
-        for (int e = tid; e < rem * rem; e += 256) {
-            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-            if (j <= i) {
-                const zd p = zmulcd(R[(size_t)i * NK + k], R[(size_t)j * NK + k]);
+        // trailing update: R[i][j] -= L[i][k] conj(L[j][k]) (k < j <= i), r[i] -= L[i][k] y[k]
+        for (int i = k + 1 + ty; i < NK; i += 16) {
+            const zd li = R[(size_t)i * NK + k];
+            for (int j = k + 1 + tx; j <= i; j += 16) {
+                const zd p = zmulcd(li, R[(size_t)j * NK + k]);
                 R[(size_t)i * NK + j] = zsubd(R[(size_t)i * NK + j], p);
+            }
+            if (tx < N) {
+                const zd y = G[(size_t)k * N + tx];
+                zd& g = G[(size_t)i * N + tx];
+                g = zmk(g.x - (li.x * y.x - li.y * y.y), g.y - (li.x * y.y + li.y * y.x));
             }
         }
         __syncthreads();
@@ -258,69 +336,108 @@ __global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict
         return;
     }
 
-    // ---- L y = r, L^H G = y (N right-hand sides; thread c owns a column) ----
-    for (int k = 0; k < NK; ++k) {
-        if (tid < N) {
-            const double inv = 1.0 / R[(size_t)k * NK + k].x;
-            zd v = G[(size_t)k * N + tid];
-            G[(size_t)k * N + tid] = zmk(v.x * inv, v.y * inv);
+    long long clk2 = 0;
+    if (a.timing && tid == 0) clk2 = (long long)__builtin_amdgcn_s_memtime();
+    // ---- L^H G = y: one wavefront per right-hand side, y in registers (rows lane and
+    // lane + 64), no workgroup barrier inside ----
+    {
+        const int lane = tid & 63, w = tid >> 6;
+        for (int c = w; c < N; c += 4) {
+            zd y0 = (lane < NK) ? G[(size_t)lane * N + c] : zmk(0.0, 0.0);
+            zd y1 = (lane + 64 < NK) ? G[(size_t)(lane + 64) * N + c] : zmk(0.0, 0.0);
+            for (int k = NK - 1; k >= 0; --k) {
+                const zd src = (k >= 64) ? y1 : y0;
+                const double inv = idiag[k];
+                const zd g = zmk(__shfl(src.x, k & 63) * inv, __shfl(src.y, k & 63) * inv);
+                // y[i] -= conj(L[k][i]) g  (i < k);  y[k] = g
+                if (lane < k) {
+                    const zd l = R[(size_t)k * NK + lane];
+                    y0 = zmk(y0.x - (l.x * g.x + l.y * g.y), y0.y - (l.x * g.y - l.y * g.x));
+                } else if (lane == k) {
+                    y0 = g;
+                }
+                if (k > 64) {
+                    if (lane + 64 < k) {
+                        const zd l = R[(size_t)k * NK + lane + 64];
+                        y1 = zmk(y1.x - (l.x * g.x + l.y * g.y), y1.y - (l.x * g.y - l.y * g.x));
+                    }
+                }
+                if (lane + 64 == k) y1 = g;
+            }
+            if (lane < NK) G[(size_t)lane * N + c] = y0;
+            if (lane + 64 < NK) G[(size_t)(lane + 64) * N + c] = y1;
         }
-        __syncthreads();
-        for (int e = tid; e < (NK - k - 1) * N; e += 256) {
-            const int i = k + 1 + e / N, c = e % N;
-            const zd l = R[(size_t)i * NK + k], y = G[(size_t)k * N + c];
-            // r[i] -= L[i][k] y[k]
-            zd& g = G[(size_t)i * N + c];
-            g = zmk(g.x - (l.x * y.x - l.y * y.y), g.y - (l.x * y.y + l.y * y.x));
-        }
-        __syncthreads();
     }
-    for (int k = NK - 1; k >= 0; --k) {
-        if (tid < N) {
-            const double inv = 1.0 / R[(size_t)k * NK + k].x;
-            zd v = G[(size_t)k * N + tid];
-            G[(size_t)k * N + tid] = zmk(v.x * inv, v.y * inv);
-        }
-        __syncthreads();
-        for (int e = tid; e < k * N; e += 256) {
-            const int i = e / N, c = e % N;
-            // y[i] -= conj(L[k][i]) G[k]
-            const zd l = R[(size_t)k * NK + i], g = G[(size_t)k * N + c];
-            zd& y = G[(size_t)i * N + c];
-            y = zmk(y.x - (l.x * g.x + l.y * g.y), y.y - (l.x * g.y - l.y * g.x));
-        }
-        __syncthreads();
-    }
+    __syncthreads();
+    long long clk3 = 0;
+    if (a.timing && tid == 0) clk3 = (long long)__builtin_amdgcn_s_memtime();
 
-    // ---- d[c][t] = x[c][t] - sum_m conj(G[m][c]) yt[m][t] ----
-    for (int i = tid; i < N * T; i += 256) {
-        const int c = i / T, t = i - c * T;
-        zd s = zmk(0.0, 0.0);
-        for (int k = 0; k < taps; ++k) {
-            const int src = t - k - delay;
-            if (src < 0) break;
-            for (int n = 0; n < N; ++n) {
-                const float2 y = xf[(size_t)n * T + src];
-                const zd g = G[(size_t)(k * N + n) * N + c];
-                // conj(g) * y
-                s.x += g.x * y.x + g.y * y.y;
-                s.y += g.x * y.y - g.y * y.x;
+    // ---- d[c][t] = x[c][t] - sum_m conj(G[m][c]) yt[m][t]: a thread owns a frame and works
+    // through the channels four at a time (every delayed sample is loaded once per group) ----
+    for (int t = tid; t < T; t += 256) {
+        for (int c0 = 0; c0 < N; c0 += 4) {
+            zd s[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] = zmk(0.0, 0.0);
+            for (int k = 0; k < taps; ++k) {
+                const int src = t - k - delay;
+                if (src < 0) break;
+                for (int n = 0; n < N; ++n) {
+                    const float2 yf = xf[(size_t)n * T + src];
+                    const double yx = yf.x, yy = yf.y;
+                    const zd* g = G + (size_t)(k * N + n) * N + c0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (c0 + q < N) {
+                            // conj(g) * y
+                            s[q].x += g[q].x * yx + g[q].y * yy;
+                            s[q].y += g[q].x * yy - g[q].y * yx;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (c0 + q < N) {
+                    const size_t o = (size_t)(c0 + q) * T + t;
+                    const float2 xv = xf[o];
+                    a.out[(size_t)f * N * T + o] = make_float2((float)((double)xv.x - s[q].x),
+                                                               (float)((double)xv.y - s[q].y));
+                }
             }
         }
-        const float2 xv = xf[i];
-        a.out[(size_t)f * N * T + i] = make_float2((float)((double)xv.x - s.x),
-                                                   (float)((double)xv.y - s.y));
+    }
+    if (a.timing) {
+        __syncthreads();
+        if (tid == 0) {
+            const long long clk4 = (long long)__builtin_amdgcn_s_memtime();
+            long long* o = a.timing + (size_t)f * 4;
+            o[0] = clk1 - clk0;
+            o[1] = clk2 - clk1;
+            o[2] = clk3 - clk2;
+            o[3] = clk4 - clk3;
+        }
     }
 }
 
-size_t wpe_lds_bytes(int N, int taps) {
-    const size_t NK = (size_t)N * taps, D = NK + N;
-    return (NK * NK + NK * N + (size_t)kWpeTC * D) * sizeof(zd) + kWpeTC * sizeof(double) + 16;
+size_t wpe_lds_bytes_tc(int N, int taps, int TC) {
+    const size_t NK = (size_t)N * taps, W = (size_t)TC + taps - 1;
+    return (NK * NK + NK * N + N * (W + TC) + TC) * sizeof(zd) + (TC + NK) * sizeof(double) + 16;
 }
+
+// frames per staged chunk: the largest of 64 / 32 / 16 that leaves R, r and the chunk in
+// the 160 KB of a CU
+int wpe_chunk_frames(int N, int taps) {
+    for (int tc = 64; tc > kWpeTC; tc >>= 1)
+        if (wpe_lds_bytes_tc(N, taps, tc) <= 160 * 1024) return tc;
+    return kWpeTC;
+}
+
+size_t wpe_lds_bytes(int N, int taps) { return wpe_lds_bytes_tc(N, taps, wpe_chunk_frames(N, taps)); }
 
 bool wpe_supported(int N, int taps) {
     const int NK = N * taps;
-    return N >= 1 && N <= 16 && taps >= 1 && NK <= kWpeMaxNK && NK + N <= 16 * kWpeCols &&
+    return N >= 1 && N <= 16 && taps >= 1 && NK <= kWpeMaxNK &&
            wpe_lds_bytes(N, taps) <= 160 * 1024;
 }
 
@@ -331,7 +448,7 @@ const char* wpe_limit_message(int N, int taps) {
     const int NK = N * taps;
     snprintf(buf, sizeof(buf),
              "WPE on the device needs 1 <= channels <= 16, channels * taps <= %d and "
-             "(NK^2 + NK N + %d (NK + N)) complex128 entries <= 160 KB of LDS "
+             "(NK^2 + NK N + %d (2 N + 1) + N (taps - 1)) complex128 entries <= 160 KB of LDS "
              "(channels = %d, taps = %d: NK = %d, %zu bytes)",
              kWpeMaxNK, kWpeTC, N, taps, NK, wpe_lds_bytes(N, taps));
     return buf;
@@ -376,12 +493,13 @@ hipError_t launch_wpe_inv_lambda(const double* lam, int T, int F, float* out, hi
 size_t wpe_args_bytes() { return sizeof(WpeArgs); }
 
 void wpe_fill_args(void* dst, const float* x_fct, const double* lam, float* out_fct, int* status,
-                   int N, int T, int taps, int delay) {
+                   int N, int T, int taps, int delay, long long* timing) {
     WpeArgs a;
     a.x = reinterpret_cast<const float2*>(x_fct);
     a.lam = lam;
     a.out = reinterpret_cast<float2*>(out_fct);
     a.status = status;
+    a.timing = timing;
     a.N = N;
     a.T = T;
     a.taps = taps;
@@ -393,11 +511,32 @@ void wpe_fill_args(void* dst, const float* x_fct, const double* lam, float* out_
 hipError_t launch_wpe_step_batch(const void* d_tbl, int n_utts, int N, int F, int taps,
                                  hipStream_t s) {
     const size_t lds = wpe_lds_bytes(N, taps);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wpe_step_kernel),
+    void (*kern)(const WpeArgs*, int) = nullptr;
+    const int RT = (N * taps + 7) / 8, XT = (N + 7) / 8;
+    const int ntw = (RT * (RT + 1) / 2 + RT * XT + 3) / 4;  // tiles per wavefront, <= 26
+#define SETK_WPE_CASE(n) \
+    if (!kern && ntw <= n) kern = wpe_step_kernel<n>
+    SETK_WPE_CASE(1);
+    SETK_WPE_CASE(2);
+    SETK_WPE_CASE(3);
+    SETK_WPE_CASE(4);
+    SETK_WPE_CASE(5);
+    SETK_WPE_CASE(6);
+    SETK_WPE_CASE(8);
+    SETK_WPE_CASE(10);
+    SETK_WPE_CASE(12);
+    SETK_WPE_CASE(14);
+    SETK_WPE_CASE(17);
+    SETK_WPE_CASE(20);
+    SETK_WPE_CASE(23);
+    SETK_WPE_CASE(26);
+#undef SETK_WPE_CASE
+    if (!kern) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(wpe_step_kernel, dim3(F, n_utts), dim3(256), lds, s,
-                       static_cast<const WpeArgs*>(d_tbl));
+    hipLaunchKernelGGL(kern, dim3(F, n_utts), dim3(256), lds, s, static_cast<const WpeArgs*>(d_tbl),
+                       wpe_chunk_frames(N, taps));
     return hipGetLastError();
 }
 

@@ -481,3 +481,71 @@ class CgmmEstimator(object):
             for i, m in zip(idx, self.estimate_device(audio)):
                 out[i] = m.cpu().numpy()
         return out
+
+
+class BatchDereverb(object):
+    """apply_wpe.py:30-66 for a batch, resident on the device: the STFT of every channel,
+    num_iters WPE steps over every (bin, utterance) per launch (setk_wpe_batch, fp64) and
+    the inverse STFT of every channel (inverse_stft with norm = None), one upload of the
+    samples and one download of the waveforms per batch.  run() takes a list of C x N
+    float32 arrays or Pcm16Frames with the same channel count and returns C x L float32
+    arrays, None where the tap correlation of a bin is singular (the reference's
+    LinAlgError, apply_wpe.py:55-57)."""
+
+    def __init__(self, taps=10, delay=3, context=1, num_iters=3, frame_len=512, frame_hop=256,
+                 center=True, round_power_of_two=True, window="hann", device=None):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _ffi.SetkError("setk_amd needs an MI355X GPU (no CPU fallback)")
+        self.ctx = _ffi.default_context(device)
+        self.dev = torch.device("cuda", self.ctx.device)
+        self.taps, self.delay, self.context, self.num_iters = taps, delay, context, num_iters
+        n_fft = nextpow2(frame_len) if round_power_of_two else frame_len
+        self.stft = dict(frame_len=frame_len, frame_hop=frame_hop, n_fft=n_fft, center=center,
+                         window=stft_window(window, frame_len))
+        self.num_bins = n_fft // 2 + 1
+
+    def run(self, utts):
+        torch, ctx, dev, F = self.torch, self.ctx, self.dev, self.num_bins
+        if not len(utts):
+            return []
+        s = self.stft
+        ctx.stft_plan(s["frame_len"], s["frame_hop"], s["n_fft"], s["center"], s["window"])
+        C = _channels_and_size(utts[0])[0]
+        if any(_channels_and_size(u)[0] != C for u in utts):
+            raise ValueError("BatchDereverb.run needs the same channel count in every utterance")
+        audio, ns = [], []
+        for samps in utts:
+            if isinstance(samps, Pcm16Frames):
+                N = samps.frames.shape[0]
+                a = torch.empty((C, N), dtype=torch.float32, device=dev)
+                ctx.pcm16_to_float(torch.from_numpy(samps.frames).to(dev), C, N, a)
+            else:
+                samps = np.ascontiguousarray(samps, dtype=np.float32)
+                a = torch.from_numpy(samps[None] if samps.ndim == 1 else samps).to(dev)
+                N = a.shape[1]
+            audio.append(a)
+            ns.append(N)
+        frames = [ctx.num_frames(N) for N in ns]
+        specs = [torch.empty((C, T, F), dtype=torch.complex64, device=dev) for T in frames]
+        if s["n_fft"] == 512 and C <= 8:
+            ctx.stft_batch(C, [a.data_ptr() for a in audio], ns, [t.data_ptr() for t in specs])
+        else:
+            for a, t in zip(audio, specs):
+                ctx.stft(a, t)
+        outs = [torch.empty_like(t) for t in specs]
+        status = np.zeros((len(utts), F), dtype=np.int32)
+        ctx.wpe_batch(specs, C, frames, F, self.taps, self.delay, self.context, self.num_iters,
+                      outs, status=status)
+        lens = [ctx.istft_num_samples(T) for T in frames]
+        waves = torch.empty((C * sum(lens),), dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for t, T, L in zip(outs, frames, lens):
+            w = waves[off:off + C * L].view(C, L)
+            ctx.istft(t, C, T, None, None, w)
+            views.append((off, L))
+            off += C * L
+        host = waves.cpu().numpy()
+        return [None if status[u].any() else host[o:o + C * L].reshape(C, L)
+                for u, (o, L) in enumerate(views)]

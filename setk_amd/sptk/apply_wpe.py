@@ -3,21 +3,20 @@
 GWPE dereverberation on the MI355X.
 
 Drop-in for funcwj/setk ``scripts/sptk/apply_wpe.py`` (same positional arguments,
-options and defaults, :86-135; multi-channel PCM_16 wav out): STFT, the WPE
-iterations (setk_wpe_batch, fp64, --batch-utts utterances per launch) and the
-inverse STFT of every channel run on the GPU.  ``--nara-wpe true`` is refused: that third-party package is not part of
+options and defaults, :86-135; multi-channel PCM_16 wav out): the samples go up
+once per batch, the STFT, the WPE iterations (setk_wpe_batch, fp64, --batch-utts
+utterances per launch) and the inverse STFT of every channel run on the GPU
+(setk_amd.engine.BatchDereverb), the waveforms come down once.  ``--nara-wpe true`` is refused: that third-party package is not part of
 this path.
 """
 import argparse
 
-import numpy as np
-
 from .._ffi import SetkUnsupported
 from setk_amd.dist import Shard
-from setk_amd.libs.data_handler import SpectrogramReader, WaveWriter
+from setk_amd.engine import BatchDereverb, Pcm16Frames, _channels_and_size
+from setk_amd.libs.data_handler import WaveReader, WaveWriter
 from setk_amd.libs.opts import StftParser, strtobool
-from setk_amd.libs.utils import get_logger, inverse_stft
-from setk_amd.libs.wpe import wpe_batch
+from setk_amd.libs.utils import get_logger
 
 logger = get_logger(__name__)
 
@@ -25,53 +24,47 @@ logger = get_logger(__name__)
 def run(args):
     if args.nara_wpe:
         raise RuntimeError("--nara-wpe: the nara_wpe package is not available here")
-    stft_kwargs = {
-        "frame_len": args.frame_len,
-        "frame_hop": args.frame_hop,
-        "window": args.window,
-        "center": args.center,
-        "transpose": True  # T x F
-    }
     shard = Shard()
-    reader = SpectrogramReader(args.wav_scp, round_power_of_two=args.round_power_of_two,
-                               **stft_kwargs)
+    device = shard.device if shard.world > 1 else None
+    engine = BatchDereverb(taps=args.taps, delay=args.delay, context=args.context,
+                           num_iters=args.num_iters, frame_len=args.frame_len,
+                           frame_hop=args.frame_hop, center=bool(args.center),
+                           round_power_of_two=bool(args.round_power_of_two), window=args.window,
+                           device=device)
+    reader = WaveReader(args.wav_scp)  # 16 kHz tables like the reference (SpectrogramReader)
     num_done = 0
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
 
         def flush(pending):
-            """--batch-utts utterances (grouped by channel count) per setk_wpe_batch call:
-            one launch per iteration over every (bin, utterance)."""
+            """--batch-utts utterances (grouped by channel count) per engine call: samples
+            up once, STFT -> WPE iterations -> inverse STFT on the device, waveforms down
+            once."""
             done = 0
             groups = {}
-            for key, rev in pending:
-                groups.setdefault(rev.shape[1], []).append((key, rev))
+            for key, samps in pending:
+                groups.setdefault(_channels_and_size(samps)[0], []).append((key, samps))
             for _, items in groups.items():
                 try:
-                    outs = wpe_batch([r for _, r in items], num_iters=args.num_iters,
-                                     context=args.context, taps=args.taps, delay=args.delay)
+                    outs = engine.run([s for _, s in items])
                 except SetkUnsupported as e:
                     # a shape beyond the device kernels' limits (channels x taps): skip the
                     # utterances like a numerical failure instead of ending the run
                     for key, _ in items:
                         logger.warning(f"{key}: skipped, {e}")
                     continue
-                for (key, _), dereverb in zip(items, outs):
-                    if dereverb is None:
+                for (key, _), samps in zip(items, outs):
+                    if samps is None:
                         logger.warning(f"{key}: Failed cause LinAlgError in wpe")
                         continue
-                    dereverb = np.transpose(dereverb, (1, 2, 0))  # F x N x T => N x T x F
-                    samps = np.stack([inverse_stft(spectra, **stft_kwargs) for spectra in dereverb])
-                    writer.write(key, samps)
+                    writer.write(key, samps)  # multi-channel
                     done += 1
             return done
 
         pending = []
         for key in shard.assign_by_duration(reader):
-            reverbed = reader[key]
             logger.info(f"Processing utt {key}...")
-            if reverbed.ndim == 2:
-                reverbed = reverbed[None, ...]
-            pending.append((key, np.transpose(reverbed, (2, 0, 1))))  # N x T x F => F x N x T
+            pcm = reader.read_pcm16(key)
+            pending.append((key, Pcm16Frames(pcm) if pcm is not None else reader.read(key)))
             if len(pending) >= max(1, args.batch_utts):
                 num_done += flush(pending)
                 pending = []

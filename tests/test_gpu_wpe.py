@@ -99,13 +99,21 @@ def test_wpe_singular_is_linalg_error():
 
 def test_wpe_rank_deficient_goes_through_like_lu():
     """Fewer frames than channels x taps: R is semi-definite.  numpy's pivoted LU (the
-    reference) returns a finite result without raising; the device Cholesky floors its
-    pivots relative to the largest diagonal entry and must not drop the utterance."""
+    reference) returns a finite result without raising; the device Cholesky drops the
+    columns whose pivot is at the noise level (dividing by a floored pivot lets the noise
+    grow until it overflows: 1 bin in 5 of the first case with the MFMA summation order)
+    and must neither drop the utterance nor return anything unbounded."""
     from setk_amd.libs import wpe as W
     rng = np.random.default_rng(12)
     fnt = (rng.standard_normal((5, 4, 10)) + 1j * rng.standard_normal((5, 4, 10))).astype(np.complex64)
     out = W.wpe(fnt, taps=5, delay=1, context=0, num_iters=1)
     assert out.shape == fnt.shape and np.all(np.isfinite(out))
+    for seed, (C, T, taps) in enumerate([(4, 10, 5), (4, 16, 6), (2, 9, 12), (8, 30, 10), (6, 7, 3)]):
+        rng = np.random.default_rng(200 + seed)
+        fnt = (rng.standard_normal((64, C, T)) + 1j * rng.standard_normal((64, C, T))).astype(np.complex64)
+        out = W.wpe(fnt, taps=taps, delay=1, context=0, num_iters=2)
+        assert np.all(np.isfinite(out)), (C, T, taps)
+        assert np.abs(out).max() < 100 * np.abs(fnt).max(), (C, T, taps, np.abs(out).max())
 
 
 def test_facted_wpd_matches_oracle():
@@ -153,3 +161,35 @@ def test_doc_wpe_and_wpd_clis(tmp_path):
     _, enh = o.facted_wpd(obs, cgmm_iters=10, wpd_iters=2, taps=10, delay=3, context=1, gauge=True)
     ref = o.inverse_stft(enh, norm=np.max(np.abs(samps)), transpose=True, **STFT_KW)
     assert pcm16_rel_rms(y, ref) < 1e-3, pcm16_rel_rms(y, ref)
+
+
+@pytest.mark.parametrize("hop,window,pcm", [(128, "blackman", False), (256, "hann", True)])
+def test_batch_dereverb_resident_matches_oracle(hop, window, pcm):
+    """engine.BatchDereverb (what apply_wpe.py runs): samples -> STFT -> WPE -> inverse STFT
+    without leaving the device, ragged batch, against the oracle's forward_stft -> wpe ->
+    inverse_stft of every channel (apply_wpe.py:30-66)."""
+    from setk_amd.engine import BatchDereverb, Pcm16Frames
+    kw = dict(frame_len=512, frame_hop=hop, window=window, center=True)
+    utts = []
+    for u, N in enumerate((30000, 17333, 24001)):
+        mix = o.synth_utterance(300 + u, 3, N)
+        rev = mix.copy()
+        for d in (900, 2100):
+            rev[:, d:] += 0.4 * mix[:, :-d]
+        if pcm:
+            q = np.round(rev * 32768.0 * 0.5).astype(np.int16)
+            utts.append((Pcm16Frames(np.ascontiguousarray(q.T)), q.astype(np.float32) / 32768.0))
+        else:
+            utts.append((rev.astype(np.float32), rev.astype(np.float32)))
+    eng = BatchDereverb(taps=6, delay=3, context=1, num_iters=3, **kw)
+    outs = eng.run([a for a, _ in utts])
+    for (_, samps), got in zip(utts, outs):
+        obs = o.multichannel_stft(samps, transpose=True, **kw)
+        der = o.wpe(np.transpose(obs, (2, 0, 1)), taps=6, delay=3, context=1, num_iters=3)
+        ref = np.stack([o.inverse_stft(s, transpose=True, **kw) for s in np.transpose(der, (1, 2, 0))])
+        assert got.shape == ref.shape and got.dtype == np.float32
+        assert rel_rms(got, ref) < 1e-4, rel_rms(got, ref)
+    # a silent utterance inside the batch is the reference's LinAlgError, the others go through
+    outs2 = eng.run([utts[0][0], np.zeros((3, 20000), np.float32)] if not pcm else
+                    [utts[0][0], Pcm16Frames(np.zeros((20000, 3), np.int16))])
+    assert outs2[1] is None and np.array_equal(outs2[0], outs[0])

@@ -57,6 +57,17 @@ def run(utts=16, seconds=10.0):
             "workload": f"the same, {4 * len(specs)} utterances per setk_wpe_batch call",
             "ms_per_utt": round(1e3 * dtb / (4 * len(specs)), 2),
             "value": round(4 * len(specs) * seconds / dtb, 1)}
+    # the CLI's engine: samples in, waveforms out, spectra never leave the device
+    from setk_amd.engine import BatchDereverb
+    eng = BatchDereverb(taps=10, delay=3, context=1, num_iters=3, frame_len=512, frame_hop=128,
+                        window="hann", center=True)
+    auds = [m.astype(np.float32) for m in mixes] * 4
+    dtr = timed(lambda: eng.run(auds), 3)
+    res["wpe_4ch_10taps_resident"] = {
+        "workload": f"the same from samples to samples (engine.BatchDereverb: STFT -> WPE -> inverse "
+                    f"STFT on the device), {len(auds)} utterances per call",
+        "ms_per_utt": round(1e3 * dtr / len(auds), 2),
+        "value": round(len(auds) * seconds / dtr, 1)}
     # ---- directional features on a mask ----
     mix, sp, nz = synth.synth_utterance(3100, 4, N, return_parts=True)
     spec = device_stft(mix, 512, 256, True, True, "hann")          # C x T x F
