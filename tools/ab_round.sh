@@ -5,7 +5,7 @@
 TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 LIBS="setk_amd/libsetk_hip.so $@"
-B="python bench.py --steps 20 --warmup 3 --cpu-sample 0 --e2e-utts 0 --full-batch 0 --sustain-sec 0 --other-configs 0"
+B="python bench.py --steps 20 --warmup 3 --cpu-sample 0 --e2e-utts 0 --full-batch 0 --sustain-sec 0 --other-configs 0 --pmc 0"
 for rep in 1 2 3; do
   for L in $LIBS; do
     SETK_LIB=$PWD/$L $B 2>/dev/null | tail -1 > /tmp/ab.json
