@@ -489,17 +489,20 @@ class BatchDereverb(object):
     the inverse STFT of every channel (inverse_stft with norm = None), one upload of the
     samples and one download of the waveforms per batch.  run() takes a list of C x N
     float32 arrays or Pcm16Frames with the same channel count and returns C x L float32
-    arrays, None where the tap correlation of a bin is singular (the reference's
-    LinAlgError, apply_wpe.py:55-57)."""
+    arrays (pcm16: L x C int16 frames, ready for the wav writer), None where the tap
+    correlation of a bin is singular (the reference's LinAlgError, apply_wpe.py:55-57)."""
 
     def __init__(self, taps=10, delay=3, context=1, num_iters=3, frame_len=512, frame_hop=256,
-                 center=True, round_power_of_two=True, window="hann", device=None):
+                 center=True, round_power_of_two=True, window="hann", device=None, pcm16=False):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
             raise _ffi.SetkError("setk_amd needs an MI355X GPU (no CPU fallback)")
         self.ctx = _ffi.default_context(device)
         self.dev = torch.device("cuda", self.ctx.device)
+        # pcm16: hand back interleaved int16 frames L x C, quantised on the device by the
+        # writer's rule (wavio.float_to_pcm16: rint(x * 32767) in float64, wrapping)
+        self.pcm16 = bool(pcm16)
         self.taps, self.delay, self.context, self.num_iters = taps, delay, context, num_iters
         n_fft = nextpow2(frame_len) if round_power_of_two else frame_len
         self.stft = dict(frame_len=frame_len, frame_hop=frame_hop, n_fft=n_fft, center=center,
@@ -546,6 +549,12 @@ class BatchDereverb(object):
             ctx.istft(t, C, T, None, None, w)
             views.append((off, L))
             off += C * L
+        if self.pcm16:
+            q = torch.round(waves.double() * 32767.0).to(torch.int64).to(torch.int16)
+            # channel-major C x L per utterance -> interleaved frames L x C
+            host = torch.cat([q[o:o + C * L].view(C, L).t().reshape(-1) for o, L in views]).cpu().numpy()
+            return [None if status[u].any() else host[o:o + C * L].reshape(L, C)
+                    for u, (o, L) in enumerate(views)]
         host = waves.cpu().numpy()
         return [None if status[u].any() else host[o:o + C * L].reshape(C, L)
                 for u, (o, L) in enumerate(views)]

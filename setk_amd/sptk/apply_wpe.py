@@ -30,7 +30,7 @@ def run(args):
                            num_iters=args.num_iters, frame_len=args.frame_len,
                            frame_hop=args.frame_hop, center=bool(args.center),
                            round_power_of_two=bool(args.round_power_of_two), window=args.window,
-                           device=device)
+                           device=device, pcm16=True)
     reader = WaveReader(args.wav_scp)  # 16 kHz tables like the reference (SpectrogramReader)
     num_done = 0
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
@@ -56,7 +56,7 @@ def run(args):
                     if samps is None:
                         logger.warning(f"{key}: Failed cause LinAlgError in wpe")
                         continue
-                    writer.write(key, samps)  # multi-channel
+                    writer.write_pcm16(key, samps)  # multi-channel frames, quantised on the device
                     done += 1
             return done
 

@@ -189,6 +189,11 @@ def test_batch_dereverb_resident_matches_oracle(hop, window, pcm):
         ref = np.stack([o.inverse_stft(s, transpose=True, **kw) for s in np.transpose(der, (1, 2, 0))])
         assert got.shape == ref.shape and got.dtype == np.float32
         assert rel_rms(got, ref) < 1e-4, rel_rms(got, ref)
+    # the CLI's form: frames quantised on the device by the wav writer's rule
+    from setk_amd.libs.wavio import float_to_pcm16
+    q = BatchDereverb(taps=6, delay=3, context=1, num_iters=3, pcm16=True, **kw).run([a for a, _ in utts])
+    for f32, i16 in zip(outs, q):
+        assert i16.dtype == np.int16 and np.array_equal(i16, float_to_pcm16(f32).T)
     # a silent utterance inside the batch is the reference's LinAlgError, the others go through
     outs2 = eng.run([utts[0][0], np.zeros((3, 20000), np.float32)] if not pcm else
                     [utts[0][0], Pcm16Frames(np.zeros((20000, 3), np.int16))])
