@@ -328,6 +328,11 @@ def main():
 SIMDS = 256 * 4            # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 XCDS = 8
 VALU_CYCLES_PER_INST = 2   # a wave64 VALU instruction occupies its SIMD-32 for two cycles
+# measured issue rate of a SIMD shared by n waves (plain fp32 VALU, profiles/r02t_valu_rate_pinned.txt)
+ISSUE_CYCLES_AT_WAVES = {1: 7.6, 2: 3.6, 4: 2.24}
+WAVES_PER_SIMD = {"pass1": 4, "pass2": 2}
+WAVES_WHY = {"pass1": "one 1024-thread workgroup per CU at the 128-VGPR budget",
+             "pass2": "two 256-thread workgroups per CU: 63.6 KB of LDS each, 256 VGPRs per wave"}
 KERNELS = {"pass1": "stft_covar_kernel", "pass2": "beamform_istft_kernel"}
 
 
@@ -426,6 +431,16 @@ def build_roofline(C, b_k1, b_k2, k1_ms, k2_ms, pmc):
                                  "frac": round(floor_ms / p["profiled_kernel_ms"], 4)
                                  if p.get("profiled_kernel_ms") else None,
                                  "frac_unprofiled": round(floor_ms / kms, 4)}
+            # what the kernel's OCCUPANCY lets a SIMD issue: measured with pinned instruction
+            # streams (tools/ubench/valu_rate2.hip, profiles/r02t_valu_rate_pinned.txt): one
+            # plain fp32 VALU instruction per 7.6 / 3.6 / 2.24 cycles with 1 / 2 / 4 waves
+            waves = WAVES_PER_SIMD[key]
+            occ_floor = floor_ms * ISSUE_CYCLES_AT_WAVES[waves] / VALU_CYCLES_PER_INST
+            ent["valu_issue"]["at_occupancy"] = {
+                "waves_per_simd": waves, "cycles_per_inst": ISSUE_CYCLES_AT_WAVES[waves],
+                "floor_ms": round(occ_floor, 4),
+                "frac": round(occ_floor / p["profiled_kernel_ms"], 4) if p.get("profiled_kernel_ms") else None,
+                "why": WAVES_WHY[key]}
         roof[key] = ent
     p1 = roof.get("pass1", {})
     if "traffic" in p1.get("hbm", {}):
