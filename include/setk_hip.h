@@ -104,6 +104,25 @@ int setk_host_register(setk_handle_t h, void* ptr, size_t bytes);
 int setk_host_unregister(setk_handle_t h, void* ptr);
 int setk_memcpy_h2d_async(setk_handle_t h, void* dst, const void* src, size_t bytes,
                           void* stream);
+int setk_memcpy_d2h_async(setk_handle_t h, void* dst, const void* src, size_t bytes,
+                          void* stream);
+/* Buffers, streams and events on the handle's device, for a host program that brings no HIP
+ * runtime binding of its own (setk_amd/pipeline.py runs without importing torch): device and
+ * page-locked host memory, non-blocking streams (pass them as the `stream` argument of any
+ * entry point), events without timing.  Thread safe.  What the reference has in their place:
+ * nothing -- it is single-threaded numpy (apply_adaptive_beamformer.py:130-178). */
+int setk_device_alloc(setk_handle_t h, size_t bytes, void** out);
+int setk_device_free(setk_handle_t h, void* ptr);
+int setk_host_alloc(setk_handle_t h, size_t bytes, void** out);
+int setk_host_free(setk_handle_t h, void* ptr);
+int setk_stream_create(setk_handle_t h, void** out);
+int setk_stream_destroy(setk_handle_t h, void* stream);
+int setk_stream_synchronize(setk_handle_t h, void* stream);
+int setk_stream_wait_event(setk_handle_t h, void* stream, void* event);
+int setk_event_create(setk_handle_t h, void** out);
+int setk_event_destroy(setk_handle_t h, void* event);
+int setk_event_record(setk_handle_t h, void* event, void* stream);
+int setk_event_synchronize(setk_handle_t h, void* event);
 
 /* ---- STFT plan ---------------------------------------------------------
  * Mirrors the arguments of forward_stft / inverse_stft

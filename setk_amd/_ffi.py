@@ -5,10 +5,12 @@ There is no CPU fallback: if the HIP library has not been built or no GPU is
 visible, every operator raises.  PyTorch is imported first so that its bundled
 HIP runtime (same SONAME, libamdhip64.so.7) is the one the library binds to --
 torch tensors and this library then share one runtime, one device context and
-torch's streams.
+torch's streams.  A process that needs none of that (the streaming CLI: buffers,
+streams and events come from the library itself) sets TORCH_FREE and skips the import.
 """
 import ctypes
 import os
+import sys
 from ctypes import (POINTER, c_char_p, c_float, c_int, c_void_p)
 
 import numpy as np
@@ -46,10 +48,21 @@ class SetkUnsupported(SetkError, NotImplementedError):
 _lib = None
 
 
+# The streaming CLI needs no torch at all (buffers, streams and events come from the library):
+# it sets this before the first Context so that the second of `import torch` is not spent.
+# The library then runs on the HIP runtime of /opt/rocm; a process that is going to use torch
+# tensors with this library must import torch BEFORE the library is loaded (the default).
+TORCH_FREE = os.environ.get("SETK_TORCH_FREE", "") not in ("", "0")
+
+
 def exported_symbols():
     """Names declared in include/setk_hip.h (checked by the CPU test-suite)."""
     return [
         "setk_abi_version", "setk_create", "setk_destroy", "setk_last_error",
+        "setk_memcpy_d2h_async", "setk_device_alloc", "setk_device_free", "setk_host_alloc",
+        "setk_host_free", "setk_stream_create", "setk_stream_destroy", "setk_stream_synchronize",
+        "setk_stream_wait_event", "setk_event_create", "setk_event_destroy", "setk_event_record",
+        "setk_event_synchronize",
         "setk_host_register", "setk_host_unregister", "setk_memcpy_h2d_async",
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_stft_batch", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
@@ -70,10 +83,11 @@ def load_library():
         raise SetkError(
             f"{LIB_PATH} is missing: build it with `python -m setk_amd.build` "
             "(there is no CPU fallback)")
-    try:
-        import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first)
-    except Exception:  # pragma: no cover - torch is plumbing, not required
-        pass
+    if not TORCH_FREE or "torch" in sys.modules:
+        try:
+            import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first)
+        except Exception:  # pragma: no cover - torch is plumbing, not required
+            pass
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     H = c_void_p
     fp = c_void_p  # raw data pointers (host or device)
@@ -85,6 +99,16 @@ def load_library():
     lib.setk_host_register.argtypes = [H, c_void_p, ctypes.c_size_t]
     lib.setk_host_unregister.argtypes = [H, c_void_p]
     lib.setk_memcpy_h2d_async.argtypes = [H, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]
+    lib.setk_memcpy_d2h_async.argtypes = [H, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]
+    for name in ("setk_device_alloc", "setk_host_alloc"):
+        getattr(lib, name).argtypes = [H, ctypes.c_size_t, POINTER(c_void_p)]
+    for name in ("setk_device_free", "setk_host_free", "setk_stream_destroy", "setk_stream_synchronize",
+                 "setk_event_destroy", "setk_event_synchronize"):
+        getattr(lib, name).argtypes = [H, c_void_p]
+    for name in ("setk_stream_create", "setk_event_create"):
+        getattr(lib, name).argtypes = [H, POINTER(c_void_p)]
+    lib.setk_stream_wait_event.argtypes = [H, c_void_p, c_void_p]
+    lib.setk_event_record.argtypes = [H, c_void_p, c_void_p]
     lib.setk_set_profiling.argtypes = [H, c_int]
     lib.setk_last_stage_ms.argtypes = [H, POINTER(c_float)]
     lib.setk_stft_plan.argtypes = [H, c_int, c_int, c_int, c_int, fp]
@@ -154,11 +178,22 @@ def _ptr(x):
     raise TypeError(f"unsupported buffer type {type(x)}")
 
 
-def current_stream_ptr():
-    """torch's current HIP stream as a raw hipStream_t (0 = default stream)."""
+def _torch():
+    """torch, or None in a torch-free process (TORCH_FREE and nobody imported it)."""
+    if TORCH_FREE and "torch" not in sys.modules:
+        return None
     try:
         import torch
-        if torch.cuda.is_available():
+        return torch
+    except Exception:  # pragma: no cover
+        return None
+
+
+def current_stream_ptr():
+    """torch's current HIP stream as a raw hipStream_t (0 = default stream)."""
+    torch = _torch()
+    try:
+        if torch is not None and torch.cuda.is_available():
             return torch.cuda.current_stream().cuda_stream
     except Exception:
         pass
@@ -209,6 +244,56 @@ class Context:
 
     def host_unregister(self, ptr):
         self._lib.setk_host_unregister(self._h, c_void_p(int(ptr)))
+
+    # -- buffers, streams, events (a host pipeline without a runtime binding of its own) ----
+    def _out_ptr(self, fn, *args):
+        p = c_void_p()
+        self.check(fn(self._h, *args, ctypes.byref(p)))
+        return p.value or 0
+
+    def device_alloc(self, nbytes):
+        return self._out_ptr(self._lib.setk_device_alloc, ctypes.c_size_t(int(nbytes)))
+
+    def device_free(self, ptr):
+        self.check(self._lib.setk_device_free(self._h, c_void_p(ptr)))
+
+    def host_alloc(self, nbytes):
+        """Page-locked host memory: (address, uint8 numpy view)."""
+        nbytes = int(nbytes)
+        addr = self._out_ptr(self._lib.setk_host_alloc, ctypes.c_size_t(nbytes))
+        view = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(addr))
+        return addr, view
+
+    def host_free(self, addr):
+        self.check(self._lib.setk_host_free(self._h, c_void_p(addr)))
+
+    def stream_create(self):
+        return self._out_ptr(self._lib.setk_stream_create)
+
+    def stream_destroy(self, stream):
+        self.check(self._lib.setk_stream_destroy(self._h, c_void_p(stream)))
+
+    def stream_synchronize(self, stream):
+        self.check(self._lib.setk_stream_synchronize(self._h, c_void_p(stream)))
+
+    def stream_wait_event(self, stream, event):
+        self.check(self._lib.setk_stream_wait_event(self._h, c_void_p(stream), c_void_p(event)))
+
+    def event_create(self):
+        return self._out_ptr(self._lib.setk_event_create)
+
+    def event_destroy(self, event):
+        self.check(self._lib.setk_event_destroy(self._h, c_void_p(event)))
+
+    def event_record(self, event, stream):
+        self.check(self._lib.setk_event_record(self._h, c_void_p(event), c_void_p(stream)))
+
+    def event_synchronize(self, event):
+        self.check(self._lib.setk_event_synchronize(self._h, c_void_p(event)))
+
+    def memcpy_d2h_async(self, dst, src, nbytes, stream):
+        self.check(self._lib.setk_memcpy_d2h_async(self._h, c_void_p(dst), c_void_p(src),
+                                                   ctypes.c_size_t(int(nbytes)), c_void_p(stream)))
 
     def memcpy_h2d_async(self, dst, src, nbytes, stream):
         self.check(self._lib.setk_memcpy_h2d_async(self._h, c_void_p(int(dst)), c_void_p(int(src)),
@@ -459,9 +544,9 @@ def default_context(device=None):
             device = int(os.environ["LOCAL_RANK"])
         else:
             device = 0
+            torch = _torch()
             try:
-                import torch
-                if torch.cuda.is_available():
+                if torch is not None and torch.cuda.is_available():
                     device = torch.cuda.current_device()
             except Exception:
                 pass

@@ -350,6 +350,102 @@ int setk_memcpy_h2d_async(setk_handle_t h, void* dst, const void* src, size_t by
     return SETK_OK;
 }
 
+int setk_memcpy_d2h_async(setk_handle_t h, void* dst, const void* src, size_t bytes, void* stream) {
+    if (!h || !dst || !src) return SETK_ERR_INVALID;
+    HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost,
+                              static_cast<hipStream_t>(stream)));
+    return SETK_OK;
+}
+
+// ---- buffers, streams and events for a host pipeline that brings no runtime of its own ----
+int setk_device_alloc(setk_handle_t h, size_t bytes, void** out) {
+    if (!h || !out || !bytes) return SETK_ERR_INVALID;
+    *out = nullptr;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (hipMalloc(out, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(h, SETK_ERR_NOMEM, "hipMalloc");
+    }
+    return SETK_OK;
+}
+
+int setk_device_free(setk_handle_t h, void* ptr) {
+    if (!h) return SETK_ERR_INVALID;
+    if (ptr) HIP_TRY(h, hipFree(ptr));
+    return SETK_OK;
+}
+
+int setk_host_alloc(setk_handle_t h, size_t bytes, void** out) {
+    if (!h || !out || !bytes) return SETK_ERR_INVALID;
+    *out = nullptr;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(h, SETK_ERR_NOMEM, "hipHostMalloc");
+    }
+    return SETK_OK;
+}
+
+int setk_host_free(setk_handle_t h, void* ptr) {
+    if (!h) return SETK_ERR_INVALID;
+    if (ptr) HIP_TRY(h, hipHostFree(ptr));
+    return SETK_OK;
+}
+
+int setk_stream_create(setk_handle_t h, void** out) {
+    if (!h || !out) return SETK_ERR_INVALID;
+    hipStream_t s = nullptr;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = s;
+    return SETK_OK;
+}
+
+int setk_stream_destroy(setk_handle_t h, void* stream) {
+    if (!h) return SETK_ERR_INVALID;
+    if (stream) HIP_TRY(h, hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return SETK_OK;
+}
+
+int setk_stream_synchronize(setk_handle_t h, void* stream) {
+    if (!h) return SETK_ERR_INVALID;
+    HIP_TRY(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return SETK_OK;
+}
+
+int setk_stream_wait_event(setk_handle_t h, void* stream, void* event) {
+    if (!h || !event) return SETK_ERR_INVALID;
+    HIP_TRY(h, hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0));
+    return SETK_OK;
+}
+
+int setk_event_create(setk_handle_t h, void** out) {
+    if (!h || !out) return SETK_ERR_INVALID;
+    hipEvent_t e = nullptr;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *out = e;
+    return SETK_OK;
+}
+
+int setk_event_destroy(setk_handle_t h, void* event) {
+    if (!h) return SETK_ERR_INVALID;
+    if (event) HIP_TRY(h, hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return SETK_OK;
+}
+
+int setk_event_record(setk_handle_t h, void* event, void* stream) {
+    if (!h || !event) return SETK_ERR_INVALID;
+    HIP_TRY(h, hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+    return SETK_OK;
+}
+
+int setk_event_synchronize(setk_handle_t h, void* event) {
+    if (!h || !event) return SETK_ERR_INVALID;
+    HIP_TRY(h, hipEventSynchronize(static_cast<hipEvent_t>(event)));
+    return SETK_OK;
+}
+
 int setk_stft_plan(setk_handle_t h, int frame_len, int frame_hop, int n_fft, int center,
                    const float* window) {
     if (!h) return SETK_ERR_INVALID;

@@ -78,12 +78,11 @@ class BatchEnhancer(object):
                  max_batch_samples=1 << 28):
         if beamformer not in BEAMFORMER_KINDS:
             raise ValueError(f"unknown beamformer {beamformer}")
-        import torch
-        self.torch = torch
-        if not torch.cuda.is_available():
-            raise _ffi.SetkError("BatchEnhancer needs an MI355X (no CPU fallback)")
+        # no GPU / no library: setk_create fails here, loudly (there is no CPU fallback).
+        # torch is the plumbing of enhance() only -- the streaming pipeline brings its own
+        # buffers and streams -- and is imported when enhance() first needs it.
         self.ctx = ctx or _ffi.default_context(device)
-        self.dev = torch.device("cuda", self.ctx.device)
+        self._torch = None
         n_fft = nextpow2(frame_len) if round_power_of_two else frame_len
         self.stft = dict(frame_len=frame_len, frame_hop=frame_hop, n_fft=n_fft, center=center,
                          window=stft_window(window, frame_len))
@@ -102,6 +101,19 @@ class BatchEnhancer(object):
         self.pcm16 = pcm16
         self.vad_proportion = vad_proportion
         self.max_batch_samples = max_batch_samples
+
+    @property
+    def torch(self):
+        if self._torch is None:
+            import torch
+            if not torch.cuda.is_available():
+                raise _ffi.SetkError("BatchEnhancer needs an MI355X (no CPU fallback)")
+            self._torch = torch
+        return self._torch
+
+    @property
+    def dev(self):
+        return self.torch.device("cuda", self.ctx.device)
 
     def _plan(self):
         s = self.stft

@@ -10,7 +10,6 @@ import os
 import warnings
 
 import numpy as np
-import scipy.signal
 
 from . import wavio
 from .. import _ffi
@@ -62,14 +61,32 @@ def read_wav(fname, beg=0, end=None, normalize=True, sr=16000):
     return samps
 
 
+# scipy.signal.windows.general_cosine(M, a, sym=False), operation for operation (same bits):
+# the three windows the STFT options are normally given, without the quarter second that
+# importing scipy.signal costs a command-line run
+_COSINE_WINDOWS = {"hann": (0.5, 0.5), "hamming": (0.54, 1.0 - 0.54),
+                   "blackman": (0.42, 0.50, 0.08)}
+
+
+def _cosine_window(name, frame_len):
+    fac = np.linspace(-np.pi, np.pi, frame_len + 1)
+    w = np.zeros(frame_len + 1)
+    for k, a in enumerate(_COSINE_WINDOWS[name]):
+        w += a * np.cos(k * fac)
+    return w[:-1]
+
+
 def stft_window(window, frame_len):
     """The analysis/synthesis window the reference hands to librosa:
     scipy.signal.get_window(name, frame_len, fftbins=True), the sqrt-hann
     special case (utils.py:116-117), or a caller supplied array."""
     if isinstance(window, str):
         if window == "sqrthann":
-            w = scipy.signal.windows.hann(frame_len, sym=False)**0.5
+            w = _cosine_window("hann", frame_len)**0.5
+        elif window in _COSINE_WINDOWS and frame_len > 1:
+            w = _cosine_window(window, frame_len)
         else:
+            import scipy.signal
             w = scipy.signal.get_window(window, frame_len, fftbins=True)
     else:
         w = np.asarray(window, dtype=np.float64)

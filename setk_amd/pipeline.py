@@ -225,42 +225,67 @@ class Job(object):
 
 
 class _Slot(object):
-    """Buffers of one in-flight batch."""
+    """Buffers of one in-flight batch: device slabs and their page-locked twins, from the
+    library's own allocator (setk_device_alloc / setk_host_alloc)."""
 
-    def __init__(self, torch, dev, in_cap, f32_cap, out_cap):
-        self.torch, self.dev = torch, dev
+    def __init__(self, ctx, in_cap, f32_cap, out_cap):
+        self.ctx = ctx
         self.lock = threading.Lock()
         self.maps = []  # Mapping objects pinned for the batch in flight
         self.in_cap = self.f32_cap = self.out_cap = 0
-        self.h_in = self.d_in = self.d_f32 = self.h_out = self.d_out = None
+        self.d_in = self.d_f32 = self.d_out = 0      # device addresses
+        self.h_in = self.h_out = 0                   # page-locked host addresses
+        self.np_in = self.np_out = None              # ... and their uint8 views
         self.ensure(in_cap, f32_cap, out_cap)
-        self.e_in = torch.cuda.Event()
-        self.e_compute = torch.cuda.Event()
-        self.e_out = torch.cuda.Event()
+        self.e_in = ctx.event_create()
+        self.e_compute = ctx.event_create()
+        self.e_out = ctx.event_create()
 
     def ensure(self, in_cap, f32_cap, out_cap):
-        torch, dev = self.torch, self.dev
+        ctx = self.ctx
         if in_cap > self.in_cap:
-            self.d_in = torch.empty(in_cap, dtype=torch.uint8, device=dev)
-            self.h_in = self.np_in = None  # page-locked twin: made when a payload needs staging
-            self.in_cap = in_cap
+            if self.d_in:
+                ctx.device_free(self.d_in)
+            if self.h_in:
+                self.np_in = None
+                ctx.host_free(self.h_in)
+                self.h_in = 0
+            self.d_in = ctx.device_alloc(in_cap)
+            self.in_cap = in_cap  # page-locked twin: made when a payload needs staging
         if f32_cap > self.f32_cap:
-            self.d_f32 = torch.empty(f32_cap, dtype=torch.uint8, device=dev)
+            if self.d_f32:
+                ctx.device_free(self.d_f32)
+            self.d_f32 = ctx.device_alloc(f32_cap)
             self.f32_cap = f32_cap
         if out_cap > self.out_cap:
-            self.h_out = torch.empty(out_cap, dtype=torch.uint8, pin_memory=True)
-            self.d_out = torch.empty(out_cap, dtype=torch.uint8, device=dev)
-            self.np_out = self.h_out.numpy()
+            if self.d_out:
+                ctx.device_free(self.d_out)
+            if self.h_out:
+                self.np_out = None
+                ctx.host_free(self.h_out)
+            self.h_out, self.np_out = ctx.host_alloc(out_cap)
+            self.d_out = ctx.device_alloc(out_cap)
             self.out_cap = out_cap
-
 
     def staging(self):
         """The page-locked twin of d_in (allocated on first use)."""
         with self.lock:
             if self.np_in is None:
-                self.h_in = self.torch.empty(self.in_cap, dtype=self.torch.uint8, pin_memory=True)
-                self.np_in = self.h_in.numpy()
+                self.h_in, self.np_in = self.ctx.host_alloc(self.in_cap)
             return self.np_in
+
+    def release(self):
+        ctx = self.ctx
+        self.np_in = self.np_out = None
+        for p in (self.d_in, self.d_f32, self.d_out):
+            if p:
+                ctx.device_free(p)
+        for p in (self.h_in, self.h_out):
+            if p:
+                ctx.host_free(p)
+        for e in (self.e_in, self.e_compute, self.e_out):
+            ctx.event_destroy(e)
+        self.d_in = self.d_f32 = self.d_out = self.h_in = self.h_out = 0
 
 
 class StreamPipeline(object):
@@ -278,11 +303,8 @@ class StreamPipeline(object):
 
     def __init__(self, engine, sink, announce=None, batch_utts=32, depth=3, read_threads=None,
                  write_threads=4, slab_mb=0, zero_copy=False, h2d="batch"):
-        import torch
-        self.torch = torch
         self.engine = engine
         self.ctx = engine.ctx
-        self.dev = engine.dev
         self.sink = sink
         self.announce = announce
         self.zero_copy = bool(zero_copy)
@@ -316,9 +338,11 @@ class StreamPipeline(object):
                           t_alloc=0.0, zero_copy_payloads=0, staged_payloads=0)
         self.lock = threading.Lock()
         engine._plan()
-        self.s_in = torch.cuda.Stream(device=self.dev)
-        self.s_compute = torch.cuda.Stream(device=self.dev)
-        self.s_out = torch.cuda.Stream(device=self.dev)
+        # buffers, streams and events come from the library: no torch in this process
+        self.s_in = self.ctx.stream_create()
+        self.s_compute = self.ctx.stream_create()
+        self.s_out = self.ctx.stream_create()
+        self.slots = []
         self.t_first = None
         self.launcher = threading.Thread(target=self._launch_loop, name="setk-launch", daemon=True)
         self.completer = threading.Thread(target=self._complete_loop, name="setk-done", daemon=True)
@@ -382,8 +406,9 @@ class StreamPipeline(object):
             self.slots_made += 1
             grow = 1.25  # head room: later batches of ragged lengths reuse the buffers
             t0 = time.perf_counter()
-            slot = _Slot(self.torch, self.dev, max(int(in_cap * grow), self.min_in),
+            slot = _Slot(self.ctx, max(int(in_cap * grow), self.min_in),
                          int(f32_cap * grow), int(out_cap * grow))
+            self.slots.append(slot)
             with self.lock:
                 self.stats["t_alloc"] += time.perf_counter() - t0
         else:
@@ -433,8 +458,8 @@ class StreamPipeline(object):
     def _to_device(self, payload, slot, off):
         """One payload -> device slab at `off`, enqueued on the copy-in stream."""
         ctx = self.ctx
-        dst = slot.d_in.data_ptr() + off
-        stream = self.s_in.cuda_stream
+        dst = slot.d_in + off
+        stream = self.s_in
         if self.zero_copy and payload.zero_copy_ok():
             fd = os.open(payload.path, os.O_RDONLY)
             try:
@@ -459,7 +484,6 @@ class StreamPipeline(object):
 
     def _read_job(self, job, slot):
         try:
-            self.torch.cuda.set_device(self.dev)
             zc = self._to_device(job.audio, slot, job.off_audio)
             zc += self._to_device(job.mask, slot, job.off_mask)
             n = 2
@@ -474,9 +498,7 @@ class StreamPipeline(object):
 
     # ---- H2D + kernels + D2H (one thread owns the handle) ---------------------------
     def _launch_loop(self):
-        torch = self.torch
         try:
-            torch.cuda.set_device(self.dev)
             while True:
                 item = self.launch_q.get()
                 if item is None:
@@ -501,46 +523,42 @@ class StreamPipeline(object):
             self.done_q.put(None)
 
     def _launch(self, jobs, n_all, slot, used_in, off_status, off_power, out_total):
-        torch, ctx, eng = self.torch, self.ctx, self.engine
+        ctx, eng = self.ctx, self.engine
         # the payload copies were enqueued on the copy-in stream by the reader threads --
         # or the slab goes over in one piece now
         if self.h2d == "batch" and not self.zero_copy:
-            ctx.memcpy_h2d_async(slot.d_in.data_ptr(), slot.staging().ctypes.data, used_in,
-                                 self.s_in.cuda_stream)
-        slot.e_in.record(self.s_in)
+            ctx.memcpy_h2d_async(slot.d_in, slot.staging().ctypes.data, used_in, self.s_in)
+        ctx.event_record(slot.e_in, self.s_in)
         C = jobs[0].C
         has_itf = jobs[0].itf is not None
-        base_in, base_f32, base_out = (slot.d_in.data_ptr(), slot.d_f32.data_ptr(),
-                                       slot.d_out.data_ptr())
-        with torch.cuda.stream(self.s_compute):
-            self.s_compute.wait_event(slot.e_in)
-            stream = self.s_compute.cuda_stream
-            pcm = [j for j in jobs if j.pcm16]
-            if pcm:
-                # int16 frames -> float32 C x N; sum(x0^2) of the k-th converted
-                # utterance lands at off_power + 8 k of the out-slab (log line only)
-                for k, j in enumerate(pcm):
-                    j.pw_idx = k
-                ctx.pcm16_to_float_batch(C, [base_in + j.off_audio for j in pcm],
-                                         [j.N for j in pcm], [base_f32 + j.off_f32 for j in pcm],
-                                         power0=base_out + off_power, stream=stream)
-            aptr = [(base_f32 + j.off_f32) if j.pcm16 else (base_in + j.off_audio) for j in jobs]
-            mptr = [base_in + j.off_mask for j in jobs]
-            iptr = [base_in + j.off_itf for j in jobs] if has_itf else None
-            wptr = [base_out + j.off_out for j in jobs]
-            kind = eng.opts_kw["kind"]
-            if has_itf and kind == _ffi.BF_MPDR:
-                iptr = None  # plain MPDR never reads the interferer mask
-            flags = eng.base_flags | _ffi.FLAG_OUT_PCM16 | (0 if has_itf else _ffi.FLAG_CLAMP_MASK)
-            opts = _ffi.BfOpts(flags=flags, **eng.opts_kw)
-            # status of job i at off_status + 4 * i (positions within `jobs`)
-            ctx.enhance_batch(opts, C, aptr, [j.N for j in jobs], mptr, iptr, wptr,
-                              stream=stream, status_ptr=base_out + off_status)
-            slot.e_compute.record(self.s_compute)
-        with torch.cuda.stream(self.s_out):
-            self.s_out.wait_event(slot.e_compute)
-            slot.h_out[:out_total].copy_(slot.d_out[:out_total], non_blocking=True)
-            slot.e_out.record(self.s_out)
+        base_in, base_f32, base_out = slot.d_in, slot.d_f32, slot.d_out
+        ctx.stream_wait_event(self.s_compute, slot.e_in)
+        stream = self.s_compute
+        pcm = [j for j in jobs if j.pcm16]
+        if pcm:
+            # int16 frames -> float32 C x N; sum(x0^2) of the k-th converted
+            # utterance lands at off_power + 8 k of the out-slab (log line only)
+            for k, j in enumerate(pcm):
+                j.pw_idx = k
+            ctx.pcm16_to_float_batch(C, [base_in + j.off_audio for j in pcm],
+                                     [j.N for j in pcm], [base_f32 + j.off_f32 for j in pcm],
+                                     power0=base_out + off_power, stream=stream)
+        aptr = [(base_f32 + j.off_f32) if j.pcm16 else (base_in + j.off_audio) for j in jobs]
+        mptr = [base_in + j.off_mask for j in jobs]
+        iptr = [base_in + j.off_itf for j in jobs] if has_itf else None
+        wptr = [base_out + j.off_out for j in jobs]
+        kind = eng.opts_kw["kind"]
+        if has_itf and kind == _ffi.BF_MPDR:
+            iptr = None  # plain MPDR never reads the interferer mask
+        flags = eng.base_flags | _ffi.FLAG_OUT_PCM16 | (0 if has_itf else _ffi.FLAG_CLAMP_MASK)
+        opts = _ffi.BfOpts(flags=flags, **eng.opts_kw)
+        # status of job i at off_status + 4 * i (positions within `jobs`)
+        ctx.enhance_batch(opts, C, aptr, [j.N for j in jobs], mptr, iptr, wptr,
+                          stream=stream, status_ptr=base_out + off_status)
+        ctx.event_record(slot.e_compute, self.s_compute)
+        ctx.stream_wait_event(self.s_out, slot.e_compute)
+        ctx.memcpy_d2h_async(slot.h_out, slot.d_out, out_total, self.s_out)
+        ctx.event_record(slot.e_out, self.s_out)
 
     # ---- completion: wait for D2H, hand the samples to the writers ------------------
     def _complete_loop(self):
@@ -549,7 +567,6 @@ class StreamPipeline(object):
         the batch's slot still returns to the pool and the following batches are still
         consumed -- the launcher can always finish and close() can always join,
         independently of how depth and the queue sizes are chosen."""
-        self.torch.cuda.set_device(self.dev)
         while True:
             item = self.done_q.get()
             if item is None:
@@ -563,7 +580,7 @@ class StreamPipeline(object):
             finally:
                 try:
                     if not launched:
-                        self.s_in.synchronize()  # copies of a batch that never launched
+                        self.ctx.stream_synchronize(self.s_in)  # copies of a batch that never launched
                     for m in slot.maps:
                         m.close(self.ctx)
                 except BaseException as e:  # pragma: no cover
@@ -575,7 +592,7 @@ class StreamPipeline(object):
     def _complete_batch(self, batch, slot, off_status, off_power, launched):
         t0 = time.perf_counter()
         if launched:
-            slot.e_out.synchronize()
+            self.ctx.event_synchronize(slot.e_out)
         t1 = time.perf_counter()
         good = [j for j in batch if j.error is None]
         status = np.frombuffer(slot.np_out[off_status:off_status + 4 * len(good)], dtype=np.int32)
@@ -618,6 +635,7 @@ class StreamPipeline(object):
             self.completer.join()
             self.readers.shutdown()
             self.writers.shutdown()
+            self._release()
         if self.exc:
             raise self.exc
         st = dict(self.stats)
@@ -626,6 +644,21 @@ class StreamPipeline(object):
         st["depth"] = self.depth
         st["batch_utts"] = self.batch_utts
         return self.num_done, st
+
+
+    def _release(self):
+        """Everything has drained: give the slabs, events and streams back."""
+        try:
+            for st in (self.s_in, self.s_compute, self.s_out):
+                self.ctx.stream_synchronize(st)
+            for slot in self.slots:
+                slot.release()
+            for st in (self.s_in, self.s_compute, self.s_out):
+                self.ctx.stream_destroy(st)
+        except Exception as e:  # the original failure, if any, is the one to report
+            if self.exc is None:
+                self.exc = e
+        self.slots = []
 
 
 # ----------------------------------------------------------------------------

@@ -223,6 +223,10 @@ def run_offline(args, shard):
     device = None if args.device < 0 else args.device
     if device is None and shard.world > 1:
         device = shard.device
+    if _fast_path_ok(args) and shard.world == 1:
+        # the streaming pipeline gets its buffers, streams and events from the library: a
+        # single-process run never imports torch (0.9 s of a 2 s run on 192 utterances)
+        _ffi.TORCH_FREE = True
     engine = BatchEnhancer(beamformer=args.beamformer, frame_len=args.frame_len,
                            frame_hop=args.frame_hop, center=bool(args.center),
                            round_power_of_two=bool(args.round_power_of_two), window=args.window,

@@ -184,8 +184,32 @@ def wpe(ctx, C, T, taps, delay):
         pass
 
 
+def runtime_helpers(ctx):
+    """setk_device_alloc / host_alloc / streams / events: what the streaming pipeline runs on."""
+    d = ctx.device_alloc(4096)
+    h, view = ctx.host_alloc(4096)
+    view[:] = 7
+    s1, s2 = ctx.stream_create(), ctx.stream_create()
+    e = ctx.event_create()
+    ctx.memcpy_h2d_async(d, h, 4096, s1)
+    ctx.event_record(e, s1)
+    ctx.stream_wait_event(s2, e)
+    view[:] = 0
+    ctx.memcpy_d2h_async(h, d, 4096, s2)
+    ctx.event_synchronize(e)
+    ctx.stream_synchronize(s2)
+    assert int(view.sum()) == 7 * 4096
+    ctx.event_destroy(e)
+    ctx.stream_destroy(s1)
+    ctx.stream_destroy(s2)
+    ctx.host_free(h)
+    ctx.device_free(d)
+    expect(ValueError, ctx.device_alloc, 0)
+
+
 def main():
     ctx = _ffi.Context(0)
+    runtime_helpers(ctx)
     if "--selftest-overflow" in sys.argv:
         # the sanitizer must be live: an output buffer one matrix short -> heap-buffer-overflow
         ctx.covar(cplx(2, 8, F), np.ones((8, F), np.float32), 2, 8, F, np.empty((F - 1, 2, 2), np.complex64))

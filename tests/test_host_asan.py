@@ -58,3 +58,32 @@ def test_every_entry_point_is_clean_under_asan_ubsan(asan_env):
     assert rec["violations"] == 0, rec
     assert rec["launches"] > 500 and rec["copies"] > 1000
     assert rec["live_allocations"] == 0, "device memory still held after setk_destroy"
+
+
+def test_streaming_cli_host_side_under_asan(asan_env, tmp_path):
+    """The whole host pipeline of apply_adaptive_beamformer.py (table readers, reader threads,
+    page-locked slabs, copy / compute / copy-out streams, writer threads) against the stand-in:
+    it needs no torch and no GPU, so it runs here under ASAN + UBSan.  The kernels do nothing,
+    the waveforms are silence of the right length."""
+    import numpy as np
+    import scipy.io.wavfile
+    from setk_amd.libs import wavio
+    rng = np.random.default_rng(0)
+    td = str(tmp_path)
+    lens = [16000, 23456, 8000, 30011, 16000, 12345, 4000]
+    with open(f"{td}/wav.scp", "w") as ws, open(f"{td}/mask.scp", "w") as ms:
+        for i, n in enumerate(lens):
+            x = (rng.standard_normal((n, 4)) * 1000).astype(np.int16)
+            wavio.write_pcm16(f"{td}/u{i}.wav", x, 16000)
+            np.save(f"{td}/m{i}.npy", rng.random((1 + n // 256, 257)).astype(np.float32))
+            ws.write(f"u{i} {td}/u{i}.wav\n")
+            ms.write(f"u{i} {td}/m{i}.npy\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py"),
+                        "--mask-format", "numpy", "--batch-utts", "3", f"{td}/wav.scp", f"{td}/mask.scp",
+                        f"{td}/out"], capture_output=True, text=True, env=asan_env, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    assert "Processed 7 utterances out of 7" in r.stderr
+    for i, n in enumerate(lens):
+        sr, y = scipy.io.wavfile.read(f"{td}/out/u{i}.wav")
+        assert sr == 16000 and y.dtype == np.int16 and y.shape == (256 * (n // 256),)

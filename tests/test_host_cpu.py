@@ -550,3 +550,18 @@ def test_permu_aligner_realigns_flipped_bins():
         m3 = rng.random((3, 40, 257))
         m3 /= m3.sum(0, keepdims=True)
         assert np.array_equal(permu_aligner(m3.copy()), rh.load().cluster.permu_aligner(m3.copy()))
+
+
+def test_cosine_windows_equal_scipy_bit_for_bit():
+    """libs.utils builds hann / hamming / blackman itself (no scipy.signal import on the CLI's
+    start-up path): the same operations as scipy.signal.windows.general_cosine, same bits."""
+    import scipy.signal
+    from setk_amd.libs.utils import stft_window
+    for name in ("hann", "hamming", "blackman"):
+        for L in (2, 3, 25, 400, 512, 1024):
+            ref = scipy.signal.get_window(name, L, fftbins=True).astype(np.float32)
+            assert np.array_equal(stft_window(name, L), ref), (name, L)
+    assert np.array_equal(stft_window("sqrthann", 512),
+                          (scipy.signal.windows.hann(512, sym=False)**0.5).astype(np.float32))
+    assert np.array_equal(stft_window("bartlett", 400),
+                          scipy.signal.get_window("bartlett", 400, fftbins=True).astype(np.float32))

@@ -1,4 +1,4 @@
-// A host-memory stand-in for the 28 HIP runtime entry points libsetk_hip.so imports, for the
+// A host-memory stand-in for the 34 HIP runtime entry points libsetk_hip.so imports, for the
 // sanitizer test of the library's HOST side (tools/hoststub/build.sh, tests/test_host_asan.py).
 // Test infrastructure only: nothing in the product links or loads it.
 //
@@ -168,6 +168,29 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* at, const void* p) {
     memset(at, 0, sizeof *at);
     at->type = hipMemoryTypeDevice;
     at->devicePointer = const_cast<void*>(p);
+    return hipSuccess;
+}
+
+// page-locked host memory is ordinary (ASAN-tracked) heap here
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) {
+    *p = calloc(1, n ? n : 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipHostFree(void* p) {
+    free(p);
+    return hipSuccess;
+}
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+    *s = reinterpret_cast<hipStream_t>(new int(0));
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s) {
+    delete reinterpret_cast<int*>(s);
+    return hipSuccess;
+}
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t e, unsigned) { return e ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) {
+    *e = reinterpret_cast<hipEvent_t>(new int(0));
     return hipSuccess;
 }
 
