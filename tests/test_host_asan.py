@@ -1,6 +1,6 @@
 """The HOST side of libsetk_hip.so under AddressSanitizer + UBSan, no GPU: the library is
 rebuilt host-only (hipcc --cuda-host-only) against tools/hoststub/hip_stub.cpp, a host-memory
-stand-in for the 28 HIP entry points it imports whose kernel launches only validate their
+stand-in for the 34 HIP entry points it imports whose kernel launches only validate their
 geometry and whose copies bound-check the device side; tests/host_asan_driver.py then calls
 every entry point of include/setk_hip.h at the shapes the GPU tests use (1-16 channels, ragged
 batches, 30 s utterances, the streaming and bin-resident CGMM paths, WPE)."""
