@@ -479,19 +479,34 @@ class CgmmEstimator(object):
         return masks
 
     def estimate(self, utts):
-        """utts: list of C x N float32 numpy arrays -> list of T x F float32 masks."""
+        """utts: list of C x N float32 numpy arrays or Pcm16Frames (16-bit frames as stored:
+        converted on the device, one launch per group) -> list of T x F float32 masks, one
+        download per group."""
+        torch, ctx, dev = self.torch, self.ctx, self.dev
         out = [None] * len(utts)
         groups = {}
         for i, s in enumerate(utts):
-            s = np.asarray(s)
-            groups.setdefault(1 if s.ndim == 1 else s.shape[0], []).append(i)
+            groups.setdefault(_channels_and_size(s)[0], []).append(i)
         for C, idx in groups.items():
-            audio = []
+            audio, pcm = [], []
             for i in idx:
-                s = np.ascontiguousarray(utts[i], dtype=np.float32)
-                audio.append(self.torch.from_numpy(s[None] if s.ndim == 1 else s).to(self.dev))
-            for i, m in zip(idx, self.estimate_device(audio)):
-                out[i] = m.cpu().numpy()
+                s = utts[i]
+                if isinstance(s, Pcm16Frames):
+                    a = torch.empty((C, s.frames.shape[0]), dtype=torch.float32, device=dev)
+                    pcm.append((torch.from_numpy(s.frames).to(dev), a))
+                else:
+                    s = np.ascontiguousarray(s, dtype=np.float32)
+                    a = torch.from_numpy(s[None] if s.ndim == 1 else s).to(dev)
+                audio.append(a)
+            if pcm:
+                ctx.pcm16_to_float_batch(C, [p.data_ptr() for p, _ in pcm], [a.shape[1] for _, a in pcm],
+                                         [a.data_ptr() for _, a in pcm])
+            masks = self.estimate_device(audio)
+            host = torch.cat([m.reshape(-1) for m in masks]).cpu().numpy()
+            off = 0
+            for i, m in zip(idx, masks):
+                out[i] = host[off:off + m.numel()].reshape(m.shape)
+                off += m.numel()
         return out
 
 

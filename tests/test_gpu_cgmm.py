@@ -292,3 +292,20 @@ def test_bin_em_long_utterance_with_init_mask_and_alpha():
     got = CgmmTrainer(obs, 2, update_alpha=True).train(5)
     assert np.mean(np.abs(got - ref)) < 1e-4
     assert np.allclose(got.sum(0), 1.0, atol=1e-5)
+
+
+def test_estimator_pcm16_frames_equal_float_input():
+    """CgmmEstimator.estimate with the 16-bit frames as stored (converted on the device, what
+    estimate_cgmm_masks.py hands over) == the same samples decoded on the host, bit for bit;
+    mixed channel counts and lengths in one call."""
+    from setk_amd.engine import CgmmEstimator, Pcm16Frames
+    est = CgmmEstimator(num_iters=4, **STFT_KW)
+    utts_f, utts_q = [], []
+    for u, (C, N) in enumerate(((4, 30000), (6, 20011), (4, 16000))):
+        q = np.round(o.synth_utterance(60 + u, C, N) * 16000.0).astype(np.int16)   # C x N
+        utts_q.append(Pcm16Frames(np.ascontiguousarray(q.T)))
+        utts_f.append(q.astype(np.float32) / 32768.0)
+    a = est.estimate(utts_f)
+    b = est.estimate(utts_q)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and x.dtype == np.float32 and np.array_equal(x, y)
