@@ -60,6 +60,12 @@ struct setk_context {
     // stream of the most recent call (arena_reset)
     hipStream_t last_stream = nullptr;
     bool have_last_stream = false;
+    // page-locked staging of the small host tables (h2d_small)
+    char* pin_base = nullptr;
+    size_t pin_head = 0;
+    bool pin_failed = false;
+    std::vector<hipEvent_t> pin_live;  // one per copy issued out of the buffer since the last lap
+    std::vector<hipEvent_t> pin_free;
     // tunables
     int p1_items = 1024;
     int p2_items = 1024;
@@ -125,6 +131,56 @@ void* arena_alloc(setk_handle_t h, size_t bytes) {
     return nb.ptr;
 }
 
+// Small host tables (descriptors, pointer lists, argument blocks) go to the device through a
+// page-locked buffer of the handle.  hipMemcpyAsync from PAGEABLE memory does not return
+// before the copy has run, i.e. before everything queued on the stream ahead of it has -- in
+// the streaming pipeline that is the 300 MB slab transfer the compute stream is waiting for,
+// ~6 ms per batch during which the launching thread could not queue the next batch.  From the
+// page-locked buffer the copy is queued and the call returns.  The buffer is used linearly;
+// when it is full, every copy issued out of it is waited for (an event each) and it starts
+// over.  Tables larger than a quarter of it, or a failed allocation, take the pageable path.
+constexpr size_t kPinCap = 8u << 20;
+
+hipError_t h2d_small(setk_handle_t h, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (!bytes) return hipSuccess;
+    if (bytes > kPinCap / 4 || h->pin_failed)
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+    if (!h->pin_base) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, kPinCap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            h->pin_failed = true;
+            return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+        }
+        h->pin_base = static_cast<char*>(p);
+    }
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (h->pin_head + need > kPinCap || h->pin_live.size() >= 4096) {
+        for (hipEvent_t e : h->pin_live) {
+            (void)hipEventSynchronize(e);
+            h->pin_free.push_back(e);
+        }
+        h->pin_live.clear();
+        h->pin_head = 0;
+    }
+    char* p = h->pin_base + h->pin_head;
+    h->pin_head += need;
+    memcpy(p, src, bytes);
+    hipError_t e = hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    hipEvent_t ev = nullptr;
+    if (!h->pin_free.empty()) {
+        ev = h->pin_free.back();
+        h->pin_free.pop_back();
+    } else {
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    e = hipEventRecord(ev, s);
+    h->pin_live.push_back(ev);
+    return e;
+}
+
 // Stage an input: device pointers pass through, host data is copied.
 template <typename T>
 int stage_in(setk_handle_t h, const T* src, size_t count, hipStream_t s, const T** out) {
@@ -168,15 +224,14 @@ int copy_back(setk_handle_t h, const OutBuf& ob, hipStream_t s) {
     return SETK_OK;
 }
 
-// Descriptor tables are built in ordinary (pageable) host vectors that die when
-// the entry point returns.  hipMemcpyAsync from pageable memory is staged by the
-// runtime before it returns (the documented behaviour of cudaMemcpyAsync /
-// hipMemcpyAsync for non-page-locked sources), so the source may be released;
-// only the device side of the copy is asynchronous.
+// Descriptor tables are built in ordinary host vectors that die when the entry point
+// returns: h2d_small copies them into the handle's page-locked buffer first (or, for a large
+// table, lets the runtime stage the pageable source before hipMemcpyAsync returns), so the
+// source may be released either way.
 int upload(setk_handle_t h, const void* src, size_t bytes, hipStream_t s, void** out) {
     void* d = arena_alloc(h, bytes);
     if (!d) return fail(h, SETK_ERR_NOMEM, "device arena allocation failed");
-    HIP_TRY(h, hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, h2d_small(h, d, src, bytes, s));
     *out = d;
     return SETK_OK;
 }
@@ -283,6 +338,12 @@ int setk_destroy(setk_handle_t h) {
     if (h->d_desc) (void)hipFree(h->d_desc);
     for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
     for (auto& e : h->ev_used) (void)hipEventDestroy(e);
+    for (auto& e : h->pin_live) {
+        (void)hipEventSynchronize(e);
+        (void)hipEventDestroy(e);
+    }
+    for (auto& e : h->pin_free) (void)hipEventDestroy(e);
+    if (h->pin_base) (void)hipHostFree(h->pin_base);
     delete h;
     return SETK_OK;
 }
@@ -1763,8 +1824,10 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
             HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_desc), blob.size() * 2));
             h->d_desc_cap = blob.size() * 2;
         }
-        HIP_TRY(h, hipMemcpyAsync(h->d_desc, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(h, hipStreamSynchronize(s));
+        // ordered on the stream behind the previous call's kernels (which read the old
+        // contents) and ahead of this call's; a previous call on ANOTHER stream was drained
+        // by arena_reset.  No host synchronisation: the launching thread runs ahead.
+        HIP_TRY(h, h2d_small(h, h->d_desc, blob.data(), blob.size(), s));
         h->desc_cache.swap(blob);
     }
     const UttDesc* d_uds = reinterpret_cast<const UttDesc*>(h->d_desc);

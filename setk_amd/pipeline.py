@@ -36,6 +36,7 @@ import mmap
 import os
 import queue
 import struct
+import sys
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -550,11 +551,14 @@ class StreamPipeline(object):
 
     def _launch(self, jobs, n_all, slot, used_in, off_status, off_power, out_total):
         ctx, eng = self.ctx, self.engine
+        dbg = os.environ.get("SETK_PIPE_DEBUG")
+        tt = [time.perf_counter()]
         # the payload copies were enqueued on the copy-in stream by the reader threads --
         # or the slab goes over in one piece now
         if self.h2d == "batch" and not self.zero_copy:
             ctx.memcpy_h2d_async(slot.d_in, slot.staging().ctypes.data, used_in, self.s_in)
         ctx.event_record(slot.e_in, self.s_in)
+        tt.append(time.perf_counter())
         C = jobs[0].C
         has_itf = jobs[0].itf is not None
         base_in, base_f32, base_out = slot.d_in, slot.d_f32, slot.d_out
@@ -569,6 +573,7 @@ class StreamPipeline(object):
             ctx.pcm16_to_float_batch(C, [base_in + j.off_audio for j in pcm],
                                      [j.N for j in pcm], [base_f32 + j.off_f32 for j in pcm],
                                      power0=base_out + off_power, stream=stream)
+        tt.append(time.perf_counter())
         aptr = [(base_f32 + j.off_f32) if j.pcm16 else (base_in + j.off_audio) for j in jobs]
         mptr = [base_in + j.off_mask for j in jobs]
         iptr = [base_in + j.off_itf for j in jobs] if has_itf else None
@@ -581,10 +586,15 @@ class StreamPipeline(object):
         # status of job i at off_status + 4 * i (positions within `jobs`)
         ctx.enhance_batch(opts, C, aptr, [j.N for j in jobs], mptr, iptr, wptr,
                           stream=stream, status_ptr=base_out + off_status)
+        tt.append(time.perf_counter())
         ctx.event_record(slot.e_compute, self.s_compute)
         ctx.stream_wait_event(self.s_out, slot.e_compute)
         ctx.memcpy_d2h_async(slot.h_out, slot.d_out, out_total, self.s_out)
         ctx.event_record(slot.e_out, self.s_out)
+        tt.append(time.perf_counter())
+        if dbg:
+            print("launch ms: h2d %.2f pcm %.2f enhance %.2f d2h %.2f" % tuple(
+                1e3 * (b - a) for a, b in zip(tt, tt[1:])), file=sys.stderr)
 
     # ---- completion: wait for D2H, hand the samples to the writers ------------------
     def _complete_loop(self):

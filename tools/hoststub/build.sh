@@ -7,9 +7,16 @@
 # /opt/rocm/lib/asan, which is not installed -- tools/asan_build.sh keeps that recipe.)
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
-OUT="$ROOT/_abl/hostasan"; mkdir -p "$OUT"
+# PLAIN=1: the same without the sanitizers (-O2) -> _abl/libsetk_hoststub.so, for profiling the
+# host pipeline on a machine without a GPU (kernels do nothing, copies are memcpy)
+if [ -n "$PLAIN" ]; then
+  OUT="$ROOT/_abl/hoststub"; LIBOUT="$ROOT/_abl/libsetk_hoststub.so"; SAN="-O2"
+else
+  OUT="$ROOT/_abl/hostasan"; LIBOUT="$ROOT/_abl/libsetk_hostasan.so"
+  SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -shared-libsan"
+fi
+mkdir -p "$OUT"
 CLANG=/opt/rocm/lib/llvm/bin/clang++
-SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -shared-libsan"
 pids=""
 for u in pass1 pass2 solve modular cgmm cgmm_bin wpe capi; do
   src="$ROOT/setk_amd/csrc/$u.hip"
@@ -26,5 +33,5 @@ $CLANG -x c++ -std=c++17 -O1 -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include $S
 rm -f "$OUT/fatbin_dummies.o"
 nm --undefined-only "$OUT"/*.o | awk '/__hip_fatbin_/ {print "char " $2 "[16];"}' | sort -u > "$OUT/fatbin_dummies.c"
 /opt/rocm/lib/llvm/bin/clang -fPIC -c "$OUT/fatbin_dummies.c" -o "$OUT/fatbin_dummies.o"
-$CLANG -shared -fPIC $SAN -o "$ROOT/_abl/libsetk_hostasan.so" "$OUT"/*.o
-echo "_abl/libsetk_hostasan.so"
+$CLANG -shared -fPIC $SAN -o "$LIBOUT" "$OUT"/*.o
+echo "$LIBOUT"
