@@ -139,10 +139,19 @@ void* arena_alloc(setk_handle_t h, size_t bytes) {
 // page-locked buffer the copy is queued and the call returns.  The buffer is used linearly;
 // when it is full, every copy issued out of it is waited for (an event each) and it starts
 // over.  Tables larger than a quarter of it, or a failed allocation, take the pageable path.
-constexpr size_t kPinCap = 8u << 20;
+size_t pin_cap() {
+    // 8 MB; SETK_PIN_CAP_KB shrinks it so that tests see the buffer wrap
+    static const size_t cap = [] {
+        const char* e = getenv("SETK_PIN_CAP_KB");
+        const long kb = e ? atol(e) : 0;
+        return kb >= 4 ? (size_t)kb << 10 : (size_t)8 << 20;
+    }();
+    return cap;
+}
 
 hipError_t h2d_small(setk_handle_t h, void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (!bytes) return hipSuccess;
+    const size_t kPinCap = pin_cap();
     if (bytes > kPinCap / 4 || h->pin_failed)
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
     if (!h->pin_base) {

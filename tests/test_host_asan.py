@@ -32,7 +32,9 @@ def asan_env():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     env = dict(os.environ)
+    # (a 64 KB table-staging buffer: the library's page-locked ring wraps many times in a run)
     env.update(LD_PRELOAD=rt, SETK_LIB=os.path.join(ROOT, "_abl", "libsetk_hostasan.so"),
+               SETK_PIN_CAP_KB="64",
                ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:exitcode=99",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     return env
