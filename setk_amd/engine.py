@@ -414,13 +414,12 @@ class CgmmEstimator(object):
 
     def __init__(self, frame_len=512, frame_hop=256, center=True, round_power_of_two=True,
                  window="hann", num_iters=20, device=None, ctx=None, update_alpha=False):
-        import torch
-        self.torch = torch
         self.update_alpha = bool(update_alpha)
-        if not torch.cuda.is_available():
-            raise _ffi.SetkError("CgmmEstimator needs an MI355X (no CPU fallback)")
+        # no GPU / no library: setk_create fails here, loudly.  torch is the plumbing of
+        # estimate_device() (tensors in, tensors out); estimate() brings its own buffers.
         self.ctx = ctx or _ffi.default_context(device)
-        self.dev = torch.device("cuda", self.ctx.device)
+        self._torch = None
+        self._bufs = None
         n_fft = nextpow2(frame_len) if round_power_of_two else frame_len
         self.stft = dict(frame_len=frame_len, frame_hop=frame_hop, n_fft=n_fft, center=center,
                          window=stft_window(window, frame_len))
@@ -428,6 +427,19 @@ class CgmmEstimator(object):
         self.num_iters = num_iters
         import os
         self.force_streaming = os.environ.get("SETK_CGMM_STREAMING", "") not in ("", "0")
+
+    @property
+    def torch(self):
+        if self._torch is None:
+            import torch
+            if not torch.cuda.is_available():
+                raise _ffi.SetkError("CgmmEstimator needs an MI355X (no CPU fallback)")
+            self._torch = torch
+        return self._torch
+
+    @property
+    def dev(self):
+        return self.torch.device("cuda", self.ctx.device)
 
     def _plan(self):
         s = self.stft
@@ -480,34 +492,147 @@ class CgmmEstimator(object):
 
     def estimate(self, utts):
         """utts: list of C x N float32 numpy arrays or Pcm16Frames (16-bit frames as stored:
-        converted on the device, one launch per group) -> list of T x F float32 masks, one
-        download per group."""
-        torch, ctx, dev = self.torch, self.ctx, self.dev
+        converted on the device) -> list of T x F float32 masks.  Per channel count: the
+        samples go up in ONE copy out of a page-locked slab, the masks come down in one; the
+        buffers, the stream and the copies are the library's (no torch in this path).  Shapes
+        the one-call estimator does not take (n_fft != 512, more than 8 channels, a bin that
+        does not fit a CU) go through estimate_device()."""
         out = [None] * len(utts)
         groups = {}
         for i, s in enumerate(utts):
             groups.setdefault(_channels_and_size(s)[0], []).append(i)
         for C, idx in groups.items():
-            audio, pcm = [], []
-            for i in idx:
-                s = utts[i]
-                if isinstance(s, Pcm16Frames):
-                    a = torch.empty((C, s.frames.shape[0]), dtype=torch.float32, device=dev)
-                    pcm.append((torch.from_numpy(s.frames).to(dev), a))
-                else:
-                    s = np.ascontiguousarray(s, dtype=np.float32)
-                    a = torch.from_numpy(s[None] if s.ndim == 1 else s).to(dev)
-                audio.append(a)
-            if pcm:
-                ctx.pcm16_to_float_batch(C, [p.data_ptr() for p, _ in pcm], [a.shape[1] for _, a in pcm],
-                                         [a.data_ptr() for _, a in pcm])
-            masks = self.estimate_device(audio)
-            host = torch.cat([m.reshape(-1) for m in masks]).cpu().numpy()
-            off = 0
-            for i, m in zip(idx, masks):
-                out[i] = host[off:off + m.numel()].reshape(m.shape)
-                off += m.numel()
+            if self.stft["n_fft"] != 512 or C > 8 or self.force_streaming:
+                self._estimate_torch(utts, C, idx, out)
+                continue
+            try:
+                self._estimate_native(utts, C, idx, out)
+            except _ffi.SetkUnsupported:
+                self._estimate_torch(utts, C, idx, out)
         return out
+
+    def _estimate_torch(self, utts, C, idx, out):
+        torch, ctx, dev = self.torch, self.ctx, self.dev
+        audio, pcm = [], []
+        for i in idx:
+            s = utts[i]
+            if isinstance(s, Pcm16Frames):
+                a = torch.empty((C, s.frames.shape[0]), dtype=torch.float32, device=dev)
+                pcm.append((torch.from_numpy(s.frames).to(dev), a))
+            else:
+                s = np.ascontiguousarray(s, dtype=np.float32)
+                a = torch.from_numpy(s[None] if s.ndim == 1 else s).to(dev)
+            audio.append(a)
+        if pcm:
+            ctx.pcm16_to_float_batch(C, [p.data_ptr() for p, _ in pcm], [a.shape[1] for _, a in pcm],
+                                     [a.data_ptr() for _, a in pcm])
+        masks = self.estimate_device(audio)
+        host = torch.cat([m.reshape(-1) for m in masks]).cpu().numpy()
+        off = 0
+        for i, m in zip(idx, masks):
+            out[i] = host[off:off + m.numel()].reshape(m.shape)
+            off += m.numel()
+
+    def _buffers(self, n_in, n_f32, n_out):
+        """Grow-only slabs: page-locked input / output twins and the device side."""
+        ctx = self.ctx
+        b = self._bufs or dict(cap=(0, 0, 0), h_in=0, np_in=None, d_in=0, d_f32=0, h_out=0,
+                               np_out=None, d_out=0, stream=ctx.stream_create())
+        cap = b["cap"]
+        if n_in > cap[0]:
+            b["np_in"] = None
+            if b["h_in"]:
+                ctx.host_free(b["h_in"])
+                ctx.device_free(b["d_in"])
+            n = int(n_in * 1.25)
+            b["h_in"], b["np_in"] = ctx.host_alloc(n)
+            b["d_in"] = ctx.device_alloc(n)
+            cap = (n, cap[1], cap[2])
+        if n_f32 > cap[1]:
+            if b["d_f32"]:
+                ctx.device_free(b["d_f32"])
+            n = int(n_f32 * 1.25)
+            b["d_f32"] = ctx.device_alloc(n)
+            cap = (cap[0], n, cap[2])
+        if n_out > cap[2]:
+            b["np_out"] = None
+            if b["h_out"]:
+                ctx.host_free(b["h_out"])
+                ctx.device_free(b["d_out"])
+            n = int(n_out * 1.25)
+            b["h_out"], b["np_out"] = ctx.host_alloc(n)
+            b["d_out"] = ctx.device_alloc(n)
+            cap = (cap[0], cap[1], n)
+        b["cap"] = cap
+        self._bufs = b
+        return b
+
+    def close(self):
+        """Give the slabs of estimate() back (also done when the estimator is collected)."""
+        b, self._bufs = self._bufs, None
+        if b:
+            ctx = self.ctx
+            ctx.stream_synchronize(b["stream"])
+            b["np_in"] = b["np_out"] = None
+            for k in ("h_in", "h_out"):
+                if b[k]:
+                    ctx.host_free(b[k])
+            for k in ("d_in", "d_f32", "d_out"):
+                if b[k]:
+                    ctx.device_free(b[k])
+            ctx.stream_destroy(b["stream"])
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _estimate_native(self, utts, C, idx, out):
+        ctx, F = self.ctx, self.num_bins
+        self._plan()
+        al = lambda v: (v + 255) & ~255  # noqa: E731
+        off_in, off_f32, off_out, n_in, n_f32, n_out = [], [], [], 0, 0, 0
+        for i in idx:
+            s = utts[i]
+            pcm = isinstance(s, Pcm16Frames)
+            N = s.frames.shape[0] if pcm else _channels_and_size(s)[1] // C
+            off_in.append(n_in)
+            n_in = al(n_in + (2 if pcm else 4) * C * N)
+            off_f32.append(n_f32)
+            if pcm:
+                n_f32 = al(n_f32 + 4 * C * N)
+            off_out.append(n_out)
+            n_out = al(n_out + 4 * ctx.num_frames(N) * F)
+        b = self._buffers(max(n_in, 256), max(n_f32, 256), max(n_out, 256))
+        st = b["stream"]
+        ctx.stream_synchronize(st)  # the slabs of the previous call are free again
+        aptr, ns, pcm_jobs = [], [], []
+        for k, i in enumerate(idx):
+            s = utts[i]
+            if isinstance(s, Pcm16Frames):
+                N = s.frames.shape[0]
+                b["np_in"][off_in[k]:off_in[k] + 2 * C * N] = np.frombuffer(s.frames, dtype=np.uint8)
+                pcm_jobs.append((b["d_in"] + off_in[k], N, b["d_f32"] + off_f32[k]))
+                aptr.append(b["d_f32"] + off_f32[k])
+            else:
+                a = np.ascontiguousarray(s, dtype=np.float32)
+                N = a.size // C
+                b["np_in"][off_in[k]:off_in[k] + a.nbytes] = np.frombuffer(a, dtype=np.uint8)
+                aptr.append(b["d_in"] + off_in[k])
+            ns.append(N)
+        ctx.memcpy_h2d_async(b["d_in"], b["h_in"], n_in, st)
+        if pcm_jobs:
+            ctx.pcm16_to_float_batch(C, [p for p, _, _ in pcm_jobs], [n for _, n, _ in pcm_jobs],
+                                     [o for _, _, o in pcm_jobs], stream=st)
+        ctx.cgmm_estimate_batch(C, aptr, ns, self.num_iters, None, [b["d_out"] + o for o in off_out],
+                                stream=st, update_alpha=self.update_alpha)
+        ctx.memcpy_d2h_async(b["h_out"], b["d_out"], n_out, st)
+        ctx.stream_synchronize(st)
+        for k, i in enumerate(idx):
+            T = ctx.num_frames(ns[k])
+            out[i] = np.frombuffer(b["np_out"][off_out[k]:off_out[k] + 4 * T * F],
+                                   dtype=np.float32).reshape(T, F).copy()
 
 
 class BatchDereverb(object):

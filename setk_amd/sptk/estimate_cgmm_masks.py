@@ -96,6 +96,9 @@ def run_batched(args, shard):
     """Fast path: waves in, masks out, STFT + EM for a batch of utterances on the GPU."""
     from setk_amd.libs.data_handler import WaveReader
     reader = WaveReader(args.wav_scp)
+    if shard.world == 1:
+        # CgmmEstimator.estimate brings its own buffers and stream: no torch in this process
+        _ffi.TORCH_FREE = True
     est = CgmmEstimator(frame_len=args.frame_len, frame_hop=args.frame_hop,
                         center=bool(args.center), round_power_of_two=True, window=args.window,
                         num_iters=args.num_iters, update_alpha=bool(args.update_alpha),

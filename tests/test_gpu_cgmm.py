@@ -309,3 +309,11 @@ def test_estimator_pcm16_frames_equal_float_input():
     b = est.estimate(utts_q)
     for x, y in zip(a, b):
         assert x.shape == y.shape and x.dtype == np.float32 and np.array_equal(x, y)
+    # estimate() runs on the library's own buffers and stream; the tensor API gives the same
+    import torch
+    dev = torch.device("cuda", est.ctx.device)
+    for k in (0, 2):
+        m = est.estimate_device([torch.from_numpy(utts_f[k]).to(dev)])[0].cpu().numpy()
+        assert np.array_equal(m, a[k])
+    est.close()
+    assert est.estimate(utts_q[:1])[0].shape == a[0].shape   # buffers come back after close()

@@ -89,3 +89,25 @@ def test_streaming_cli_host_side_under_asan(asan_env, tmp_path):
     for i, n in enumerate(lens):
         sr, y = scipy.io.wavfile.read(f"{td}/out/u{i}.wav")
         assert sr == 16000 and y.dtype == np.int16 and y.shape == (256 * (n // 256),)
+
+
+def test_cgmm_cli_host_side_under_asan(asan_env, tmp_path):
+    """estimate_cgmm_masks.py (batched path: CgmmEstimator.estimate on the library's own slabs
+    and stream, no torch) against the stand-in, under ASAN + UBSan."""
+    import numpy as np
+    from setk_amd.libs import wavio
+    rng = np.random.default_rng(1)
+    td = str(tmp_path)
+    lens = [16000, 20011, 9000]
+    with open(f"{td}/wav.scp", "w") as ws:
+        for i, n in enumerate(lens):
+            wavio.write_pcm16(f"{td}/u{i}.wav", (rng.standard_normal((n, 3)) * 900).astype(np.int16), 16000)
+            ws.write(f"u{i} {td}/u{i}.wav\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "sptk", "estimate_cgmm_masks.py"),
+                        "--num-iters", "3", "--batch-utts", "2", f"{td}/wav.scp", f"{td}/masks"],
+                       capture_output=True, text=True, env=asan_env, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    assert "Train 3 utterances over 3" in r.stderr
+    for i, n in enumerate(lens):
+        assert np.load(f"{td}/masks/u{i}.npy").shape == (1 + n // 256, 257)
