@@ -9,6 +9,7 @@ Conversions follow libsndfile's defaults: integer PCM -> float32 divides by
 (lrintf) without clipping.
 """
 import io
+import os
 import struct
 
 import numpy as np
@@ -149,14 +150,23 @@ def write_pcm16(file, pcm, sr):
     """pcm: int16 [N] or [N, C]."""
     pcm = np.ascontiguousarray(pcm, dtype="<i2")
     ch = 1 if pcm.ndim == 1 else pcm.shape[1]
-    data = pcm.tobytes()
-    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack(
+    # the samples are written out of the array itself: a bytes copy of every waveform is a
+    # memcpy under the GIL in each writer thread of the streaming pipeline
+    data = memoryview(pcm.reshape(-1)).cast("B") if pcm.size else b""
+    nbytes = pcm.nbytes
+    hdr = b"RIFF" + struct.pack("<I", 36 + nbytes) + b"WAVE" + b"fmt " + struct.pack(
         "<IHHIIHH", 16, WAVE_FORMAT_PCM, ch, int(sr), int(sr) * ch * 2, ch * 2, 16)
-    hdr += b"data" + struct.pack("<I", len(data))
+    hdr += b"data" + struct.pack("<I", nbytes)
     if isinstance(file, (str, bytes)) or hasattr(file, "__fspath__"):
-        with open(file, "wb") as fd:
-            fd.write(hdr)
-            fd.write(data)
+        fd = os.open(file, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+        try:
+            bufs, want = [hdr, data], len(hdr) + nbytes
+            n = os.writev(fd, bufs)
+            while n < want:  # short write: continue from where it stopped
+                whole = hdr + bytes(data)
+                n += os.write(fd, memoryview(whole)[n:])
+        finally:
+            os.close(fd)
     else:
         file.write(hdr)
         file.write(data)
