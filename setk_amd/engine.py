@@ -71,6 +71,104 @@ def compute_vad_masks(spectrogram, proportion):
     return (energy < threshold).transpose(), index
 
 
+class _Slabs(object):
+    """Grow-only working set of the engines' torch-free batch paths: a page-locked input slab
+    and its device twin, a device scratch for converted samples, a device output slab and its
+    page-locked twin, one stream -- all from the library (setk_host_alloc / setk_device_alloc
+    / setk_stream_create)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.cap = [0, 0, 0]
+        self.h_in = self.d_in = self.d_f32 = self.h_out = self.d_out = 0
+        self.np_in = self.np_out = None
+        self.stream = ctx.stream_create()
+
+    def reserve(self, n_in, n_f32, n_out):
+        ctx = self.ctx
+        ctx.stream_synchronize(self.stream)  # the previous call's work has left the slabs
+        if n_in > self.cap[0]:
+            self.np_in = None
+            if self.h_in:
+                ctx.host_free(self.h_in)
+                ctx.device_free(self.d_in)
+            n = int(n_in * 1.25)
+            self.h_in, self.np_in = ctx.host_alloc(n)
+            self.d_in = ctx.device_alloc(n)
+            self.cap[0] = n
+        if n_f32 > self.cap[1]:
+            if self.d_f32:
+                ctx.device_free(self.d_f32)
+            n = int(n_f32 * 1.25)
+            self.d_f32 = ctx.device_alloc(n)
+            self.cap[1] = n
+        if n_out > self.cap[2]:
+            self.np_out = None
+            if self.h_out:
+                ctx.host_free(self.h_out)
+                ctx.device_free(self.d_out)
+            n = int(n_out * 1.25)
+            self.h_out, self.np_out = ctx.host_alloc(n)
+            self.d_out = ctx.device_alloc(n)
+            self.cap[2] = n
+
+    def stage_audio(self, utts, C, extra_out):
+        """Lay the utterances (C x N float32 arrays or Pcm16Frames) out in the input slab,
+        copy it up in one piece and convert the 16-bit ones on the device.  extra_out(N) ->
+        output bytes of an utterance.  Returns (device sample pointers, lengths, output
+        offsets, output bytes)."""
+        ctx = self.ctx
+        al = lambda v: (v + 255) & ~255  # noqa: E731
+        lay, n_in, n_f32, n_out = [], 0, 0, 0
+        for s in utts:
+            pcm = isinstance(s, Pcm16Frames)
+            N = s.frames.shape[0] if pcm else _channels_and_size(s)[1] // C
+            lay.append((pcm, N, n_in, n_f32, n_out))
+            n_in = al(n_in + (2 if pcm else 4) * C * N)
+            if pcm:
+                n_f32 = al(n_f32 + 4 * C * N)
+            n_out = al(n_out + extra_out(N))
+        self.reserve(max(n_in, 256), max(n_f32, 256), max(n_out, 256))
+        aptr, ns, pcm_jobs = [], [], []
+        for s, (pcm, N, o_in, o_f32, _) in zip(utts, lay):
+            if pcm:
+                self.np_in[o_in:o_in + 2 * C * N] = np.frombuffer(s.frames, dtype=np.uint8)
+                pcm_jobs.append((self.d_in + o_in, N, self.d_f32 + o_f32))
+                aptr.append(self.d_f32 + o_f32)
+            else:
+                a = np.ascontiguousarray(s, dtype=np.float32)
+                self.np_in[o_in:o_in + a.nbytes] = np.frombuffer(a, dtype=np.uint8)
+                aptr.append(self.d_in + o_in)
+            ns.append(N)
+        ctx.memcpy_h2d_async(self.d_in, self.h_in, n_in, self.stream)
+        if pcm_jobs:
+            ctx.pcm16_to_float_batch(C, [p for p, _, _ in pcm_jobs], [n for _, n, _ in pcm_jobs],
+                                     [o for _, _, o in pcm_jobs], stream=self.stream)
+        return aptr, ns, [l[4] for l in lay], n_out
+
+    def fetch(self, n_out):
+        """One copy down; returns the page-locked view (valid until the next reserve())."""
+        self.ctx.memcpy_d2h_async(self.h_out, self.d_out, n_out, self.stream)
+        self.ctx.stream_synchronize(self.stream)
+        return self.np_out
+
+    def close(self):
+        ctx = self.ctx
+        if not self.stream:
+            return
+        ctx.stream_synchronize(self.stream)
+        self.np_in = self.np_out = None
+        for p in (self.h_in, self.h_out):
+            if p:
+                ctx.host_free(p)
+        for p in (self.d_in, self.d_f32, self.d_out):
+            if p:
+                ctx.device_free(p)
+        ctx.stream_destroy(self.stream)
+        self.stream = 0
+        self.h_in = self.d_in = self.d_f32 = self.h_out = self.d_out = 0
+
+
 class BatchEnhancer(object):
     def __init__(self, beamformer="mvdr", frame_len=512, frame_hop=256, center=True,
                  round_power_of_two=True, window="hann", ban=False, pmwf_ref=-1, rank1_appro="",
@@ -299,12 +397,13 @@ class FixedBatchBeamformer(object):
     def __init__(self, weights, frame_len=512, frame_hop=256, center=True,
                  round_power_of_two=True, window="hann", pcm16=False, device=None,
                  max_batch_samples=1 << 29, renorm=True):
-        import torch
-        self.torch = torch
-        if not torch.cuda.is_available():
-            raise _ffi.SetkError("setk_amd needs an MI355X GPU (no CPU fallback)")
+        # no GPU / no library: setk_create fails here, loudly.  The fused batch path brings
+        # its own buffers and stream; torch is the plumbing of the stand-alone operators only
+        # (n_fft != 512, more than 8 channels) and is imported when they are first needed.
         self.ctx = _ffi.default_context(device)
-        self.dev = torch.device("cuda", self.ctx.device)
+        self._torch = None
+        self._slabs = None
+        self._dw = 0
         # renorm=False: inverse_stft(norm=None), apply_classic_beamformer.py:109-110
         self.renorm = bool(renorm)
         weights = np.asarray(weights)
@@ -320,11 +419,38 @@ class FixedBatchBeamformer(object):
                              f"{n_fft // 2 + 1}")
         self.pcm16 = pcm16
         self.max_batch_samples = max_batch_samples
-        self._d_weights = None
+
+    @property
+    def torch(self):
+        if self._torch is None:
+            import torch
+            if not torch.cuda.is_available():
+                raise _ffi.SetkError("setk_amd needs an MI355X GPU (no CPU fallback)")
+            self._torch = torch
+        return self._torch
+
+    @property
+    def dev(self):
+        return self.torch.device("cuda", self.ctx.device)
 
     def _plan(self):
         s = self.stft
         self.ctx.stft_plan(s["frame_len"], s["frame_hop"], s["n_fft"], s["center"], s["window"])
+
+    def close(self):
+        """Give the slabs and the device copy of the weights back."""
+        b, self._slabs = self._slabs, None
+        if b:
+            b.close()
+        if self._dw:
+            self.ctx.device_free(self._dw)
+            self._dw = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def run(self, utts):
         self._plan()
@@ -362,27 +488,29 @@ class FixedBatchBeamformer(object):
         return torch.from_numpy(samps).to(dev), samps.shape[1]
 
     def _run(self, utts, batch, C, results):
-        torch, ctx, dev = self.torch, self.ctx, self.dev
+        ctx = self.ctx
         if self.n_fft != 512 or C > 8:
             return self._run_unfused(utts, batch, C, results)
-        if self._d_weights is None:
-            self._d_weights = torch.from_numpy(self.weights).to(dev)
-        audio, waves, ns, beams = [], [], [], []
-        for i in batch:
-            samps, beam = utts[i]
-            a, N = self._upload(samps, C)
-            L = ctx.istft_num_samples(ctx.num_frames(N))
-            audio.append(a)
-            waves.append(torch.empty(L, dtype=torch.int16 if self.pcm16 else torch.float32,
-                                     device=dev))
-            ns.append(N)
-            beams.append(int(beam))
-        ctx.apply_weights_batch(C, [t.data_ptr() for t in audio], ns, self._d_weights,
-                                self.weights.shape[0], beams, [t.data_ptr() for t in waves],
+        # one slab up, setk_apply_weights_batch, one slab down -- on the library's own
+        # buffers and stream
+        if self._slabs is None:
+            self._slabs = _Slabs(ctx)
+        b = self._slabs
+        esz = 2 if self.pcm16 else 4
+        aptr, ns, off_out, n_out = b.stage_audio(
+            [utts[i][0] for i in batch], C, lambda N: esz * ctx.istft_num_samples(ctx.num_frames(N)))
+        if not self._dw:
+            self._dw = ctx.device_alloc(self.weights.nbytes)
+            ctx.memcpy_h2d_async(self._dw, self.weights.ctypes.data, self.weights.nbytes, b.stream)
+        ctx.apply_weights_batch(C, aptr, ns, self._dw, self.weights.shape[0],
+                                [int(utts[i][1]) for i in batch], [b.d_out + o for o in off_out],
                                 flags=(_ffi.FLAG_OUT_PCM16 if self.pcm16 else 0) |
-                                (0 if self.renorm else _ffi.FLAG_NO_RENORM))
-        for j, i in enumerate(batch):
-            results[i] = waves[j].cpu().numpy()
+                                (0 if self.renorm else _ffi.FLAG_NO_RENORM), stream=b.stream)
+        host = b.fetch(n_out)
+        for k, i in enumerate(batch):
+            L = ctx.istft_num_samples(ctx.num_frames(ns[k]))
+            results[i] = np.frombuffer(host[off_out[k]:off_out[k] + esz * L],
+                                       dtype=np.int16 if self.pcm16 else np.float32).copy()
 
     def _run_unfused(self, utts, batch, C, results):
         """n_fft != 512: setk_stft -> setk_beamform -> setk_istft per utterance."""
@@ -533,54 +661,11 @@ class CgmmEstimator(object):
             out[i] = host[off:off + m.numel()].reshape(m.shape)
             off += m.numel()
 
-    def _buffers(self, n_in, n_f32, n_out):
-        """Grow-only slabs: page-locked input / output twins and the device side."""
-        ctx = self.ctx
-        b = self._bufs or dict(cap=(0, 0, 0), h_in=0, np_in=None, d_in=0, d_f32=0, h_out=0,
-                               np_out=None, d_out=0, stream=ctx.stream_create())
-        cap = b["cap"]
-        if n_in > cap[0]:
-            b["np_in"] = None
-            if b["h_in"]:
-                ctx.host_free(b["h_in"])
-                ctx.device_free(b["d_in"])
-            n = int(n_in * 1.25)
-            b["h_in"], b["np_in"] = ctx.host_alloc(n)
-            b["d_in"] = ctx.device_alloc(n)
-            cap = (n, cap[1], cap[2])
-        if n_f32 > cap[1]:
-            if b["d_f32"]:
-                ctx.device_free(b["d_f32"])
-            n = int(n_f32 * 1.25)
-            b["d_f32"] = ctx.device_alloc(n)
-            cap = (cap[0], n, cap[2])
-        if n_out > cap[2]:
-            b["np_out"] = None
-            if b["h_out"]:
-                ctx.host_free(b["h_out"])
-                ctx.device_free(b["d_out"])
-            n = int(n_out * 1.25)
-            b["h_out"], b["np_out"] = ctx.host_alloc(n)
-            b["d_out"] = ctx.device_alloc(n)
-            cap = (cap[0], cap[1], n)
-        b["cap"] = cap
-        self._bufs = b
-        return b
-
     def close(self):
         """Give the slabs of estimate() back (also done when the estimator is collected)."""
         b, self._bufs = self._bufs, None
         if b:
-            ctx = self.ctx
-            ctx.stream_synchronize(b["stream"])
-            b["np_in"] = b["np_out"] = None
-            for k in ("h_in", "h_out"):
-                if b[k]:
-                    ctx.host_free(b[k])
-            for k in ("d_in", "d_f32", "d_out"):
-                if b[k]:
-                    ctx.device_free(b[k])
-            ctx.stream_destroy(b["stream"])
+            b.close()
 
     def __del__(self):
         try:
@@ -591,47 +676,17 @@ class CgmmEstimator(object):
     def _estimate_native(self, utts, C, idx, out):
         ctx, F = self.ctx, self.num_bins
         self._plan()
-        al = lambda v: (v + 255) & ~255  # noqa: E731
-        off_in, off_f32, off_out, n_in, n_f32, n_out = [], [], [], 0, 0, 0
-        for i in idx:
-            s = utts[i]
-            pcm = isinstance(s, Pcm16Frames)
-            N = s.frames.shape[0] if pcm else _channels_and_size(s)[1] // C
-            off_in.append(n_in)
-            n_in = al(n_in + (2 if pcm else 4) * C * N)
-            off_f32.append(n_f32)
-            if pcm:
-                n_f32 = al(n_f32 + 4 * C * N)
-            off_out.append(n_out)
-            n_out = al(n_out + 4 * ctx.num_frames(N) * F)
-        b = self._buffers(max(n_in, 256), max(n_f32, 256), max(n_out, 256))
-        st = b["stream"]
-        ctx.stream_synchronize(st)  # the slabs of the previous call are free again
-        aptr, ns, pcm_jobs = [], [], []
-        for k, i in enumerate(idx):
-            s = utts[i]
-            if isinstance(s, Pcm16Frames):
-                N = s.frames.shape[0]
-                b["np_in"][off_in[k]:off_in[k] + 2 * C * N] = np.frombuffer(s.frames, dtype=np.uint8)
-                pcm_jobs.append((b["d_in"] + off_in[k], N, b["d_f32"] + off_f32[k]))
-                aptr.append(b["d_f32"] + off_f32[k])
-            else:
-                a = np.ascontiguousarray(s, dtype=np.float32)
-                N = a.size // C
-                b["np_in"][off_in[k]:off_in[k] + a.nbytes] = np.frombuffer(a, dtype=np.uint8)
-                aptr.append(b["d_in"] + off_in[k])
-            ns.append(N)
-        ctx.memcpy_h2d_async(b["d_in"], b["h_in"], n_in, st)
-        if pcm_jobs:
-            ctx.pcm16_to_float_batch(C, [p for p, _, _ in pcm_jobs], [n for _, n, _ in pcm_jobs],
-                                     [o for _, _, o in pcm_jobs], stream=st)
-        ctx.cgmm_estimate_batch(C, aptr, ns, self.num_iters, None, [b["d_out"] + o for o in off_out],
-                                stream=st, update_alpha=self.update_alpha)
-        ctx.memcpy_d2h_async(b["h_out"], b["d_out"], n_out, st)
-        ctx.stream_synchronize(st)
+        if self._bufs is None:
+            self._bufs = _Slabs(ctx)
+        b = self._bufs
+        aptr, ns, off_out, n_out = b.stage_audio([utts[i] for i in idx], C,
+                                                 lambda N: 4 * ctx.num_frames(N) * F)
+        ctx.cgmm_estimate_batch(C, aptr, ns, self.num_iters, None, [b.d_out + o for o in off_out],
+                                stream=b.stream, update_alpha=self.update_alpha)
+        host = b.fetch(n_out)
         for k, i in enumerate(idx):
             T = ctx.num_frames(ns[k])
-            out[i] = np.frombuffer(b["np_out"][off_out[k]:off_out[k] + 4 * T * F],
+            out[i] = np.frombuffer(host[off_out[k]:off_out[k] + 4 * T * F],
                                    dtype=np.float32).reshape(T, F).copy()
 
 

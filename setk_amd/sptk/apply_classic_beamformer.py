@@ -18,6 +18,7 @@ import math
 
 import numpy as np
 
+from setk_amd import _ffi
 from setk_amd.dist import Shard
 from setk_amd.engine import FixedBatchBeamformer, Pcm16Frames
 from setk_amd.libs.beamformer import (CircularDSBeamformer, CircularSDBeamformer,
@@ -106,6 +107,8 @@ def run_offline(args, beamformer, utt2doa, shard):
     num_bins = n_fft // 2 + 1
     wav_reader = WaveReader(args.wav_scp, sr=args.sr)
     device = shard.device if shard.world > 1 else None
+    if n_fft == 512 and shard.world == 1:
+        _ffi.TORCH_FREE = True  # the batch engine brings its own buffers and stream
     done = 0
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
 
@@ -120,7 +123,10 @@ def run_offline(args, beamformer, utt2doa, shard):
                                           round_power_of_two=bool(args.round_power_of_two),
                                           window=args.window, pcm16=True, device=device,
                                           renorm=bool(args.normalize))
-            outs = engine.run([(s, doas.index(d)) for (_, s, d) in pending])
+            try:
+                outs = engine.run([(s, doas.index(d)) for (_, s, d) in pending])
+            finally:
+                engine.close()
             for (key, _, _), pcm in zip(pending, outs):
                 writer.write_pcm16(key, pcm)
             return len(pending)

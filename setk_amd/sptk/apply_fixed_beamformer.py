@@ -39,6 +39,9 @@ def run(args):
         raise RuntimeError(f"Expect weights in shape F x M or B x F x M, got {weights.shape}")
     shard = Shard()
     device = shard.device if shard.world > 1 else None
+    n_fft = 2**int(np.ceil(np.log2(args.frame_len))) if args.round_power_of_two else args.frame_len
+    if n_fft == 512 and shard.world == 1:
+        _ffi.TORCH_FREE = True  # the batch engine brings its own buffers and stream
     engine = FixedBatchBeamformer(weights, frame_len=args.frame_len, frame_hop=args.frame_hop,
                                   center=bool(args.center),
                                   round_power_of_two=bool(args.round_power_of_two),

@@ -111,3 +111,30 @@ def test_cgmm_cli_host_side_under_asan(asan_env, tmp_path):
     assert "Train 3 utterances over 3" in r.stderr
     for i, n in enumerate(lens):
         assert np.load(f"{td}/masks/u{i}.npy").shape == (1 + n // 256, 257)
+
+
+def test_fixed_beamformer_cli_host_side_under_asan(asan_env, tmp_path):
+    """apply_fixed_beamformer.py (FixedBatchBeamformer on the library's own slabs and stream, no
+    torch) against the stand-in, under ASAN + UBSan: two beams, ragged lengths."""
+    import numpy as np
+    import scipy.io.wavfile
+    from setk_amd.libs import wavio
+    rng = np.random.default_rng(2)
+    td = str(tmp_path)
+    lens = [16000, 12001, 30000, 8000, 5000]
+    w = (rng.standard_normal((2, 257, 4)) + 1j * rng.standard_normal((2, 257, 4))).astype(np.complex64)
+    np.save(f"{td}/w.npy", w)
+    with open(f"{td}/wav.scp", "w") as ws, open(f"{td}/beam.scp", "w") as bs:
+        for i, n in enumerate(lens):
+            wavio.write_pcm16(f"{td}/u{i}.wav", (rng.standard_normal((n, 4)) * 900).astype(np.int16), 16000)
+            ws.write(f"u{i} {td}/u{i}.wav\n")
+            bs.write(f"u{i} {i % 2}\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "sptk", "apply_fixed_beamformer.py"),
+                        "--beam", f"{td}/beam.scp", "--batch-utts", "2", f"{td}/wav.scp", f"{td}/w.npy",
+                        f"{td}/out"], capture_output=True, text=True, env=asan_env, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    assert "Processed 5 utterances" in r.stderr
+    for i, n in enumerate(lens):
+        sr, y = scipy.io.wavfile.read(f"{td}/out/u{i}.wav")
+        assert sr == 16000 and y.dtype == np.int16 and y.shape == (256 * (n // 256),)
