@@ -32,6 +32,7 @@ host by the ordinary readers and copied into the slab as float32.
 
 PyTorch is plumbing here: pinned / device buffers, streams and events.
 """
+import contextlib
 import mmap
 import os
 import queue
@@ -671,11 +672,15 @@ class StreamPipeline(object):
             self.completer.join()
             self.readers.shutdown()
             self.writers.shutdown()
+            # every wav is closed: the clock stops here, then the slabs go back
+            wall = (time.perf_counter() - self.t_first) if self.t_first else 0.0
+            t0 = time.perf_counter()
             self._release()
+            self.stats["t_release"] = time.perf_counter() - t0
         if self.exc:
             raise self.exc
         st = dict(self.stats)
-        st["wall_s"] = (time.perf_counter() - self.t_first) if self.t_first else 0.0
+        st["wall_s"] = wall
         st["read_threads"] = self.read_threads
         st["depth"] = self.depth
         st["batch_utts"] = self.batch_utts
@@ -700,10 +705,15 @@ class StreamPipeline(object):
 # ----------------------------------------------------------------------------
 # scp entries -> sources
 # ----------------------------------------------------------------------------
-def wav_source(wav_reader, key, files):
+_NO_LOCK = contextlib.nullcontext()
+
+
+def wav_source(wav_reader, key, files, lock=None):
     """What submit() takes as `audio` for an entry of a WaveReader table: the PCM16
     payload as it lies in the file when the entry is ONE 16-bit PCM file (plain
-    path or path.ark:offset), else the decoded C x N float32 array."""
+    path or path.ark:offset), else the decoded C x N float32 array.  lock: held around
+    the table reader's own decode (its archive handles are not for concurrent use) when
+    several threads prepare sources."""
     import glob
     fname = wav_reader.index_dict[key].rstrip()
     if wav_reader.normalize and fname and fname[-1] != "|":
@@ -725,11 +735,12 @@ def wav_source(wav_reader, key, files):
                 n = min(n, max(0, (size - data_off) // (2 * ch)))
                 return (Payload(path=path, offset=data_off, nbytes=2 * ch * n, fsize=size),
                         ch, n)
-    samps = wav_reader.read(key)
+    with lock or _NO_LOCK:
+        samps = wav_reader.read(key)
     return samps[None] if samps.ndim == 1 else samps
 
 
-def mask_source(reader, key, files, num_bins):
+def mask_source(reader, key, files, num_bins, lock=None):
     """Payload of the float32 [T][F] rows when the mask is stored that way (a
     C-ordered float32 .npy, or a Kaldi FM matrix), else the loaded array."""
     from .libs.data_handler import NumpyReader, ScriptReader
@@ -748,4 +759,5 @@ def mask_source(reader, key, files, num_bins):
                                fsize=os.fstat(files.get(path)).st_size)
     except (OSError, ValueError, KeyError, SyntaxError):
         pass
-    return reader[key]
+    with lock or _NO_LOCK:
+        return reader[key]
