@@ -207,6 +207,13 @@ int setk_pcm16_to_float_batch(setk_handle_t h, int n_utts, int num_channels,
                               const int16_t* const* pcm, const int* num_samples,
                               float* const* audio, double* power0, void* stream);
 
+/* The way back for a multi-channel result (apply_wpe.py:58-61 -> write_wav,
+ * libs/utils.py:45-62 -> soundfile.write, float -> PCM_16): float32 rows audio[C][N] ->
+ * interleaved frames pcm[N][C], lrint(x * 32767) without clipping (libsndfile's default;
+ * out-of-range values wrap).  Host or device pointers. */
+int setk_float_to_pcm16(setk_handle_t h, const float* audio, int num_channels, int num_samples,
+                        int16_t* pcm, void* stream);
+
 /* do_ban (libs/beamformer.py:14-28) on an arbitrary weight:
  * out[f] = w[f] * sqrt(|w^H Rn Rn w|) / max(Re w^H Rn w, eps_f32). */
 int setk_ban(setk_handle_t h, const float* weight, const float* Rn, int num_bins,

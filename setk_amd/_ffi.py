@@ -66,7 +66,7 @@ def exported_symbols():
         "setk_host_register", "setk_host_unregister", "setk_memcpy_h2d_async",
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_stft_batch", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
-        "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
+        "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_float_to_pcm16", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
         "setk_cgmm_masks_batch", "setk_cgmm_estimate_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
         "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_wpe_batch", "setk_set_profiling",
@@ -124,6 +124,7 @@ def load_library():
                                  fp, fp, POINTER(c_int), c_void_p]
     lib.setk_ban.argtypes = [H, fp, fp, c_int, c_int, fp, c_void_p]
     lib.setk_pcm16_to_float.argtypes = [H, c_void_p, c_int, c_int, fp, c_void_p]
+    lib.setk_float_to_pcm16.argtypes = [H, fp, c_int, c_int, c_void_p, c_void_p]
     lib.setk_pcm16_to_float_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int),
                                               POINTER(c_void_p), c_void_p, c_void_p]
     lib.setk_rank1.argtypes = [H, fp, fp, c_int, c_int, fp, fp, c_void_p]
@@ -376,6 +377,12 @@ class Context:
         """interleaved int16 frames pcm[N][C] -> float32 out[C][N] (= pcm / 32768)."""
         self.check(
             self._lib.setk_pcm16_to_float(self._h, _ptr(pcm), C, N, _ptr(out),
+                                          current_stream_ptr() if stream is None else stream))
+
+    def float_to_pcm16(self, audio, C, N, pcm, stream=None):
+        """float32 audio[C][N] -> interleaved int16 frames pcm[N][C] (rint(x * 32767), wrapping)."""
+        self.check(
+            self._lib.setk_float_to_pcm16(self._h, _ptr(audio), C, N, _ptr(pcm),
                                           current_stream_ptr() if stream is None else stream))
 
     def pcm16_to_float_batch(self, C, pcm_ptrs, num_samples, out_ptrs, power0=None, stream=None):

@@ -1106,6 +1106,27 @@ int setk_pcm16_to_float(setk_handle_t h, const int16_t* pcm, int num_channels, i
     return SETK_OK;
 }
 
+int setk_float_to_pcm16(setk_handle_t h, const float* audio, int num_channels, int num_samples,
+                        int16_t* pcm, void* stream) {
+    if (!h || !pcm || !audio || num_channels <= 0 || num_samples <= 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h, s);
+    const size_t n = (size_t)num_channels * num_samples;
+    const float* d_in;
+    int rc = stage_in(h, audio, n, s, &d_in);
+    if (rc) return rc;
+    OutBuf ob;
+    rc = stage_out(h, pcm, n * sizeof(int16_t), &ob);
+    if (rc) return rc;
+    HIP_TRY(h, launch_float_to_pcm16(d_in, num_channels, num_samples, static_cast<int16_t*>(ob.dev), s));
+    rc = copy_back(h, ob, s);
+    if (rc) return rc;
+    if (ob.host) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
 int setk_pcm16_to_float_batch(setk_handle_t h, int n_utts, int num_channels,
                               const int16_t* const* pcm, const int* num_samples,
                               float* const* audio, double* power0, void* stream) {

@@ -187,6 +187,7 @@ hipError_t launch_maxabs(const UttDesc* utts, int C, unsigned* norm_bits, int n_
                          hipStream_t s);
 hipError_t launch_pack_fixed_weights(const float* sets, const int* index, int n_utts, int C,
                                      float* out, hipStream_t s);
+hipError_t launch_float_to_pcm16(const float* in, int C, int N, int16_t* out, hipStream_t s);
 hipError_t launch_pcm16_to_float(const int16_t* pcm, int C, int N, float* out, hipStream_t s);
 size_t pcm_item_bytes();
 void pcm_item_fill(void* dst, int i, const int16_t* pcm, float* out, int n);

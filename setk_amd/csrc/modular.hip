@@ -476,6 +476,24 @@ hipError_t launch_pcm16_to_float(const int16_t* pcm, int C, int N, float* out, h
     return hipGetLastError();
 }
 
+// The way back for a multi-channel result: float rows [C][N] -> interleaved 16-bit frames
+// [N][C], quantised by libsndfile's float -> short rule as the host writer applies it
+// (wavio.float_to_pcm16: rint(x * 32767) in double, no clipping -- out-of-range values wrap).
+__global__ __launch_bounds__(256) void float_to_pcm16_kernel(const float* __restrict__ in, int C, int N,
+                                                             int16_t* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    for (int c = 0; c < C; ++c) {
+        const double v = rint((double)in[(size_t)c * N + n] * 32767.0);
+        out[(size_t)n * C + c] = (int16_t)(long long)v;
+    }
+}
+
+hipError_t launch_float_to_pcm16(const float* in, int C, int N, int16_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(float_to_pcm16_kernel, dim3((N + 255) / 256), dim3(256), 0, s, in, C, N, out);
+    return hipGetLastError();
+}
+
 // Batched form: one launch for a whole staging slab (blockIdx.y = utterance).
 // Optionally sums x^2 of channel 0 (SpectrogramReader.power, only used for the
 // CLI's log line) into power0[u] (double, atomics: log precision only).

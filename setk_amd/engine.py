@@ -701,12 +701,12 @@ class BatchDereverb(object):
 
     def __init__(self, taps=10, delay=3, context=1, num_iters=3, frame_len=512, frame_hop=256,
                  center=True, round_power_of_two=True, window="hann", device=None, pcm16=False):
-        import torch
-        self.torch = torch
-        if not torch.cuda.is_available():
-            raise _ffi.SetkError("setk_amd needs an MI355X GPU (no CPU fallback)")
+        # no GPU / no library: setk_create fails here, loudly.  The n_fft = 512 path brings its
+        # own buffers and stream; torch is the plumbing of the other transform sizes only.
         self.ctx = _ffi.default_context(device)
-        self.dev = torch.device("cuda", self.ctx.device)
+        self._torch = None
+        self._slabs = None
+        self._scratch, self._scratch_cap = 0, 0
         # pcm16: hand back interleaved int16 frames L x C, quantised on the device by the
         # writer's rule (wavio.float_to_pcm16: rint(x * 32767) in float64, wrapping)
         self.pcm16 = bool(pcm16)
@@ -716,8 +716,36 @@ class BatchDereverb(object):
                          window=stft_window(window, frame_len))
         self.num_bins = n_fft // 2 + 1
 
+    @property
+    def torch(self):
+        if self._torch is None:
+            import torch
+            if not torch.cuda.is_available():
+                raise _ffi.SetkError("setk_amd needs an MI355X GPU (no CPU fallback)")
+            self._torch = torch
+        return self._torch
+
+    @property
+    def dev(self):
+        return self.torch.device("cuda", self.ctx.device)
+
+    def close(self):
+        """Give the slabs and the spectrogram scratch of run() back."""
+        b, self._slabs = self._slabs, None
+        if b:
+            b.close()
+        if self._scratch:
+            self.ctx.device_free(self._scratch)
+            self._scratch, self._scratch_cap = 0, 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def run(self, utts):
-        torch, ctx, dev, F = self.torch, self.ctx, self.dev, self.num_bins
+        ctx = self.ctx
         if not len(utts):
             return []
         s = self.stft
@@ -725,6 +753,66 @@ class BatchDereverb(object):
         C = _channels_and_size(utts[0])[0]
         if any(_channels_and_size(u)[0] != C for u in utts):
             raise ValueError("BatchDereverb.run needs the same channel count in every utterance")
+        if s["n_fft"] == 512 and C <= 8:
+            return self._run_native(utts, C)
+        return self._run_torch(utts, C)
+
+    def _run_native(self, utts, C):
+        """One slab of samples up, setk_stft_batch -> setk_wpe_batch -> setk_istft (->
+        setk_float_to_pcm16), one slab of waveforms down: the library's own buffers and stream."""
+        ctx, F = self.ctx, self.num_bins
+        if self._slabs is None:
+            self._slabs = _Slabs(ctx)
+        b = self._slabs
+        esz = 2 if self.pcm16 else 4
+        aptr, ns, off_out, n_out = b.stage_audio(
+            utts, C, lambda N: esz * C * ctx.istft_num_samples(ctx.num_frames(N)))
+        frames = [ctx.num_frames(N) for N in ns]
+        lens = [ctx.istft_num_samples(T) for T in frames]
+        al = lambda v: (v + 255) & ~255  # noqa: E731
+        # scratch: spectrogram in / out per utterance, float waveforms when PCM16 goes out
+        need, spec_in, spec_out, wav32 = 0, [], [], []
+        for T, L in zip(frames, lens):
+            spec_in.append(need)
+            need = al(need + 8 * C * T * F)
+            spec_out.append(need)
+            need = al(need + 8 * C * T * F)
+            wav32.append(need)
+            if self.pcm16:
+                need = al(need + 4 * C * L)
+        if need > self._scratch_cap:
+            ctx.stream_synchronize(b.stream)
+            if self._scratch:
+                ctx.device_free(self._scratch)
+            self._scratch_cap = int(need * 1.25)
+            self._scratch = ctx.device_alloc(self._scratch_cap)
+        base = self._scratch
+        ctx.stft_batch(C, aptr, ns, [base + o for o in spec_in], stream=b.stream)
+        status = np.zeros((len(utts), F), dtype=np.int32)
+        ctx.wpe_batch([base + o for o in spec_in], C, frames, F, self.taps, self.delay, self.context,
+                      self.num_iters, [base + o for o in spec_out], status=status, stream=b.stream)
+        for k, (T, L) in enumerate(zip(frames, lens)):
+            if self.pcm16:
+                ctx.istft(base + spec_out[k], C, T, None, None, base + wav32[k], stream=b.stream)
+                ctx.float_to_pcm16(base + wav32[k], C, L, b.d_out + off_out[k], stream=b.stream)
+            else:
+                ctx.istft(base + spec_out[k], C, T, None, None, b.d_out + off_out[k], stream=b.stream)
+        host = b.fetch(n_out)
+        out = []
+        for k, L in enumerate(lens):
+            if status[k].any():
+                out.append(None)
+            elif self.pcm16:
+                out.append(np.frombuffer(host[off_out[k]:off_out[k] + 2 * C * L],
+                                         dtype=np.int16).reshape(L, C).copy())
+            else:
+                out.append(np.frombuffer(host[off_out[k]:off_out[k] + 4 * C * L],
+                                         dtype=np.float32).reshape(C, L).copy())
+        return out
+
+    def _run_torch(self, utts, C):
+        torch, ctx, dev, F = self.torch, self.ctx, self.dev, self.num_bins
+        s = self.stft
         audio, ns = [], []
         for samps in utts:
             if isinstance(samps, Pcm16Frames):

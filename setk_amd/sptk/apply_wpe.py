@@ -11,6 +11,9 @@ this path.
 """
 import argparse
 
+import numpy as np
+
+from .. import _ffi
 from .._ffi import SetkUnsupported
 from setk_amd.dist import Shard
 from setk_amd.engine import BatchDereverb, Pcm16Frames, _channels_and_size
@@ -26,6 +29,9 @@ def run(args):
         raise RuntimeError("--nara-wpe: the nara_wpe package is not available here")
     shard = Shard()
     device = shard.device if shard.world > 1 else None
+    n_fft = 2**int(np.ceil(np.log2(args.frame_len))) if args.round_power_of_two else args.frame_len
+    if n_fft == 512 and shard.world == 1:
+        _ffi.TORCH_FREE = True  # the engine brings its own buffers and stream
     engine = BatchDereverb(taps=args.taps, delay=args.delay, context=args.context,
                            num_iters=args.num_iters, frame_len=args.frame_len,
                            frame_hop=args.frame_hop, center=bool(args.center),

@@ -138,6 +138,9 @@ def fused(ctx, C, lens, kind):
     ctx.pcm16_to_float_batch(C, pcm, lens, audio, power0=dmalloc(4 * n * F * max(frames)))
     ctx.pcm16_to_float(rng.integers(-9, 9, (lens[0], C)).astype(np.int16), C, lens[0],
                        np.empty((C, lens[0]), np.float32))
+    ctx.float_to_pcm16(rng.standard_normal((C, lens[0])).astype(np.float32), C, lens[0],
+                       np.empty((lens[0], C), np.int16))
+    ctx.float_to_pcm16(audio[0], C, lens[0], dmalloc(2 * C * lens[0]))
     specs = [dmalloc(C * t * F * 8) for t in frames]
     try:
         ctx.stft_batch(C, audio, lens, specs)
