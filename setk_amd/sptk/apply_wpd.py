@@ -11,6 +11,7 @@ import argparse
 
 import numpy as np
 
+from .. import _ffi
 from .._ffi import SetkUnsupported
 from setk_amd.dist import Shard
 from setk_amd.libs.data_handler import SpectrogramReader, WaveWriter
@@ -30,6 +31,8 @@ def run(args):
         "transpose": True  # T x F
     }
     shard = Shard()
+    if shard.world == 1:
+        _ffi.TORCH_FREE = True  # numpy arrays in and out of the library: nothing here needs torch
     reader = SpectrogramReader(args.wav_scp, round_power_of_two=args.round_power_of_two,
                                **stft_kwargs)
     num_done = 0

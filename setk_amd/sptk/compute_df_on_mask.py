@@ -13,6 +13,7 @@ import argparse
 
 import numpy as np
 
+from setk_amd import _ffi
 from setk_amd.libs.beamformer import compute_covar, solve_pevd
 from setk_amd.libs.data_handler import ArchiveWriter, NumpyReader, ScriptReader, SpectrogramReader
 from setk_amd.libs.opts import StftParser
@@ -31,6 +32,7 @@ def run(args):
         "center": args.center,
         "transpose": False  # F x T
     }
+    _ffi.TORCH_FREE = True  # numpy arrays in and out of the library: nothing here needs torch
     feat_reader = SpectrogramReader(args.wav_scp, **stft_kwargs)
     mask_reader = {"numpy": NumpyReader, "kaldi": ScriptReader}[args.fmt](args.mask_scp)
     df_pair = [tuple(map(int, p.split(","))) for p in args.df_pair.split(";")]
