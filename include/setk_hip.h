@@ -322,6 +322,13 @@ int setk_wpe_batch(setk_handle_t h, int n_utts, const float* const* spec, int nu
                    const int* num_frames, int num_bins, int taps, int delay, int context,
                    int num_iters, float* const* out, int* status, void* stream);
 
+/* The same with spec[u] / out[u] in the reference's own layout, F x N x T_u complex64 (the
+ * `reverb` / return value of wpe(), libs/wpe.py:84-110): it is the layout the step kernel
+ * works in, so no transposition happens on either side.  out[u] must not alias spec[u]. */
+int setk_wpe_batch_fnt(setk_handle_t h, int n_utts, const float* const* spec, int num_channels,
+                       const int* num_frames, int num_bins, int taps, int delay, int context,
+                       int num_iters, float* const* out, int* status, void* stream);
+
 /* ---- fused hot path ------------------------------------------------------
  * The compute body of apply_adaptive_beamformer.py:130-178 for a batch of
  * utterances that share the channel count, in four kernel stages:

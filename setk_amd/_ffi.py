@@ -69,7 +69,7 @@ def exported_symbols():
         "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_float_to_pcm16", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
         "setk_cgmm_masks_batch", "setk_cgmm_estimate_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
-        "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_wpe_batch", "setk_set_profiling",
+        "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_wpe_batch", "setk_wpe_batch_fnt", "setk_set_profiling",
         "setk_last_stage_ms"
     ]
 
@@ -148,6 +148,7 @@ def load_library():
     lib.setk_wpe_step.argtypes = [H, fp, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, c_void_p]
     lib.setk_wpe_batch.argtypes = [H, c_int, POINTER(c_void_p), c_int, POINTER(c_int), c_int, c_int,
                                    c_int, c_int, c_int, POINTER(c_void_p), fp, c_void_p]
+    lib.setk_wpe_batch_fnt.argtypes = lib.setk_wpe_batch.argtypes
     lib.setk_directional_feats.argtypes = [H, fp, fp, POINTER(c_int), c_int, c_int, c_int, c_int,
                                            fp, c_void_p]
     lib.setk_apply_weights_batch.argtypes = [
@@ -521,6 +522,18 @@ class Context:
             self._lib.setk_wpe_batch(self._h, n, sp, int(C), fr, int(F), int(taps), int(delay),
                                      int(context), int(num_iters), op, _ptr(status),
                                      current_stream_ptr() if stream is None else stream))
+
+    def wpe_batch_fnt(self, specs, C, frames, F, taps, delay, context, num_iters, outs, status=None,
+                      stream=None):
+        """wpe_batch with specs / outs in the reference's layout F x N x T_u (complex64)."""
+        n = len(specs)
+        sp = (c_void_p * n)(*[_ptr(a) for a in specs])
+        op = (c_void_p * n)(*[_ptr(a) for a in outs])
+        fr = (c_int * n)(*[int(t) for t in frames])
+        self.check(
+            self._lib.setk_wpe_batch_fnt(self._h, n, sp, int(C), fr, int(F), int(taps), int(delay),
+                                         int(context), int(num_iters), op, _ptr(status),
+                                         current_stream_ptr() if stream is None else stream))
 
     def wpe_step(self, spec, C, T, F, taps, delay, lambda_ft, out, status=None, stream=None):
         """One wpe_step with the caller's variances (float64 F x T) used as given."""

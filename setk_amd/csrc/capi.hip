@@ -1592,10 +1592,13 @@ namespace {
 // n_utts utterances of the same channel count per call: one wpe_step launch per
 // iteration covers every (bin, utterance).  lambda_enh / lambda_ft / inv_lambda_out only
 // with n_utts == 1 (facted_wpd, wpe_step).  status: [n_utts][F] (host or device) or NULL.
+// fnt: spec / out are in the reference's own layout, F x N x T (libs/wpe.py:84-110) -- which is
+// the layout the step kernel works in, so the two transposes fall away
 int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int num_channels,
                    const int* num_frames, int num_bins, int taps, int delay, int context,
                    int num_iters, const float* lambda_enh, const double* lambda_ft,
-                   float* const* out, float* inv_lambda_out, int* status, void* stream) {
+                   float* const* out, float* inv_lambda_out, int* status, void* stream,
+                   bool fnt = false) {
     if (!h || n_utts <= 0 || !spec || !out || !num_frames || num_bins <= 0 || num_iters <= 0 ||
         delay < 0 || context < 0)
         return fail(h, SETK_ERR_INVALID, "bad args");
@@ -1625,11 +1628,13 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
         if (rc) return rc;
         rc = stage_out(h, out[u], n * sizeof(float2), &q.ob);
         if (rc) return rc;
-        q.x_fct = static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
+        q.x_fct = fnt ? const_cast<float*>(q.d_spec) : static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
         q.bufs[0] = static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
         q.bufs[1] = static_cast<float*>(arena_alloc(h, n * sizeof(float2)));
         q.lam = static_cast<double*>(arena_alloc(h, (size_t)q.T * F * sizeof(double)));
         if (!q.x_fct || !q.bufs[0] || !q.bufs[1] || !q.lam) return fail(h, SETK_ERR_NOMEM, "arena");
+        // F x N x T in and out: the last iteration writes the caller's (or its staged) output
+        if (fnt) q.bufs[(num_iters - 1) & 1] = static_cast<float*>(q.ob.dev);
     }
     const float* d_enh = nullptr;
     if (lambda_enh) {
@@ -1648,8 +1653,9 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
     }
     int* d_st = static_cast<int*>(arena_alloc(h, (size_t)n_utts * F * sizeof(int) * (size_t)num_iters));
     if (!d_st) return fail(h, SETK_ERR_NOMEM, "arena");
-    for (int u = 0; u < n_utts; ++u)
-        HIP_TRY(h, launch_wpe_transpose(us[u].d_spec, C, us[u].T, F, us[u].x_fct, true, s));
+    if (!fnt)
+        for (int u = 0; u < n_utts; ++u)
+            HIP_TRY(h, launch_wpe_transpose(us[u].d_spec, C, us[u].T, F, us[u].x_fct, true, s));
     const size_t ab = wpe_args_bytes();
     std::vector<char> tbl((size_t)n_utts * ab);
     // SETK_WPE_TIMING=<file>: in-kernel cycle counters of the LAST iteration, [n_utts][F][4]
@@ -1683,8 +1689,9 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
     }
     for (int u = 0; u < n_utts; ++u) {
         Utt& q = us[u];
-        HIP_TRY(h, launch_wpe_transpose(q.bufs[(num_iters - 1) & 1], C, q.T, F,
-                                        static_cast<float*>(q.ob.dev), false, s));
+        if (!fnt)
+            HIP_TRY(h, launch_wpe_transpose(q.bufs[(num_iters - 1) & 1], C, q.T, F,
+                                            static_cast<float*>(q.ob.dev), false, s));
         rc = copy_back(h, q.ob, s);
         if (rc) return rc;
     }
@@ -1742,6 +1749,13 @@ int setk_wpe_batch(setk_handle_t h, int n_utts, const float* const* spec, int nu
                    int num_iters, float* const* out, int* status, void* stream) {
     return wpe_batch_impl(h, n_utts, spec, num_channels, num_frames, num_bins, taps, delay, context,
                           num_iters, nullptr, nullptr, out, nullptr, status, stream);
+}
+
+int setk_wpe_batch_fnt(setk_handle_t h, int n_utts, const float* const* spec, int num_channels,
+                       const int* num_frames, int num_bins, int taps, int delay, int context,
+                       int num_iters, float* const* out, int* status, void* stream) {
+    return wpe_batch_impl(h, n_utts, spec, num_channels, num_frames, num_bins, taps, delay, context,
+                          num_iters, nullptr, nullptr, out, nullptr, status, stream, true);
 }
 
 int setk_enhance_batch(setk_handle_t h, const setk_bf_opts* opts, int n_utts, int num_channels,

@@ -112,14 +112,32 @@ def wpe_step(reverb, yt, lambda_, taps=None, delay=None):
     return np.transpose(out, (2, 0, 1))
 
 
+def _run_fnt(reverbs, taps, delay, context, num_iters):
+    """F x N x T_u arrays through setk_wpe_batch_fnt: the reference's layout is the one the
+    step kernel works in, so nothing is transposed on the host or on the device.  Returns
+    (complex64 outputs, status [n][F])."""
+    specs = [np.ascontiguousarray(r, dtype=np.complex64) for r in reverbs]
+    F, N, _ = specs[0].shape
+    if any(s.shape[0] != F or s.shape[1] != N for s in specs):
+        raise ValueError("wpe_batch needs the same channel and bin count in every utterance")
+    outs = [np.empty_like(s) for s in specs]
+    status = np.zeros((len(specs), F), dtype=np.int32)
+    _ffi.default_context().wpe_batch_fnt(specs, N, [s.shape[2] for s in specs], F, taps, delay,
+                                         context, num_iters, outs, status=status)
+    return outs, status
+
+
 def wpe(reverb, taps=10, delay=3, context=1, num_iters=3):
     """GWPE.  reverb F x N x T complex -> dereverb F x N x T (complex128 like the
     reference's promoted result; computed in fp64, stored as complex64 between
     iterations)."""
     F, N, T = reverb.shape
     logger.info(f"WPE: F = {F}, N = {N}, T = {T}")
-    out, _ = _run(_to_ctf(reverb), taps, delay, context, num_iters)
-    return np.transpose(out, (2, 0, 1)).astype(np.complex128)
+    outs, status = _run_fnt([reverb], taps, delay, context, num_iters)
+    if status.any():
+        raise np.linalg.LinAlgError(
+            f"Singular matrix (tap correlation, {int(np.count_nonzero(status))} bins)")
+    return outs[0].astype(np.complex128)
 
 
 def wpe_batch(reverbs, taps=10, delay=3, context=1, num_iters=3):
@@ -129,16 +147,8 @@ def wpe_batch(reverbs, taps=10, delay=3, context=1, num_iters=3):
     singular comes back as None (the CLI skips it like the reference's LinAlgError)."""
     if not len(reverbs):
         return []
-    specs = [_to_ctf(r) for r in reverbs]
-    C, _, F = specs[0].shape
-    if any(s.shape[0] != C or s.shape[2] != F for s in specs):
-        raise ValueError("wpe_batch needs the same channel and bin count in every utterance")
-    outs = [np.empty_like(s) for s in specs]
-    status = np.zeros((len(specs), F), dtype=np.int32)
-    _ffi.default_context().wpe_batch(specs, C, [s.shape[1] for s in specs], F, taps, delay, context,
-                                     num_iters, outs, status=status)
-    return [None if status[u].any() else np.transpose(outs[u], (2, 0, 1)).astype(np.complex128)
-            for u in range(len(specs))]
+    outs, status = _run_fnt(reverbs, taps, delay, context, num_iters)
+    return [None if status[u].any() else outs[u].astype(np.complex128) for u in range(len(outs))]
 
 
 def facted_wpd(obs, cgmm_iters=10, wpd_iters=3, taps=10, delay=3, context=1, update_alpha=False):

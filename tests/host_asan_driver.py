@@ -181,6 +181,10 @@ def wpe(ctx, C, T, taps, delay):
         ctx.wpe(spec, C, T, F, taps, delay, 0, 1, out, lambda_enh=cplx(T, F),
                 inv_lambda_out=np.empty((F, T), np.float32), status=st)
         ctx.wpe_step(spec, C, T, F, taps, delay, rng.random((F, T)) + 0.1, out, status=st)
+        fnt = cplx(F, C, T)
+        ctx.wpe_batch_fnt([fnt, fnt[:, :, :T // 2].copy()], C, [T, T // 2], F, taps, delay, 1, 3,
+                          [np.empty_like(fnt), np.empty((F, C, T // 2), np.complex64)],
+                          status=np.zeros((2, F), np.int32))
         ctx.wpe_batch([spec, spec[:, :T // 2].copy()], C, [T, T // 2], F, taps, delay, 1, 2,
                       [out, np.empty((C, T // 2, F), np.complex64)], status=np.zeros((2, F), np.int32))
     except NotImplementedError:
