@@ -21,7 +21,6 @@ Differences, all deliberate (DESIGN.md "Reference bugs"):
 import argparse
 import os
 import math
-import sys
 
 import numpy as np
 

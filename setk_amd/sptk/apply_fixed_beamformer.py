@@ -18,7 +18,6 @@ import numpy as np
 from setk_amd import _ffi
 from setk_amd.dist import Shard
 from setk_amd.engine import FixedBatchBeamformer, Pcm16Frames
-from setk_amd.libs import wavio
 from setk_amd.libs.data_handler import ScpReader, WaveReader, WaveWriter
 from setk_amd.libs.opts import StftParser
 from setk_amd.libs.utils import get_logger
