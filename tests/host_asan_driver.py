@@ -214,9 +214,48 @@ def runtime_helpers(ctx):
     expect(ValueError, ctx.device_alloc, 0)
 
 
+def edge_geometries(ctx):
+    """Tiny and awkward lengths through the fused path, the fixed-weights path, the CGMM
+    estimator and the stand-alone transforms: every call must end in success or in an error
+    code -- never in an empty launch grid (the stand-in counts those) or a bad table."""
+    F_ = 257
+    for hop in (64, 128, 200, 256, 512):
+        for center in (True, False):
+            ctx.stft_plan(512, hop, 512, center)
+            for N in (1, 2, 255, 256, 257, 511, 512, 513, 767, 1024, 1025):
+                try:
+                    T = ctx.num_frames(N)
+                except ValueError:  # shorter than the reflect padding / than one frame
+                    T = 0
+                for C in (1, 3, 8):
+                    if T <= 0:
+                        expect((ValueError, NotImplementedError), ctx.stft,
+                               np.zeros((C, N), np.float32), np.empty((C, 1, F_), np.complex64))
+                        continue
+                    a = to_dev(rng.standard_normal((C, N)).astype(np.float32))
+                    m = to_dev(rng.random((T, F_)).astype(np.float32))
+                    L = max(ctx.istft_num_samples(T), 1)
+                    w = dmalloc(4 * L)
+                    opts = _ffi.BfOpts()
+                    opts.kind = 0
+                    opts.pmwf_ref = -1
+                    try:
+                        ctx.enhance_batch(opts, C, [a], [N], [m], None, [w])
+                        ctx.apply_weights_batch(C, [a], [N], cplx(1, F_, C), 1, None, [w])
+                        ctx.cgmm_estimate_batch(C, [a], [N], 2, None, [dmalloc(4 * T * F_)])
+                    except (ValueError, NotImplementedError):
+                        pass
+                    spec = np.empty((C, T, F_), np.complex64)
+                    ctx.stft(rng.standard_normal((C, N)).astype(np.float32), spec)
+                    ctx.istft(spec, C, T, None, None, np.empty((C, L), np.float32))
+                    release()
+    ctx.stft_plan(512, 256, 512, True)
+
+
 def main():
     ctx = _ffi.Context(0)
     runtime_helpers(ctx)
+    edge_geometries(ctx)
     if "--selftest-overflow" in sys.argv:
         # the sanitizer must be live: an output buffer one matrix short -> heap-buffer-overflow
         ctx.covar(cplx(2, 8, F), np.ones((8, F), np.float32), 2, 8, F, np.empty((F - 1, 2, 2), np.complex64))
