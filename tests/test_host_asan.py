@@ -162,3 +162,61 @@ def test_wpe_cli_host_side_under_asan(asan_env, tmp_path):
     for i, n in enumerate(lens):
         sr, y = scipy.io.wavfile.read(f"{td}/out/u{i}.wav")
         assert sr == 16000 and y.dtype == np.int16 and y.shape == (128 * (n // 128), 2)
+
+
+def _make_table(td, lens, channels=4, seed=0):
+    import numpy as np
+    from setk_amd.libs import wavio
+    rng = np.random.default_rng(seed)
+    with open(f"{td}/wav.scp", "w") as ws, open(f"{td}/mask.scp", "w") as ms:
+        for i, n in enumerate(lens):
+            wavio.write_pcm16(f"{td}/u{i}.wav", (rng.standard_normal((n, channels)) * 1000).astype(np.int16), 16000)
+            np.save(f"{td}/m{i}.npy", rng.random((1 + n // 256, 257)).astype(np.float32))
+            ws.write(f"u{i} {td}/u{i}.wav\n")
+            ms.write(f"u{i} {td}/m{i}.npy\n")
+
+
+def _cli(env, td, *extra, timeout=300):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py"),
+                           "--mask-format", "numpy", *extra, f"{td}/wav.scp", f"{td}/mask.scp", f"{td}/out"],
+                          capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_streaming_cli_failure_paths_do_not_hang(asan_env, tmp_path):
+    """What the pipeline does when things go wrong, on the stand-in (a hang is the timeout):
+    a writer that cannot create its file ends the run with that error after the other batches
+    were drained; a key without a mask is skipped; a mask of the wrong length is the reference's
+    ValueError; an empty table is a clean run."""
+    import numpy as np
+    td = str(tmp_path)
+    lens = [8000 + 997 * i for i in range(9)]
+    _make_table(td, lens)
+    os.makedirs(f"{td}/out/u4.wav")                       # the writer's open() of u4.wav fails
+    r = _cli(asan_env, td, "--batch-utts", "2", "--pipeline-depth", "2")
+    assert r.returncode != 0 and "IsADirectoryError" in r.stderr, r.stderr[-3000:]
+    assert "AddressSanitizer" not in r.stderr
+    written = sorted(f for f in os.listdir(f"{td}/out") if os.path.isfile(f"{td}/out/{f}"))
+    assert "u0.wav" in written and "u1.wav" in written    # batches before the failure came out
+    # a key without a mask is skipped, the rest is processed
+    td2 = str(tmp_path / "b")
+    os.makedirs(td2)
+    _make_table(td2, lens[:5])
+    lines = open(f"{td2}/mask.scp").read().splitlines()
+    open(f"{td2}/mask.scp", "w").write("\n".join(lines[:2] + lines[3:]) + "\n")
+    r = _cli(asan_env, td2, "--batch-utts", "2")
+    assert r.returncode == 0 and "Processed 4 utterances out of 5" in r.stderr, r.stderr[-3000:]
+    assert not os.path.exists(f"{td2}/out/u2.wav")
+    # a mask with too few rows: the reference's shape ValueError, raised by the planner
+    td3 = str(tmp_path / "c")
+    os.makedirs(td3)
+    _make_table(td3, lens[:3])
+    np.save(f"{td3}/m1.npy", np.ones((7, 257), np.float32))
+    r = _cli(asan_env, td3)
+    assert r.returncode != 0 and "do not match with mask" in r.stderr, r.stderr[-3000:]
+    # an empty table
+    td4 = str(tmp_path / "d")
+    os.makedirs(td4)
+    open(f"{td4}/wav.scp", "w").close()
+    open(f"{td4}/mask.scp", "w").close()
+    r = _cli(asan_env, td4)
+    assert (r.returncode == 0 and "Processed 0 utterances" in r.stderr) or "empty" in r.stderr.lower(), r.stderr[-2000:]
