@@ -220,3 +220,38 @@ def test_streaming_cli_failure_paths_do_not_hang(asan_env, tmp_path):
     open(f"{td4}/mask.scp", "w").close()
     r = _cli(asan_env, td4)
     assert (r.returncode == 0 and "Processed 0 utterances" in r.stderr) or "empty" in r.stderr.lower(), r.stderr[-2000:]
+
+
+def test_two_rank_cli_on_the_stand_in(tmp_path):
+    """The command line as torchrun starts it, two ranks, on CPU: gloo for the barrier and the
+    counters, the HIP stand-in (two pretended devices, no sanitizer: torch is in these
+    processes) for everything else.  Every utterance is written exactly once, by the rank the
+    duration-balanced deal gave it to, and rank 0 reports the total."""
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "hoststub", "build.sh")], capture_output=True,
+                       text=True, timeout=900, env=dict(os.environ, PLAIN="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    td = str(tmp_path)
+    lens = [16000, 64000, 8000, 30011, 16000, 12345, 48000, 9000]
+    _make_table(td, lens)
+    port = 29900 + (os.getpid() % 90)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HOSTSTUB_DEVICES="2",
+                   SETK_LIB=os.path.join(ROOT, "_abl", "libsetk_hoststub.so"))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py"),
+             "--mask-format", "numpy", "--batch-utts", "2", "--profile", f"{td}/prof.json",
+             f"{td}/wav.scp", f"{td}/mask.scp", f"{td}/out"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    errs = []
+    for p in procs:
+        _, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-3000:]
+        errs.append(e)
+    assert sorted(os.listdir(f"{td}/out")) == sorted(f"u{i}.wav" for i in range(len(lens)))
+    assert any("Processed 8 utterances out of 8" in e for e in errs), errs[0][-1500:]
+    import json
+    per_rank = [json.load(open(f"{td}/prof.json.rank{k}")) for k in range(2)]
+    assert sum(p["utts"] for p in per_rank) == 8 and all(p["utts"] >= 2 for p in per_rank)
+    assert all(p["mode"] == "pipeline" and p["world"] == 2 for p in per_rank)

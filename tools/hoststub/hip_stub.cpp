@@ -101,8 +101,14 @@ void hoststub_report(long* launches, long* violations, long* copies, long* live,
     if (first && cap > 0) snprintf(first, cap, "%s", g_first);
 }
 
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+// HOSTSTUB_DEVICES: how many devices to pretend to have (default 1; the two-rank CLI test: 2)
+static int device_count() {
+    const char* e = getenv("HOSTSTUB_DEVICES");
+    const int n = e ? atoi(e) : 1;
+    return n > 0 ? n : 1;
+}
+hipError_t hipGetDeviceCount(int* n) { *n = device_count(); return hipSuccess; }
+hipError_t hipSetDevice(int d) { return (d >= 0 && d < device_count()) ? hipSuccess : hipErrorInvalidDevice; }
 hipError_t hipGetLastError() { return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "hoststub error"; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
