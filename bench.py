@@ -329,7 +329,7 @@ SIMDS = 256 * 4            # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 XCDS = 8
 VALU_CYCLES_PER_INST = 2   # a wave64 VALU instruction occupies its SIMD-32 for two cycles
 # measured issue rate of a SIMD shared by n waves (plain fp32 VALU, profiles/r02t_valu_rate_pinned.txt)
-ISSUE_CYCLES_AT_WAVES = {1: 7.6, 2: 3.6, 4: 2.24}
+ISSUE_CYCLES_AT_WAVES = {1: 7.6, 2: 3.6, 3: 2.67, 4: 2.24}  # (3: profiles/r04f_valu_rate_pinned.txt)
 WAVES_PER_SIMD = {"pass1": 4, "pass2": 2}
 WAVES_WHY = {"pass1": "one 1024-thread workgroup per CU at the 128-VGPR budget",
              "pass2": "two 256-thread workgroups per CU: 63.6 KB of LDS each, 256 VGPRs per wave"}

@@ -78,7 +78,7 @@ void run(const char* name, int threads) {
 }
 
 int main() {
-    for (int th : {256, 512, 1024}) {
+    for (int th : {256, 512, 768, 1024}) {
         run<0>("v_fma_f32 indep", th);
         run<1>("v_fma_f32 dep", th);
         run<2>("v_add_f32 indep", th);
