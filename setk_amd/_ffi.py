@@ -89,6 +89,11 @@ def load_library():
         except Exception:  # pragma: no cover - torch is plumbing, not required
             pass
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    if hasattr(lib, "hoststub_report") and os.environ.get("SETK_ALLOW_HOSTSTUB") != "1":
+        # tools/hoststub: the library linked against a host-memory stand-in for HIP whose
+        # kernels do nothing -- test infrastructure for the host side, never a way to run
+        raise SetkError(f"{LIB_PATH} is the test build against the HIP stand-in (tools/hoststub); "
+                        "it computes nothing.  Tests that mean to load it set SETK_ALLOW_HOSTSTUB=1")
     H = c_void_p
     fp = c_void_p  # raw data pointers (host or device)
     lib.setk_abi_version.restype = c_int

@@ -2,7 +2,7 @@
 (tools/hoststub/build.sh: AddressSanitizer + UBSan, HIP replaced by a host-memory stand-in
 whose kernel launches only validate their configuration).  Run by tests/test_host_asan.py:
 
-    LD_PRELOAD=<libclang_rt.asan> SETK_LIB=_abl/libsetk_hostasan.so python tests/host_asan_driver.py
+    LD_PRELOAD=<libclang_rt.asan> SETK_ALLOW_HOSTSTUB=1 SETK_LIB=_abl/libsetk_hostasan.so python tests/host_asan_driver.py
 
 Outputs are not looked at (no kernel runs); what is checked is the host code: argument
 validation, descriptor tables, arena sizing, staging copies, launch geometry.  Prints one

@@ -34,7 +34,7 @@ def asan_env():
     env = dict(os.environ)
     # (a 64 KB table-staging buffer: the library's page-locked ring wraps many times in a run)
     env.update(LD_PRELOAD=rt, SETK_LIB=os.path.join(ROOT, "_abl", "libsetk_hostasan.so"),
-               SETK_PIN_CAP_KB="64",
+               SETK_PIN_CAP_KB="64", SETK_ALLOW_HOSTSTUB="1",
                ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:exitcode=99",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     return env
@@ -43,6 +43,15 @@ def asan_env():
 def _drive(env, *args):
     return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_asan_driver.py"), *args],
                           capture_output=True, text=True, env=env, timeout=900)
+
+
+def test_stand_in_is_refused_unless_asked_for(asan_env):
+    """SETK_LIB pointing at the stand-in build must not turn into a silent do-nothing run."""
+    env = dict(asan_env)
+    env.pop("SETK_ALLOW_HOSTSTUB")
+    r = subprocess.run([sys.executable, "-c", "from setk_amd import _ffi; _ffi.Context(0)"], capture_output=True,
+                       text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode != 0 and "stand-in" in r.stderr, r.stderr[-2000:]
 
 
 def test_sanitizer_is_live(asan_env):
@@ -237,7 +246,7 @@ def test_two_rank_cli_on_the_stand_in(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HOSTSTUB_DEVICES="2",
+                   MASTER_PORT=str(port), HOSTSTUB_DEVICES="2", SETK_ALLOW_HOSTSTUB="1",
                    SETK_LIB=os.path.join(ROOT, "_abl", "libsetk_hoststub.so"))
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py"),
