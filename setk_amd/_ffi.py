@@ -268,7 +268,7 @@ class Context:
         """Page-locked host memory: (address, uint8 numpy view)."""
         nbytes = int(nbytes)
         addr = self._out_ptr(self._lib.setk_host_alloc, ctypes.c_size_t(nbytes))
-        view = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(addr))
+        view = np.ctypeslib.as_array(ctypes.cast(addr, POINTER(ctypes.c_uint8)), shape=(nbytes,))
         return addr, view
 
     def host_free(self, addr):
