@@ -13,6 +13,7 @@
 
 #include "../../include/setk_hip.h"
 #include "common.h"
+#include "mcdft_tables.h"
 
 using namespace setk;
 
@@ -40,6 +41,12 @@ struct setk_context {
     float* d_winsq = nullptr;   // [n_fft]
     float2* d_tw256 = nullptr;  // [256]
     float2* d_tw512 = nullptr;  // [129]
+    // matrix-core transforms of the fused path (n_fft = 512; mcdft.h)
+    unsigned* d_mc_tab = nullptr;  // [mc::kTabWords][64] operand tiles (once per handle)
+    float* d_mc_win = nullptr;     // [8][64] analysis window rows x mc_scale
+    float* d_mc_syn = nullptr;     // [8][64] synthesis window rows / 512
+    double mc_peak = 1.0;          // |audio| <= mc_peak (a power of two)
+    bool mc_enabled = true;        // SETK_LEGACY_FFT=1: the fp32 butterfly kernels
     float2* d_twn = nullptr;    // [n_fft / 2] exp(-2 pi i k / n_fft), generic kernels
                                 // (Bluestein plans: [M / 2] exp(-2 pi i k / M))
     // n_fft that is not a power of two: Bluestein tables (modular.hip)
@@ -341,6 +348,9 @@ int setk_destroy(setk_handle_t h) {
     if (h->d_winsq) (void)hipFree(h->d_winsq);
     if (h->d_tw256) (void)hipFree(h->d_tw256);
     if (h->d_tw512) (void)hipFree(h->d_tw512);
+    if (h->d_mc_tab) (void)hipFree(h->d_mc_tab);
+    if (h->d_mc_win) (void)hipFree(h->d_mc_win);
+    if (h->d_mc_syn) (void)hipFree(h->d_mc_syn);
     if (h->d_twn) (void)hipFree(h->d_twn);
     if (h->d_chirp) (void)hipFree(h->d_chirp);
     if (h->d_bhat) (void)hipFree(h->d_bhat);
@@ -629,6 +639,23 @@ int setk_stft_plan(setk_handle_t h, int frame_len, int frame_hop, int n_fft, int
         h->d_twn = nullptr;
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_twn), tn.size() * sizeof(float2)));
         HIP_TRY(h, hipMemcpy(h->d_twn, tn.data(), tn.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
+    if (n_fft == kNfft) {
+        // matrix-core DFT-512: operand tiles once per handle, window rows per plan
+        if (!h->d_mc_tab) {
+            const std::vector<uint32_t> tab = mc::build_table();
+            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_mc_tab), tab.size() * sizeof(uint32_t)));
+            HIP_TRY(h, hipMemcpy(h->d_mc_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        if (!h->d_mc_win) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_mc_win), 8 * 64 * sizeof(float)));
+        if (!h->d_mc_syn) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_mc_syn), 8 * 64 * sizeof(float)));
+        std::vector<float> wt(n_fft);
+        for (int i = 0; i < n_fft; ++i) wt[i] = 2.f * w[i];  // w holds 0.5 x window (exact)
+        const std::vector<float> wr = mc::build_window_rows(wt.data(), 1024.0 / h->mc_peak);
+        const std::vector<float> sr = mc::build_synth_rows(wt.data(), h->mc_peak / 1024.0 / 512.0);
+        HIP_TRY(h, hipMemcpy(h->d_mc_win, wr.data(), wr.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_mc_syn, sr.data(), sr.size() * sizeof(float), hipMemcpyHostToDevice));
+        h->mc_enabled = !(getenv("SETK_LEGACY_FFT") && atoi(getenv("SETK_LEGACY_FFT")) != 0);
     }
     h->frame_len = frame_len;
     h->hop = frame_hop;
@@ -1919,7 +1946,13 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     p1.norm_bits = d_norm;
     p1.g = g;
     p1.flags = opts->flags;
-    HIP_TRY(h, launch_pass1(C, false, p1, (int)items1.size(), s));
+    p1.mc_tab = h->d_mc_tab;
+    p1.mc_win = h->d_mc_win;
+    const bool mc1 = h->mc_enabled && !(getenv("SETK_MC_PASS1") && atoi(getenv("SETK_MC_PASS1")) == 0);
+    if (mc1)
+        HIP_TRY(h, launch_pass1_mc(C, p1, (int)items1.size(), s));
+    else
+        HIP_TRY(h, launch_pass1(C, false, p1, (int)items1.size(), s));
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[1], s));
     FinalizeArgs fa;
     memset(&fa, 0, sizeof(fa));
@@ -1928,6 +1961,7 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     fa.covar = d_covar;
     fa.num_channels = C;
     fa.with_ry = mpdr ? 1 : 0;
+    fa.num_scale = mc1 ? (float)((h->mc_peak / 1024.0) * (h->mc_peak / 1024.0)) : 1.f;
     HIP_TRY(h, launch_finalize(fa, n_utts, s));
     OutBuf tap_rs, tap_rn, tap_w;
     if (taps && taps->Rs) {
@@ -1994,7 +2028,13 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     p2.outmax_bits = d_omax;
     p2.g = g;
     p2.flags = opts->flags;
-    HIP_TRY(h, launch_pass2(C, false, p2, (int)items2.size(), s));
+    p2.mc_tab = h->d_mc_tab;
+    p2.mc_win = h->d_mc_win;
+    p2.mc_syn = h->d_mc_syn;
+    if (h->mc_enabled && !(getenv("SETK_MC_PASS2") && atoi(getenv("SETK_MC_PASS2")) == 0))
+        HIP_TRY(h, launch_pass2_mc(C, p2, (int)items2.size(), s));
+    else
+        HIP_TRY(h, launch_pass2(C, false, p2, (int)items2.size(), s));
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[3], s));
 
     // ---- stage 4: renorm ----

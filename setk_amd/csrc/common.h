@@ -75,6 +75,9 @@ struct Pass1Args {
     int dump_pitch;         // DUMP mode: row pitch in complex entries (0 = F)
     StftGeom g;
     int flags;
+    // matrix-core transforms (pass1_mc.hip / mcdft.h)
+    const unsigned* mc_tab;  // [mc::kTabWords][64] operand tiles
+    const float* mc_win;     // [8][64] analysis window rows x 2^10 / peak
 };
 
 struct FinalizeArgs {
@@ -83,6 +86,7 @@ struct FinalizeArgs {
     float* covar;  // [n_utts][4*NP (+2*NP when with_ry)][kBinsPad]
     int num_channels;
     int with_ry;   // also emit Ry = (Rs_num + Rn_num) / T  (MPDR)
+    float num_scale;  // numerators x this (matrix-core pass 1: (peak / 2^10)^2; else 1)
 };
 
 struct SolveArgs {
@@ -113,6 +117,10 @@ struct Pass2Args {
     unsigned* outmax_bits;   // [n_utts]
     StftGeom g;
     int flags;
+    // matrix-core transforms (pass2_mc.hip / mcdft.h)
+    const unsigned* mc_tab;  // [mc::kTabWords][64]
+    const float* mc_win;     // [8][64] analysis window rows x 2^10 / peak
+    const float* mc_syn;     // [8][64] synthesis window rows x peak / 2^10 / 512
 };
 
 struct ScaleArgs {
@@ -125,6 +133,8 @@ struct ScaleArgs {
 
 // launchers (implemented in the kernel TUs)
 hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s);
+hipError_t launch_pass1_mc(int C, const Pass1Args& a, int n_items, hipStream_t s);
+hipError_t launch_pass2_mc(int C, const Pass2Args& a, int n_items, hipStream_t s);
 // STFT of whole utterances into the bin-major [F][C][Tp] layout of cgmm_bin.hip
 // (items: 64-frame blocks; UttDesc::wave_out = the utterance's output)
 hipError_t launch_stft_binmajor(int C, const Pass1Args& a, int n_items, hipStream_t s);

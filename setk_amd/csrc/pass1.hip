@@ -25,89 +25,11 @@
 // role alone, -DSETK_NO_GLOAD skips the audio loads (timing only, wrong results).
 #include "common.h"
 #include "fft512.h"
+#include "covar_fold.h"
 #include <cstdio>
 #include <cstdlib>
 
 namespace setk {
-
-// ---- Hermitian pairs split over the two covariance halves -------------------
-// Half H owns the diagonals (i, i) with i % 2 == H (real: one accumulator per
-// mask) and every other off-diagonal pair of the (i < j) enumeration.  Keeping
-// the diagonals apart saves their imaginary accumulators (8 VGPRs at C = 8).
-// Planes in the partial slab stay in the global (i <= j) order: pair_index()
-// of common.h.
-template <int C>
-struct PairSplit {
-    static constexpr int ND = (C + 1) / 2;                 // diagonals per half (max)
-    static constexpr int NO = (C * (C - 1) / 2 + 1) / 2;   // off-diagonal pairs per half (max)
-};
-
-template <int C, int H>
-SETK_DEV void accumulate_half(const cf (&x)[C], float ws, float wn, float* ds, float* dn, cf* os,
-                              cf* on) {
-#pragma unroll
-    for (int i = H; i < C; i += 2) {
-        const float p = fmaf(x[i].x, x[i].x, x[i].y * x[i].y);
-        ds[i / 2] = fmaf(ws, p, ds[i / 2]);
-        dn[i / 2] = fmaf(wn, p, dn[i / 2]);
-    }
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < C; ++i)
-#pragma unroll
-        for (int j = i + 1; j < C; ++j) {
-            if ((k & 1) == H) {
-                const cf p = cmulc(x[i], x[j]);
-                os[k / 2].x = fmaf(ws, p.x, os[k / 2].x);
-                on[k / 2].x = fmaf(wn, p.x, on[k / 2].x);
-                os[k / 2].y = fmaf(ws, p.y, os[k / 2].y);
-                on[k / 2].y = fmaf(wn, p.y, on[k / 2].y);
-            }
-            ++k;
-        }
-}
-
-template <int C, int H>
-SETK_DEV void store_half(float* P, int f, const float* ds, const float* dn, const cf* os,
-                         const cf* on) {
-    constexpr int NP = npairs(C);
-    constexpr int FP = kBinsPad;
-#pragma unroll
-    for (int i = H; i < C; i += 2) {
-        const int e = pair_index(i, i, C);
-        P[(0 * NP + e) * FP + f] = ds[i / 2];
-        P[(1 * NP + e) * FP + f] = 0.f;
-        P[(2 * NP + e) * FP + f] = dn[i / 2];
-        P[(3 * NP + e) * FP + f] = 0.f;
-    }
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < C; ++i)
-#pragma unroll
-        for (int j = i + 1; j < C; ++j) {
-            if ((k & 1) == H) {
-                const int e = pair_index(i, j, C);
-                P[(0 * NP + e) * FP + f] = os[k / 2].x;
-                P[(1 * NP + e) * FP + f] = os[k / 2].y;
-                P[(2 * NP + e) * FP + f] = on[k / 2].x;
-                P[(3 * NP + e) * FP + f] = on[k / 2].y;
-            }
-            ++k;
-        }
-}
-
-// max(m, |a|, |b|) in one VALU instruction
-SETK_DEV float max3_abs(float m, float a, float b) {
-    float r;
-    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
-    return r;
-}
-
-SETK_DEV void wg_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 template <int C, bool DUMP>
 __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
@@ -517,7 +439,7 @@ __global__ __launch_bounds__(320) void covar_finalize_kernel(FinalizeArgs a) {
             acc += P[p * slab + (size_t)e * kBinsPad + f];
             den += P[p * slab + (size_t)(4 * NP + sel) * kBinsPad + f];
         }
-        out[f] = acc / fmaxf(den, 1e-6f);
+        out[f] = acc * a.num_scale / fmaxf(den, 1e-6f);
     } else {
         // Ry: all-ones mask == speech + noise numerators when mask_n = 1 - mask_s
         const int r = e - 4 * NP;  // [0, 2NP)
@@ -525,7 +447,7 @@ __global__ __launch_bounds__(320) void covar_finalize_kernel(FinalizeArgs a) {
         for (int p = 0; p < ud.nparts; ++p)
             acc += P[p * slab + (size_t)r * kBinsPad + f] +
                    P[p * slab + (size_t)(2 * NP + r) * kBinsPad + f];
-        out[f] = acc / fmaxf((float)ud.num_frames, 1e-6f);
+        out[f] = acc * a.num_scale / fmaxf((float)ud.num_frames, 1e-6f);
     }
 }
 
