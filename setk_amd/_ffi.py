@@ -55,6 +55,29 @@ _lib = None
 TORCH_FREE = os.environ.get("SETK_TORCH_FREE", "") not in ("", "0")
 
 
+def set_torch_free(ok=True):
+    """What the CLIs call before the first Context: run torch-free unless the caller knows an
+    input needs a torch path (`ok` false), the user said SETK_TORCH_FREE=0, or torch is loaded
+    already.  Returns whether the process is torch-free now."""
+    global TORCH_FREE
+    if not ok or os.environ.get("SETK_TORCH_FREE", "") == "0" or "torch" in sys.modules:
+        return TORCH_FREE and "torch" not in sys.modules
+    TORCH_FREE = True
+    return True
+
+
+def import_torch(what="this path"):
+    """torch for the code paths that run through torch tensors.  In a process that loaded the
+    library torch-free the import would come too late (the library is bound to the HIP runtime
+    of /opt/rocm by then; torch must be imported BEFORE it): say so instead of importing."""
+    if TORCH_FREE and _lib is not None and "torch" not in sys.modules:
+        raise SetkUnsupported(
+            f"{what} runs through torch tensors, but this process loaded {LIB_PATH} torch-free "
+            "(streaming CLI mode); re-run with SETK_TORCH_FREE=0")
+    import torch
+    return torch
+
+
 def exported_symbols():
     """Names declared in include/setk_hip.h (checked by the CPU test-suite)."""
     return [

@@ -44,7 +44,10 @@ struct setk_context {
     // matrix-core transforms of the fused path (n_fft = 512; mcdft.h)
     unsigned* d_mc_tab = nullptr;  // [mc::kTabWords][64] operand tiles (once per handle)
     float* d_mc_win = nullptr;     // [8][64] analysis window rows x mc_scale
-    float* d_mc_syn = nullptr;     // [8][64] synthesis window rows / 512
+    float* d_mc_syn = nullptr;     // [8][64] synthesis window rows / 512 / sum(window^2) (hop = n_fft / 2)
+    float* d_mc_edge = nullptr;    // [8][64] corrections of the single-contribution blocks
+    int mc_cus = 256;
+    int mc_p2_items = 0;           // SETK_MC_P2_ITEMS: resident workgroup slots of pass2_mc (0: from the kernel)
     double mc_peak = 1.0;          // |audio| <= mc_peak (a power of two)
     bool mc_enabled = true;        // SETK_LEGACY_FFT=1: the fp32 butterfly kernels
     float2* d_twn = nullptr;    // [n_fft / 2] exp(-2 pi i k / n_fft), generic kernels
@@ -332,7 +335,9 @@ int setk_create(setk_handle_t* out, int device_ordinal) {
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) {
         h->p1_items = prop.multiProcessorCount;
         h->p2_items = 2 * prop.multiProcessorCount;
+        h->mc_cus = prop.multiProcessorCount;
     }
+    if (const char* e = getenv("SETK_MC_P2_ITEMS")) h->mc_p2_items = std::max(1, atoi(e));
     if (const char* e = getenv("SETK_P1_ITEMS")) h->p1_items = std::max(1, atoi(e));
     if (const char* e = getenv("SETK_P2_ITEMS")) h->p2_items = std::max(1, atoi(e));
     *out = h;
@@ -351,6 +356,7 @@ int setk_destroy(setk_handle_t h) {
     if (h->d_mc_tab) (void)hipFree(h->d_mc_tab);
     if (h->d_mc_win) (void)hipFree(h->d_mc_win);
     if (h->d_mc_syn) (void)hipFree(h->d_mc_syn);
+    if (h->d_mc_edge) (void)hipFree(h->d_mc_edge);
     if (h->d_twn) (void)hipFree(h->d_twn);
     if (h->d_chirp) (void)hipFree(h->d_chirp);
     if (h->d_bhat) (void)hipFree(h->d_bhat);
@@ -649,12 +655,29 @@ int setk_stft_plan(setk_handle_t h, int frame_len, int frame_hop, int n_fft, int
         }
         if (!h->d_mc_win) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_mc_win), 8 * 64 * sizeof(float)));
         if (!h->d_mc_syn) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_mc_syn), 8 * 64 * sizeof(float)));
+        if (!h->d_mc_edge) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_mc_edge), 8 * 64 * sizeof(float)));
         std::vector<float> wt(n_fft);
         for (int i = 0; i < n_fft; ++i) wt[i] = 2.f * w[i];  // w holds 0.5 x window (exact)
         const std::vector<float> wr = mc::build_window_rows(wt.data(), 1024.0 / h->mc_peak);
-        const std::vector<float> sr = mc::build_synth_rows(wt.data(), h->mc_peak / 1024.0 / 512.0);
+        // pass2_mc (hop = n_fft / 2): a block of hop samples is first half of frame t + second
+        // half of frame t - 1, both over the same sum(window^2) -- folded into the rows
+        // (librosa.istft: divided only where it exceeds tiny); blocks with one contribution
+        // (first / last of an utterance, center = False) take the ratio as a correction
+        const double tiny = 1.17549435e-38;
+        std::vector<float> syn(n_fft), edge(n_fft);
+        for (int m = 0; m < n_fft / 2; ++m) {
+            const double a2 = (double)w2[m], b2 = (double)w2[m + n_fft / 2];
+            const double mid = (a2 + b2 > tiny) ? a2 + b2 : 1.0;
+            syn[m] = (float)((double)wt[m] * h->mc_peak / 1024.0 / 512.0 / mid);
+            syn[m + n_fft / 2] = (float)((double)wt[m + n_fft / 2] * h->mc_peak / 1024.0 / 512.0 / mid);
+            edge[m] = (float)(mid / (a2 > tiny ? a2 : 1.0));
+            edge[m + n_fft / 2] = (float)(mid / (b2 > tiny ? b2 : 1.0));
+        }
+        const std::vector<float> sr = mc::build_synth_rows(syn.data(), 1.0);
+        const std::vector<float> er = mc::build_synth_rows(edge.data(), 1.0);
         HIP_TRY(h, hipMemcpy(h->d_mc_win, wr.data(), wr.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_mc_syn, sr.data(), sr.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_mc_edge, er.data(), er.size() * sizeof(float), hipMemcpyHostToDevice));
         h->mc_enabled = !(getenv("SETK_LEGACY_FFT") && atoi(getenv("SETK_LEGACY_FFT")) != 0);
     }
     h->frame_len = frame_len;
@@ -1837,7 +1860,12 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     std::vector<int> all_frames(n_utts);
     for (int u = 0; u < n_utts; ++u) all_frames[u] = setk_stft_num_frames(h, num_samples[u]);
     const int target1 = choose_target(all_frames, h->p1_items, pass1_tile_frames(C), pass1_tile_frames(C) * 8);
-    const int target2 = choose_target(all_frames, h->p2_items, kSuperTile, kSuperTile * 4);
+    // pass 2 on the matrix cores: hop = n_fft / 2 only (wave-resident overlap-add, pass2_mc.hip)
+    const bool mc2 = h->mc_enabled && 2 * g.hop == kNfft && g.keep == 1 &&
+                     !(getenv("SETK_MC_PASS2") && atoi(getenv("SETK_MC_PASS2")) == 0);
+    const int quant2 = mc2 ? 8 : kSuperTile;
+    const int target2 = mc2 ? choose_target(all_frames, h->mc_p2_items > 0 ? h->mc_p2_items : h->mc_cus * pass2_mc_wgs_per_cu(C), quant2, 64)
+                            : choose_target(all_frames, h->p2_items, kSuperTile, kSuperTile * 4);
     int nparts_total = 0;
     for (int u = 0; u < n_utts; ++u) {
         UttDesc& ud = uds[u];
@@ -1854,7 +1882,7 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
         max_len = std::max(max_len, ud.out_len);
         std::vector<std::pair<int, int>> r1, r2;
         split_frames(ud.num_frames, target1, pass1_tile_frames(C), &r1);
-        split_frames(ud.num_frames, target2, kSuperTile, &r2);
+        split_frames(ud.num_frames, target2, quant2, &r2);
         ud.part0 = nparts_total;
         ud.nparts = (int)r1.size();
         for (auto& r : r1)
@@ -1948,7 +1976,9 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     p1.flags = opts->flags;
     p1.mc_tab = h->d_mc_tab;
     p1.mc_win = h->d_mc_win;
-    const bool mc1 = h->mc_enabled && !(getenv("SETK_MC_PASS1") && atoi(getenv("SETK_MC_PASS1")) == 0);
+    // pass 1 on the matrix cores is opt-in (SETK_MC_PASS1=1): parity-green, but its transform
+    // waves are the long pole of the tile pipeline (0.95 ms against 0.88)
+    const bool mc1 = h->mc_enabled && getenv("SETK_MC_PASS1") && atoi(getenv("SETK_MC_PASS1")) != 0;
     if (mc1)
         HIP_TRY(h, launch_pass1_mc(C, p1, (int)items1.size(), s));
     else
@@ -2031,7 +2061,8 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     p2.mc_tab = h->d_mc_tab;
     p2.mc_win = h->d_mc_win;
     p2.mc_syn = h->d_mc_syn;
-    if (h->mc_enabled && !(getenv("SETK_MC_PASS2") && atoi(getenv("SETK_MC_PASS2")) == 0))
+    p2.mc_edge = h->d_mc_edge;
+    if (mc2)
         HIP_TRY(h, launch_pass2_mc(C, p2, (int)items2.size(), s));
     else
         HIP_TRY(h, launch_pass2(C, false, p2, (int)items2.size(), s));

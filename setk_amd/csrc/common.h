@@ -120,7 +120,8 @@ struct Pass2Args {
     // matrix-core transforms (pass2_mc.hip / mcdft.h)
     const unsigned* mc_tab;  // [mc::kTabWords][64]
     const float* mc_win;     // [8][64] analysis window rows x 2^10 / peak
-    const float* mc_syn;     // [8][64] synthesis window rows x peak / 2^10 / 512
+    const float* mc_syn;     // [8][64] synthesis window rows x peak / 2^10 / 512 / sum(window^2)
+    const float* mc_edge;    // [8][64] corrections of the single-contribution blocks (first | last)
 };
 
 struct ScaleArgs {
@@ -135,6 +136,7 @@ struct ScaleArgs {
 hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s);
 hipError_t launch_pass1_mc(int C, const Pass1Args& a, int n_items, hipStream_t s);
 hipError_t launch_pass2_mc(int C, const Pass2Args& a, int n_items, hipStream_t s);
+int pass2_mc_wgs_per_cu(int C);
 // STFT of whole utterances into the bin-major [F][C][Tp] layout of cgmm_bin.hip
 // (items: 64-frame blocks; UttDesc::wave_out = the utterance's output)
 hipError_t launch_stft_binmajor(int C, const Pass1Args& a, int n_items, hipStream_t s);

@@ -63,6 +63,16 @@ enum : int {
     kTabWords = 92
 };
 
+// Sample of register e of lane l in the stage-1 data operand: K index k = 8 g + e <-> n1 =
+// 4 g + e (e < 4: first half of the frame), 16 + 4 g + e - 4 (e >= 4: second half); the
+// contraction order is free as long as the tiles follow it (mcdft_tables.h).  With hop = 256
+// a lane's registers e >= 4 of frame t ARE its registers e < 4 of frame t + 1: a wave that
+// walks consecutive frames of a channel loads four new samples per lane and frame, not eight.
+__host__ __device__ constexpr int stage1_n1(int k) {
+    return (k % 8 < 4) ? 4 * (k / 8) + k % 8 : 16 + 4 * (k / 8) + k % 8 - 4;
+}
+__host__ __device__ constexpr int sample_of(int lane, int e) { return 16 * stage1_n1(8 * (lane >> 4) + e) + (lane & 15); }
+
 MC_DEV h8 tab_h8(const unsigned* tab, int word, int lane) {
     u4 w;
     w[0] = tab[(word + 0) * 64 + lane];
@@ -199,58 +209,68 @@ MC_DEV void load_fwd(Fwd& K, const unsigned* tab, int lane) {
     }
 }
 
-// x[e] = sample 16 (8 g + e) + l % 16 of the frame, w[e] its window value (x the range scale).
+// x[e] = sample sample_of(l, e) of the frame, w[e] its window value (x the range scale).
 // Out: lane (c = l % 16, g), register r:  z = X[bin_of(c, g, r)]
 //   = X[c + 32 (4 g + r)] for g < 2,  X[32 (13 - 4 g + r) - c] for g >= 2;
 //   column 0 is valid for g < 2 and (g, r) = (2, 3) (bin 256); its other registers repeat
 //   bins 32 .. 224 from the conjugate side
 //   a16[r] (lanes c == 0 only) = A[16][n2 = 4 g + r], the input of the odd-family tile.
-#ifndef MCDFT_HI_FIRST
-#define MCDFT_HI_FIRST 1
-#endif
-MC_DEV void forward(const float (&x)[8], const float (&w)[8], const Fwd& K, f4& zr, f4& zi, f4& a16) {
+// The operand tiles come from `tile(i)`, i = 0..7: mc_h mc_l ms_h ms_l ar_h ar_l ai_h ai_l --
+// registers (Fwd) or LDS (stage_tiles + lds_h8: four waves' worth of registers for 8 x
+// ds_read_b128 per transform).
+template <class TileFn>
+MC_DEV void forward_t(const float (&x)[8], const float (&w)[8], TileFn tile, const float (&tr)[4],
+                      const float (&ti)[4], const float (&tri)[4], f4& zr, f4& zi, f4& a16) {
     h8 xh, xl;
-#if MCDFT_HI_FIRST
     // the products of the hi halves go first: the matrix pipe starts while the lo halves
     // are still being formed on the vector ALU
     split8_mul_hi(x, w, xh);
     f4 dc = {0.f, 0.f, 0.f, 0.f}, ds = {0.f, 0.f, 0.f, 0.f};
-    dc = mfma16(xh, K.mc_h, dc);
-    ds = mfma16(xh, K.ms_h, ds);
-    dc = mfma16(xh, K.mc_l, dc);
-    ds = mfma16(xh, K.ms_l, ds);
-    split8_mul_lo(x, w, xh, xl);
-    dc = mfma16(xl, K.mc_h, dc);
-    ds = mfma16(xl, K.ms_h, ds);
-#else
-    split8_mul(x, w, xh, xl);
-    const f4 dc = mm3_data_a(xh, xl, K.mc_h, K.mc_l);
-    const f4 ds = mm3_data_a(xh, xl, K.ms_h, K.ms_l);
-#endif
+    {
+        const h8 mc_h = tile(0), ms_h = tile(2);
+        dc = mfma16(xh, mc_h, dc);
+        ds = mfma16(xh, ms_h, ds);
+        dc = mfma16(xh, tile(1), dc);
+        ds = mfma16(xh, tile(3), ds);
+        split8_mul_lo(x, w, xh, xl);
+        dc = mfma16(xl, mc_h, dc);
+        ds = mfma16(xl, ms_h, ds);
+    }
     a16 = ds;
     float b[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        b[r] = fmaf(dc[r], K.tr[r], -ds[r] * K.ti[r]);
-        b[4 + r] = fmaf(dc[r], K.ti[r], ds[r] * K.tri[r]);
+        b[r] = fmaf(dc[r], tr[r], -ds[r] * ti[r]);
+        b[4 + r] = fmaf(dc[r], ti[r], ds[r] * tri[r]);
     }
     h8 bh, bl;
-#if MCDFT_HI_FIRST
     split8_hi(b, bh);
     zr = (f4){0.f, 0.f, 0.f, 0.f};
     zi = (f4){0.f, 0.f, 0.f, 0.f};
-    zr = mfma16(K.ar_h, bh, zr);
-    zi = mfma16(K.ai_h, bh, zi);
-    zr = mfma16(K.ar_l, bh, zr);
-    zi = mfma16(K.ai_l, bh, zi);
-    split8_lo(b, bh, bl);
-    zr = mfma16(K.ar_h, bl, zr);
-    zi = mfma16(K.ai_h, bl, zi);
-#else
-    split8(b, bh, bl);
-    zr = mm3_data_b(K.ar_h, K.ar_l, bh, bl);
-    zi = mm3_data_b(K.ai_h, K.ai_l, bh, bl);
-#endif
+    {
+        const h8 ar_h = tile(4), ai_h = tile(6);
+        zr = mfma16(ar_h, bh, zr);
+        zi = mfma16(ai_h, bh, zi);
+        zr = mfma16(tile(5), bh, zr);
+        zi = mfma16(tile(7), bh, zi);
+        split8_lo(b, bh, bl);
+        zr = mfma16(ar_h, bl, zr);
+        zi = mfma16(ai_h, bl, zi);
+    }
+}
+MC_DEV void forward(const float (&x)[8], const float (&w)[8], const Fwd& K, f4& zr, f4& zi, f4& a16) {
+    forward_t(x, w, [&](int i) -> h8 {
+        switch (i) {
+            case 0: return K.mc_h;
+            case 1: return K.mc_l;
+            case 2: return K.ms_h;
+            case 3: return K.ms_l;
+            case 4: return K.ar_h;
+            case 5: return K.ar_l;
+            case 6: return K.ai_h;
+            default: return K.ai_l;
+        }
+    }, K.tr, K.ti, K.tri, zr, zi, a16);
 }
 
 // bin of register r of this lane (c = l % 16, g = l / 16)

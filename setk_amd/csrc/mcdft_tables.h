@@ -54,9 +54,11 @@ inline std::vector<uint32_t> build_table() {
     // row 4 g + r of a result tile <-> q: rows 8..15 run backwards inside each group of four, so
     // that the bins of a lane ascend with r in every lane (mcdft.h bin_of)
     auto row_q = [](int row) { return row < 8 ? row : 4 * (row / 4) + 3 - row % 4; };
-    // stage 1 (B operands): i = column c, k = n1
-    put_tile(tab, kW_MC_H, kW_MC_L, [&](int c, int n1) { return std::cos(2 * PI * n1 * c / 32); });
-    put_tile(tab, kW_MS_H, kW_MS_L, [&](int c, int n1) {
+    // stage 1 (B operands): i = column c, k <-> n1 by stage1_n1 (mcdft.h: consecutive frames
+    // share half of a lane's sample registers)
+    put_tile(tab, kW_MC_H, kW_MC_L, [&](int c, int k) { return std::cos(2 * PI * stage1_n1(k) * c / 32); });
+    put_tile(tab, kW_MS_H, kW_MS_L, [&](int c, int k) {
+        const int n1 = stage1_n1(k);
         return c == 0 ? ((n1 & 1) ? -1.0 : 1.0) : -std::sin(2 * PI * n1 * c / 32);
     });
     // stage 2 (A operands): i = row <-> q, k <-> (part, n2)
@@ -112,11 +114,11 @@ inline std::vector<uint32_t> build_table() {
     return tab;
 }
 
-// analysis window rows: [8][64] floats, entry e of lane l = window[16 (8 g + e) + l % 16] * scale
+// analysis window rows: [8][64] floats, entry e of lane l = window[sample_of(l, e)] * scale
 inline std::vector<float> build_window_rows(const float* window512, double scale) {
     std::vector<float> w(8 * 64);
     for (int l = 0; l < 64; ++l)
-        for (int e = 0; e < 8; ++e) w[e * 64 + l] = (float)(window512[16 * (8 * (l >> 4) + e) + (l & 15)] * scale);
+        for (int e = 0; e < 8; ++e) w[e * 64 + l] = (float)(window512[sample_of(l, e)] * scale);
     return w;
 }
 // synthesis window rows: [8][64], entry 4 tl + r of lane l = window[16 (16 tl + 4 g + r) + l % 16] * scale

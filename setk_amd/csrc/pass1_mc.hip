@@ -24,7 +24,7 @@ namespace setk {
 
 constexpr int kMcSlot = 272;  // complex entries per spectrum slot (257 used; 16-byte multiple)
 
-// raw frame samples in the operand layout of mcdft.h: v[e] = x[s + 16 (8 g + e) + l % 16]
+// raw frame samples in the operand layout of mcdft.h: v[e] = x[s + mc::sample_of(lane, e)]
 template <class FloatPtr>
 SETK_DEV void load_raw_mc(float (&v)[8], FloatPtr x, int n_samp, int s, int lane, bool valid) {
     if (!valid) {
@@ -32,14 +32,20 @@ SETK_DEV void load_raw_mc(float (&v)[8], FloatPtr x, int n_samp, int s, int lane
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
         return;
     }
-    const int o = 128 * (lane >> 4) + (lane & 15);
+    const int o = 64 * (lane >> 4) + (lane & 15);  // mc::sample_of(lane, e) = o + 16 e (+ 192 for e >= 4)
     if (s >= 0 && s + kFrame <= n_samp) {
         FloatPtr p = x + s + o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = p[16 * e];
+        for (int e = 0; e < 4; ++e) {
+            v[e] = p[16 * e];
+            v[4 + e] = p[256 + 16 * e];
+        }
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = x[reflect_index(s + o + 16 * e, n_samp)];
+        for (int e = 0; e < 4; ++e) {
+            v[e] = x[reflect_index(s + o + 16 * e, n_samp)];
+            v[4 + e] = x[reflect_index(s + o + 256 + 16 * e, n_samp)];
+        }
     }
 }
 

@@ -6,15 +6,16 @@
 // (libs/utils.py:142-173 -> librosa.istft 0.8.1: irfft, * window, overlap-add,
 // / sum(window^2) where > tiny, trim n_fft/2; the inf-norm rescale is scale_kernel).
 //
-// One wavefront owns one frame at a time: it transforms the C channels one after the other
-// (12 MFMA + ~60 VALU wave-instructions each; the next channel's samples in flight), folds
-// conj(w_c) X_c into four complex accumulators per lane (the lane's bins are fixed, its
-// weights come from an LDS table as one base address + immediates), adds the odd family
-// X[16 + 32 q] of all channels from ONE extra tile per frame, scales the frame's spectrum by a
-// power of two into the fp16 operand range, inverse-transforms (12 MFMA), windows and leaves
-// the frame in its LDS slot.  No workgroup barrier in that chain; the overlap-add of a
-// 16-frame super-tile is pass2.hip's.  ~110 VGPRs: four waves per SIMD (two 512-thread
-// workgroups per CU) where the butterfly kernel ran two.
+// One wavefront owns a run of consecutive frames, one frame at a time: it transforms the C
+// channels one after the other (12 MFMA + ~90 VALU wave-instructions each; the samples two
+// transforms ahead in flight), folds conj(w_c) X_c into four complex accumulators per lane (the
+// lane's bins are fixed, its weights come from an LDS table as one base address +
+// immediates), adds the odd family X[16 + 32 q] of all channels from ONE extra tile per frame,
+// scales the frame's spectrum by a power of two into the fp16 operand range,
+// inverse-transforms (12 MFMA), windows, and completes one block of hop output samples per
+// frame from its own registers (hop = n_fft / 2: see the kernel).  No frame slots, no
+// workgroup barrier, no overlap-add loop; ~128 VGPRs: four waves per SIMD where the butterfly
+// kernel ran two.  Other hops keep pass2.hip.
 #include "common.h"
 #include "fft512.h"
 #include "mcdft.h"
@@ -31,28 +32,52 @@ SETK_DEV void load_raw_mc2(float (&v)[8], FloatPtr x, int n_samp, int s, int lan
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
         return;
     }
-    const int o = 128 * (lane >> 4) + (lane & 15);
+    const int o = 64 * (lane >> 4) + (lane & 15);  // mc::sample_of(lane, e) = o + 16 e (+ 192 for e >= 4)
     if (s >= 0 && s + kFrame <= n_samp) {
         FloatPtr p = x + s + o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = p[16 * e];
+        for (int e = 0; e < 4; ++e) {
+            v[e] = p[16 * e];
+            v[4 + e] = p[256 + 16 * e];
+        }
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = x[reflect_index(s + o + 16 * e, n_samp)];
+        for (int e = 0; e < 4; ++e) {
+            v[e] = x[reflect_index(s + o + 16 * e, n_samp)];
+            v[4 + e] = x[reflect_index(s + o + 256 + 16 * e, n_samp)];
+        }
     }
 }
 
-constexpr int kP2McThreads = 512;
+#ifndef SETK_P2MC_THREADS
+#define SETK_P2MC_THREADS 512
+#endif
+#ifndef SETK_P2MC_WAVES_PER_SIMD
+#define SETK_P2MC_WAVES_PER_SIMD 4
+#endif
+#ifndef SETK_P2MC_GROUP
+#define SETK_P2MC_GROUP 2
+#endif
+// forward operand tiles in LDS (8 x ds_read_b128 per transform) instead of 32 registers
+#ifndef SETK_P2MC_KLDS
+#define SETK_P2MC_KLDS 1
+#endif
+// ... and the window rows and twiddles too (5 more reads per transform, 20 more registers free)
+#ifndef SETK_P2MC_WLDS
+#define SETK_P2MC_WLDS 1
+#endif
+struct False { static constexpr bool value = false; };
+struct True { static constexpr bool value = true; };
+constexpr int kP2McThreads = SETK_P2MC_THREADS;
 constexpr int kP2McWaves = kP2McThreads / 64;
 
-constexpr int kP2McTiles = 12;  // BR_H .. IT_L (10 tiles, contiguous words) + OT_H, OT_L
-// LDS plan (bytes): frames (16 + keep) * 2048 | wtab C * 257 * 8 | winsq 2048 | once-per-frame
-// operand tiles 12 * 1024 | synthesis window rows 2048 | a16 scratch 8 * 8 * kOddPitch * 4 |
-// yodd 8 * 16 * 4 | red 64
-size_t pass2_mc_lds_bytes(int C, int keep) {
+constexpr int kP2McTiles = SETK_P2MC_KLDS ? (SETK_P2MC_WLDS ? 25 : 20) : 12;  // BR_H .. IT_L (10 tiles, contiguous words) + OT_H, OT_L + the forward's 8
+// LDS plan (bytes): wtab C * 257 * 8 | operand tiles 25 * 1024 | synthesis rows
+// 2048 | a16 scratch NW * 8 * kOddPitch * 4 | yodd NW * 16 * 4 | red 64
+size_t pass2_mc_lds_bytes(int C) {
     const size_t wt = ((size_t)C * kBins * sizeof(cf) + 15) & ~(size_t)15;
-    return (size_t)(kSuperTile + keep) * kFrame * sizeof(float) + wt + 2048 + kP2McTiles * 1024 + 2048 +
-           (size_t)kP2McWaves * 8 * mc::kOddPitch * sizeof(float) + kP2McWaves * 16 * sizeof(float) + 64;
+    return wt + kP2McTiles * 1024 + 2048 + (size_t)kP2McWaves * SETK_P2MC_GROUP * 8 * mc::kOddPitch * sizeof(float) +
+           kP2McWaves * 16 * sizeof(float) + 64;
 }
 
 // sum over the first 8 lanes of every 16-lane row, result in lanes 0..7 of the row
@@ -85,28 +110,30 @@ SETK_DEV float wave_max_nonneg(float x) {
     return __builtin_bit_cast(float, m);
 }
 
+// hop = n_fft / 2 (the CLI's default geometry): every output block of `hop` samples is the sum
+// of exactly two frame halves, so a wavefront that walks CONSECUTIVE frames carries the second
+// half of its last frame in four registers per lane and finishes a block per frame by itself --
+// no frame slots in LDS, no workgroup barrier, no overlap-add loop.  1 / sum(window^2) is folded
+// into the synthesis rows (mc_syn); blocks with a single contribution (the first and the last
+// one of an utterance, emitted only when center = False) take the per-lane corrections mc_edge.
+// A workgroup shares the weight table and the once-per-frame operand tiles; its waves split the
+// item's frame range and each recomputes one frame ahead of its sub-range for the carry.
 template <int C>
-__global__ __launch_bounds__(kP2McThreads, 4) void beamform_istft_mc_kernel(Pass2Args a) {
+__global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamform_istft_mc_kernel(Pass2Args a) {
     constexpr int NT = kP2McThreads;
     constexpr int NW = kP2McWaves;
     constexpr int F = kBins;
-    constexpr int ST = kSuperTile;
-    constexpr int FPW = ST / NW;  // frames per wave and super-tile
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int keep = a.g.keep;
-    float* frames = reinterpret_cast<float*>(smem);  // [(keep + ST)][512]
-    char* p = smem + (size_t)(ST + keep) * kFrame * sizeof(float);
+    char* p = smem;
     cf* wtab = reinterpret_cast<cf*>(p);  // [C][257]
     p += ((size_t)C * F * sizeof(cf) + 15) & ~(size_t)15;
-    float* winsq = reinterpret_cast<float*>(p);
-    p += 2048;
     mc::u4* tiles = reinterpret_cast<mc::u4*>(p);  // [12][64]: BR_H BR_L BI_H BI_L G0_H G0_L G1_H G1_L IT_H IT_L OT_H OT_L
     p += kP2McTiles * 1024;
-    mc::f4* synr = reinterpret_cast<mc::f4*>(p);  // [2][64] float4: synthesis window rows 0..3 / 4..7 of a lane
+    mc::f4* synr = reinterpret_cast<mc::f4*>(p);  // [2][64] float4: synthesis rows 0..3 / 4..7 of a lane
     p += 2048;
-    float* a16s = reinterpret_cast<float*>(p);  // [NW][8][kOddPitch]
-    p += (size_t)NW * 8 * mc::kOddPitch * sizeof(float);
+    float* a16s = reinterpret_cast<float*>(p);  // [NW][R][8][kOddPitch]
+    p += (size_t)NW * SETK_P2MC_GROUP * 8 * mc::kOddPitch * sizeof(float);
     float* yodd_s = reinterpret_cast<float*>(p);  // [NW][16]
     p += NW * 16 * sizeof(float);
     float* red = reinterpret_cast<float*>(p);
@@ -119,11 +146,10 @@ __global__ __launch_bounds__(kP2McThreads, 4) void beamform_istft_mc_kernel(Pass
     const UttDesc ud = a.utts[wi.utt];
     const int n_samp = ud.num_samples;
     const int T = ud.num_frames;
-    const int hop = a.g.hop;
+    const int hop = kNfft / 2;
     const bool post_mask = (a.flags & 0x4) != 0;
     const bool clamp = (a.flags & 0x2) != 0;
 
-    for (int i = tid; i < kNfft; i += NT) winsq[i] = a.winsq[i];
     {
         const cf* wsrc = reinterpret_cast<const cf*>(a.weight) + (size_t)wi.utt * C * kBinsPad;
         for (int i = tid; i < C * F; i += NT) {
@@ -133,62 +159,183 @@ __global__ __launch_bounds__(kP2McThreads, 4) void beamform_istft_mc_kernel(Pass
     }
     mc::stage_tiles(tiles, a.mc_tab, mc::kW_BR_H, 10, tid, NT);
     mc::stage_tiles(tiles + 10 * 64, a.mc_tab, mc::kW_OT_H, 2, tid, NT);
+#if SETK_P2MC_KLDS
+    mc::stage_tiles(tiles + 12 * 64, a.mc_tab, mc::kW_MC_H, 8, tid, NT);
+#if SETK_P2MC_WLDS
+    mc::stage_tiles(tiles + 20 * 64, reinterpret_cast<const unsigned*>(a.mc_win), 0, 2, tid, NT);
+    mc::stage_tiles(tiles + 22 * 64, a.mc_tab, mc::kW_TR, 3, tid, NT);
+#endif
+#endif
     for (int i = tid; i < 128; i += NT) {
         const int l = i & 63, hf = i >> 6;
         synr[i] = (mc::f4){a.mc_syn[(4 * hf + 0) * 64 + l], a.mc_syn[(4 * hf + 1) * 64 + l],
                            a.mc_syn[(4 * hf + 2) * 64 + l], a.mc_syn[(4 * hf + 3) * 64 + l]};
     }
+#if SETK_P2MC_KLDS && SETK_P2MC_WLDS
+    struct { float tr[4], ti[4]; } K;  // (the inverse's conjugate twiddles: re-read there)
+#elif SETK_P2MC_KLDS
+    struct { float tr[4], ti[4], tri[4]; } K;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        K.tr[r] = mc::tab_f(a.mc_tab, mc::kW_TR + r, lane);
+        K.ti[r] = mc::tab_f(a.mc_tab, mc::kW_TI + r, lane);
+        K.tri[r] = mc::tab_f(a.mc_tab, mc::kW_TRI + r, lane);
+    }
+#else
     mc::Fwd K;
     mc::load_fwd(K, a.mc_tab, lane);
+#endif
+#if !(SETK_P2MC_KLDS && SETK_P2MC_WLDS)
     float win[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) win[e] = gptr(a.mc_win)[e * 64 + lane];
-    float* a16w = a16s + wave * 8 * mc::kOddPitch;  // rows = channels (columns 8..15 of the odd tile re-read row 7)
+#endif
     float* yoddw = yodd_s + wave * 16;
     const int lane_bin = mc::bin_of(c16, g, 0);
     const cf* wl = wtab + lane_bin;                       // + c * F + 32 r
     const int jo = c16 < C ? c16 : 0;                     // odd-family tile: column = channel
     const cf* wo = wtab + jo * F + 16 + 64 * g;           // w_j[16 + 32 (2 g)], [+ 32] the next
     const bool odd_on = c16 < C;
+    const int lane_n = 64 * g + c16;                      // sample 16 (4 g + r) + n2 = lane_n + 16 r
     float omax = 0.f;
+    __syncthreads();  // tables ready (the only workgroup barrier before the epilogue)
 
-    const int t_first = max(wi.t0 - keep, 0);
-    for (int i = tid; i < keep * kFrame; i += NT) frames[i] = 0.f;
+    // this wave's frames [ta, tb); one frame ahead of ta is recomputed for its second half
+    const int per = (wi.t1 - wi.t0 + NW - 1) / NW;
+    const int ta = wi.t0 + wave * per;
+    const int tb = min(ta + per, wi.t1);
+    const int tw = ta > 0 ? ta - 1 : ta;  // first frame computed
 
-    for (int ts = t_first; ts < wi.t1; ts += ST) {
-        __syncthreads();  // tables ready / slots free (carry copied)
-#pragma unroll 1
-        for (int k = 0; k < FPW; ++k) {
-            const int fi = wave + NW * k;
-            const int t = ts + fi;
-            const bool tvalid = t < T;
-            float* slot = frames + (size_t)(keep + fi) * kFrame;
-            mc::f4 yr = {0.f, 0.f, 0.f, 0.f}, yi = {0.f, 0.f, 0.f, 0.f};
-            float raw[8];
-            load_raw_mc2(raw, gptr(ud.audio), n_samp, t * hop - a.g.pad, lane, tvalid);
-#pragma unroll 1
-            for (int c = 0; c < C; ++c) {
-                float x[8];
+    // Channel-major over groups of R consecutive frames: with hop = n_fft / 2 frame t + 1 shares
+    // its first half with frame t -- the same lane's registers (mc::sample_of) -- so inside a
+    // group a transform loads four new samples per lane, not eight, and the weights of a channel
+    // are read once per group.  The R spectra of the group accumulate in registers.
+    constexpr int R = SETK_P2MC_GROUP;
+    float* a16g = a16s + wave * R * 8 * mc::kOddPitch;  // [R][8 channels][kOddPitch]
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+    // loaders: a whole frame (8 registers) / the second half of a frame (registers 4..7).
+    // EDGE: some sample of the group lies outside the signal (numpy "reflect" padding) -- the
+    // first and the last group of an utterance; frames past the last one repeat it (computed
+    // to keep the group uniform, never emitted).
+    auto load_full = [&](float (&v)[8], int t, int c, auto edge) __attribute__((always_inline)) {
+        gcfloat_p x = gptr(ud.audio) + (size_t)c * n_samp;
+        const int s0 = min(t, T - 1) * hop - a.g.pad, o = 64 * g + c16;
+        if (!decltype(edge)::value) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = raw[e];
-                if (c + 1 < C)
-                    load_raw_mc2(raw, gptr(ud.audio) + (size_t)(c + 1) * n_samp, n_samp, t * hop - a.g.pad, lane, tvalid);
+            for (int e = 0; e < 4; ++e) {
+                v[e] = x[s0 + o + 16 * e];
+                v[4 + e] = x[s0 + o + 256 + 16 * e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
+                v[4 + e] = x[reflect_index(s0 + o + 256 + 16 * e, n_samp)];
+            }
+        }
+    };
+    auto load_half = [&](float (&v)[8], int t, int c, auto edge) __attribute__((always_inline)) {
+        gcfloat_p x = gptr(ud.audio) + (size_t)c * n_samp;
+        const int s0 = min(t, T - 1) * hop - a.g.pad + 256, o = 64 * g + c16;
+        if (!decltype(edge)::value) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 + e] = x[s0 + o + 16 * e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 + e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
+        }
+    };
+    mc::f4 yr[R], yi[R];
+    // the R transforms of every channel of one group; `nxt` arrives holding frame (t0, channel 0)
+    // and leaves holding frame (t0 + R, channel 0)
+    float nxt[8];
+    auto group = [&](int t0, auto edge) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            yr[k] = (mc::f4){0.f, 0.f, 0.f, 0.f};
+            yi[k] = (mc::f4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int c = 0; c < C; ++c) {
+            asm volatile("" ::: "memory");  // the weights are re-read per group, not kept (64 registers)
+            const cf* wc = wl + c * F;
+            cf w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = wc[32 * r];
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = nxt[e];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                // what comes next travels while this transform runs: the second half of the
+                // next frame of the group, or the first frame of the next channel / group
+                if (k + 1 < R) load_half(nxt, t0 + k + 1, c, edge);
+                else if (c + 1 < C) load_full(nxt, t0, c + 1, edge);
                 mc::f4 zr, zi, a16;
+#if SETK_P2MC_KLDS && SETK_P2MC_WLDS
+                {
+                    asm volatile("" ::: "memory");
+                    const mc::f4 w0 = __builtin_bit_cast(mc::f4, tiles[20 * 64 + lane]);
+                    const mc::f4 w1 = __builtin_bit_cast(mc::f4, tiles[21 * 64 + lane]);
+                    const mc::f4 q0 = __builtin_bit_cast(mc::f4, tiles[22 * 64 + lane]);
+                    const mc::f4 q1 = __builtin_bit_cast(mc::f4, tiles[23 * 64 + lane]);
+                    const mc::f4 q2 = __builtin_bit_cast(mc::f4, tiles[24 * 64 + lane]);
+                    const float win[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                    const float tr[4] = {q0[0], q0[1], q0[2], q0[3]}, ti[4] = {q1[0], q1[1], q1[2], q1[3]},
+                                tri[4] = {q2[0], q2[1], q2[2], q2[3]};
+                    mc::forward_t(x, win, [&](int i) { return mc::lds_h8(tiles, 12 + i, lane); }, tr, ti, tri, zr, zi, a16);
+                }
+#elif SETK_P2MC_KLDS
+                mc::forward_t(x, win, [&](int i) { return mc::lds_h8(tiles, 12 + i, lane); }, K.tr, K.ti, K.tri, zr, zi, a16);
+#else
                 mc::forward(x, win, K, zr, zi, a16);
-                mc::store_a16(a16w, c, lane, a16);
-                const cf* wc = wl + c * F;
+#endif
+                mc::store_a16(a16g + k * 8 * mc::kOddPitch, c, lane, a16);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const cf w = wc[32 * r];
-                    yr[r] = fmaf(zr[r], w.x, fmaf(zi[r], w.y, yr[r]));
-                    yi[r] = fmaf(zi[r], w.x, fmaf(-zr[r], w.y, yi[r]));
+                    yr[k][r] = fmaf(zr[r], w[r].x, fmaf(zi[r], w[r].y, yr[k][r]));
+                    yi[k][r] = fmaf(zi[r], w[r].x, fmaf(-zr[r], w[r].y, yi[k][r]));
                 }
+                if (k + 1 < R) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = x[4 + e];
+                        x[4 + e] = nxt[4 + e];
+                    }
+                }
+                // one transform at a time: interleaved by the scheduler, the R unrolled
+                // transforms keep R working sets alive and spill 150 registers
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
+    };
+    auto span_is_edge = [&](int t0) {
+        const int lo = t0 * hop - a.g.pad, hi = (t0 + R - 1) * hop - a.g.pad + kNfft;
+        return lo < 0 || hi > n_samp || t0 + R > T;
+    };
+    if (tw < tb) {
+        if (span_is_edge(tw)) load_full(nxt, tw, 0, True());
+        else load_full(nxt, tw, 0, False());
+    }
+#pragma unroll 1
+    for (int t0 = tw; t0 < tb; t0 += R) {
+        const int nf = min(R, tb - t0);
+        if (span_is_edge(t0)) group(t0, True());
+        else group(t0, False());
+        if (t0 + R < tb) {  // first frame of the next group (issued here: its span decides the path)
+            if (span_is_edge(t0 + R)) load_full(nxt, t0 + R, 0, True());
+            else load_full(nxt, t0 + R, 0, False());
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            if (k >= nf) break;
+            const int t = t0 + k;
             // ---- odd family of all channels: one tile, then the sum over the channel lanes ----
             float yo[4];
             {
                 asm volatile("" ::: "memory");  // the once-per-frame tiles are re-read, not kept
-                const mc::f4 d = mc::odd_tile(a16w, mc::lds_h8(tiles, 10, lane), mc::lds_h8(tiles, 11, lane), lane, C);
+                const mc::f4 d = mc::odd_tile(a16g + k * 8 * mc::kOddPitch, mc::lds_h8(tiles, 10, lane),
+                                              mc::lds_h8(tiles, 11, lane), lane, C);
                 const cf w0 = wo[0], w1 = wo[32];
                 yo[0] = odd_on ? fmaf(d[0], w0.x, d[1] * w0.y) : 0.f;
                 yo[1] = odd_on ? fmaf(d[1], w0.x, -d[0] * w0.y) : 0.f;
@@ -197,15 +344,16 @@ __global__ __launch_bounds__(kP2McThreads, 4) void beamform_istft_mc_kernel(Pass
 #pragma unroll
                 for (int i = 0; i < 4; ++i) yo[i] = row8_sum(yo[i]);
             }
+            mc::f4 fr = yr[k], fi = yi[k];
             // ---- optional post-mask ----
-            if (post_mask && tvalid) {
+            if (post_mask) {
                 const float* mrow = ud.mask_s + (size_t)t * F;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float m = mrow[lane_bin + 32 * r];
                     if (clamp) m = fminf(m, 1.f);
-                    yr[r] *= m;
-                    yi[r] *= m;
+                    fr[r] *= m;
+                    fi[r] *= m;
                 }
                 float m0 = mrow[16 + 64 * g], m1 = mrow[48 + 64 * g];
                 if (clamp) { m0 = fminf(m0, 1.f); m1 = fminf(m1, 1.f); }
@@ -215,17 +363,17 @@ __global__ __launch_bounds__(kP2McThreads, 4) void beamform_istft_mc_kernel(Pass
                 yo[3] *= m1;
             }
             // only Re Y[0], Re Y[256] reach the inverse (numpy irfft drops their imaginary parts)
-            yi[0] = (lane == 0) ? 0.f : yi[0];
-            yi[3] = (lane == 32) ? 0.f : yi[3];
+            fi[0] = (lane == 0) ? 0.f : fi[0];
+            fi[3] = (lane == 32) ? 0.f : fi[3];
             // ---- power-of-two scale of the frame into the fp16 operand range: max < 2^11 ----
             float mxl = fmaxf(fmaxf(fabsf(yo[0]), fabsf(yo[1])), fmaxf(fabsf(yo[2]), fabsf(yo[3])));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mxl = fmaxf(mxl, fmaxf(fabsf(yr[r]), fabsf(yi[r])));
+            for (int r = 0; r < 4; ++r) mxl = fmaxf(mxl, fmaxf(fabsf(fr[r]), fabsf(fi[r])));
             const float mxw = wave_max_nonneg(mxl);
             int ex = (int)((__builtin_bit_cast(unsigned, mxw) >> 23) & 0xff);  // mxw < 2^(ex - 126)
             ex = ex < 16 ? 16 : (ex > 250 ? 250 : ex);                         // (zero / tiny / huge frames)
             const float sc = __builtin_bit_cast(float, (unsigned)(264 - ex) << 23);   // 2^(137 - ex)
-            const float isc = tvalid ? __builtin_bit_cast(float, (unsigned)(ex - 10) << 23) : 0.f;
+            const float isc = __builtin_bit_cast(float, (unsigned)(ex - 10) << 23);
             // ---- E16 of the odd family: its tile takes frames as rows; this frame is row 0 ----
             if (c16 == 0) *reinterpret_cast<mc::f4*>(yoddw + 4 * g) = (mc::f4){yo[0] * sc, yo[1] * sc, yo[2] * sc, yo[3] * sc};
             float e16;
@@ -244,62 +392,67 @@ __global__ __launch_bounds__(kP2McThreads, 4) void beamform_istft_mc_kernel(Pass
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                yr[r] *= sc;
-                yi[r] *= sc;
+                fr[r] *= sc;
+                fi[r] *= sc;
             }
             float bmid[8];
-            mc::inverse_a(yr, yi, e16, mc::lds_h8(tiles, 0, lane), mc::lds_h8(tiles, 1, lane),
+#if SETK_P2MC_KLDS && SETK_P2MC_WLDS
+            {
+                const mc::f4 tt0 = __builtin_bit_cast(mc::f4, tiles[22 * 64 + lane]);
+                const mc::f4 tt1 = __builtin_bit_cast(mc::f4, tiles[23 * 64 + lane]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    K.tr[r] = tt0[r];
+                    K.ti[r] = tt1[r];
+                }
+            }
+#endif
+            mc::inverse_a(fr, fi, e16, mc::lds_h8(tiles, 0, lane), mc::lds_h8(tiles, 1, lane),
                           mc::lds_h8(tiles, 2, lane), mc::lds_h8(tiles, 3, lane), K.tr, K.ti, bmid, lane);
             asm volatile("" ::: "memory");
             mc::f4 y0, y1;
             mc::inverse_b(bmid, mc::lds_h8(tiles, 4, lane), mc::lds_h8(tiles, 5, lane),
                           mc::lds_h8(tiles, 6, lane), mc::lds_h8(tiles, 7, lane), y0, y1);
-            // ---- synthesis window (x 1/512), back-scale, frame into its slot ----
+            // ---- block t = first half of frame t + second half of frame t - 1 (the carry); the
+            //      rows hold window / 512 / sum(window^2) x the back-scale of the spectra ----
             const mc::f4 s0 = synr[lane], s1 = synr[64 + lane];
-            float* dst = slot + 64 * g + c16;
+            float blk[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dst[16 * r] = y0[r] * (s0[r] * isc);
-                dst[256 + 16 * r] = y1[r] * (s1[r] * isc);
+            for (int r = 0; r < 4; ++r) blk[r] = fmaf(y0[r], s0[r] * isc, carry[r]);
+            if (t == 0) {  // no frame before the first: a single contribution (center = False only)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) blk[r] *= gptr(a.mc_edge)[r * 64 + lane];
             }
-        }
-        __syncthreads();
-        // ---- overlap-add: padded positions [pos0, pos1) are now complete ----
-        {
-            int pos0 = max(ts, wi.t0) * hop;
-            int pos1 = min(ts + ST, wi.t1) * hop;
-            if (wi.last && ts + ST >= wi.t1) pos1 = (T - 1) * hop + kNfft;
-            for (int n = pos0 + tid; n < pos1; n += NT) {
-                int t_hi = min(n / hop, T - 1);
-                int t_lo = max((n - kNfft) / hop + 1, 0);
-                if (n < kNfft) t_lo = 0;
-                float v = 0.f, wss = 0.f;
-                for (int tt = t_lo; tt <= t_hi; ++tt) {
-                    const int off = n - tt * hop;
-                    const int sl = tt - ts + keep;
-                    v += frames[sl * kFrame + off];
-                    wss += winsq[off];
-                }
-                if (wss > 1.17549435e-38f) v /= wss;
-                const int o = n - a.g.pad;
-                if (o >= 0 && o < ud.out_len) {
-                    ud.wave_f32[o] = v;
-                    omax = fmaxf(omax, fabsf(v));
+            if (t >= ta) {
+                const int o = t * hop - a.g.pad + lane_n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int oo = o + 16 * r;
+                    if (oo >= 0 && oo < ud.out_len) {
+                        ud.wave_f32[oo] = blk[r];
+                        omax = fmaxf(omax, fabsf(blk[r]));
+                    }
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) carry[r] = y1[r] * (s1[r] * isc);
         }
-        __syncthreads();
-        // ---- carry the last `keep` frames over to the next super-tile ----
-        {
-            float4* dst = reinterpret_cast<float4*>(frames);
-            const float4* src = reinterpret_cast<const float4*>(frames + ST * kFrame);
-            const int n4 = keep * (kFrame / 4);
-            for (int i = tid; i < n4; i += NT) dst[i] = src[i];
+    }
+    // ---- the block after the last frame: its second half alone (center = False only) ----
+    if (tb == T && ta < tb) {
+        const int o = T * hop - a.g.pad + lane_n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oo = o + 16 * r;
+            const float v = carry[r] * gptr(a.mc_edge)[(4 + r) * 64 + lane];
+            if (oo >= 0 && oo < ud.out_len) {
+                ud.wave_f32[oo] = v;
+                omax = fmaxf(omax, fabsf(v));
+            }
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
-    __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = omax;
     __syncthreads();
     if (tid == 0) {
@@ -310,9 +463,16 @@ __global__ __launch_bounds__(kP2McThreads, 4) void beamform_istft_mc_kernel(Pass
     }
 }
 
+// workgroups of this kernel a CU holds (registers and LDS), for the work-list cut of capi.hip
+int pass2_mc_wgs_per_cu(int C) {
+    const int by_waves = SETK_P2MC_WAVES_PER_SIMD * 4 / kP2McWaves;
+    const int by_lds = (int)((160u << 10) / pass2_mc_lds_bytes(C));
+    return by_waves < by_lds ? (by_waves > 0 ? by_waves : 1) : (by_lds > 0 ? by_lds : 1);
+}
+
 template <int C>
 static hipError_t launch_pass2_mc_t(const Pass2Args& a, int n_items, hipStream_t s) {
-    const size_t lds = pass2_mc_lds_bytes(C, a.g.keep);
+    const size_t lds = pass2_mc_lds_bytes(C);
     auto k = beamform_istft_mc_kernel<C>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -203,7 +203,7 @@ class BatchEnhancer(object):
     @property
     def torch(self):
         if self._torch is None:
-            import torch
+            torch = _ffi.import_torch(type(self).__name__ + ': this input (more than 8 channels / an unfused geometry)')
             if not torch.cuda.is_available():
                 raise _ffi.SetkError("BatchEnhancer needs an MI355X (no CPU fallback)")
             self._torch = torch
@@ -423,7 +423,7 @@ class FixedBatchBeamformer(object):
     @property
     def torch(self):
         if self._torch is None:
-            import torch
+            torch = _ffi.import_torch(type(self).__name__ + ': this input (more than 8 channels / an unfused geometry)')
             if not torch.cuda.is_available():
                 raise _ffi.SetkError("setk_amd needs an MI355X GPU (no CPU fallback)")
             self._torch = torch
@@ -559,7 +559,7 @@ class CgmmEstimator(object):
     @property
     def torch(self):
         if self._torch is None:
-            import torch
+            torch = _ffi.import_torch(type(self).__name__ + ': this input (more than 8 channels / an unfused geometry)')
             if not torch.cuda.is_available():
                 raise _ffi.SetkError("CgmmEstimator needs an MI355X (no CPU fallback)")
             self._torch = torch
@@ -719,7 +719,7 @@ class BatchDereverb(object):
     @property
     def torch(self):
         if self._torch is None:
-            import torch
+            torch = _ffi.import_torch(type(self).__name__ + ': this input (more than 8 channels / an unfused geometry)')
             if not torch.cuda.is_available():
                 raise _ffi.SetkError("setk_amd needs an MI355X GPU (no CPU fallback)")
             self._torch = torch

@@ -355,6 +355,39 @@ class WaveReader(ScpReader):
         frame = info["channels"] * (info["bits"] // 8)
         return info["data_bytes"] // frame if frame else None
 
+    def peek_channels(self, key):
+        """Channel count from the wave header(s) alone, or None for a pipe / unreadable header
+        (a glob of single-channel files counts its files)."""
+        fname = self.index_dict[key].rstrip()
+        if fname[-1] == "|":
+            return None
+        wav_list = glob.glob(fname)
+        if ":" in fname and not wav_list:
+            wav_list = [fname]
+        if not wav_list:
+            return None
+        if len(wav_list) > 1:
+            return len(wav_list)
+        addr = wav_list[0]
+        try:
+            if ":" in addr and not os.path.exists(addr):
+                path, offset = addr.rsplit(":", 1)
+                with open(path, "rb") as fd:
+                    fd.seek(int(offset))
+                    return wavio.read_header(fd)["channels"]
+            with open(addr, "rb") as fd:
+                return wavio.read_header(fd)["channels"]
+        except (OSError, ValueError, wavio.WaveFormatError):
+            return None
+
+    def first_channels_at_most(self, limit):
+        """True if the first utterance's header shows at most `limit` channels (corpora are
+        uniform; what the CLIs use to decide on the torch-free mode before any decode)."""
+        for key in self.index_keys:
+            n = self.peek_channels(key)
+            return n is not None and n <= limit
+        return True
+
     def maxabs(self, key):
         return np.max(np.abs(self.read(key)))
 

@@ -158,15 +158,26 @@ def write_pcm16(file, pcm, sr):
         "<IHHIIHH", 16, WAVE_FORMAT_PCM, ch, int(sr), int(sr) * ch * 2, ch * 2, 16)
     hdr += b"data" + struct.pack("<I", nbytes)
     if isinstance(file, (str, bytes)) or hasattr(file, "__fspath__"):
-        fd = os.open(file, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+        # written under a temporary name and renamed into place: a run killed in the middle of a
+        # file never leaves a truncated {key}.wav behind (--skip-existing trusts what it finds)
+        final = os.fspath(file)
+        tmp = final + (b".part" if isinstance(final, bytes) else ".part")
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
         try:
             bufs, want = [hdr, data], len(hdr) + nbytes
             n = os.writev(fd, bufs)
             while n < want:  # short write: continue from where it stopped
                 whole = hdr + bytes(data)
                 n += os.write(fd, memoryview(whole)[n:])
-        finally:
+        except BaseException:
             os.close(fd)
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+            raise
+        os.close(fd)
+        os.replace(tmp, final)
     else:
         file.write(hdr)
         file.write(data)

@@ -121,6 +121,25 @@ def do_online_beamform(beamformer, speech_mask, interf_mask, stft_mat, args):
     return np.hstack(out)
 
 
+def _complete_wav(path):
+    """True if `path` is a WAV file whose size is what its RIFF / data chunk headers say (the
+    writer renames finished files into place; this also rejects files truncated by other
+    means, e.g. a full disk under an older version)."""
+    try:
+        size = os.path.getsize(path)
+        if size <= 44:
+            return False
+        with open(path, "rb") as f:
+            head = f.read(44)
+    except OSError:
+        return False
+    if len(head) < 44 or head[:4] != b"RIFF" or head[8:12] != b"WAVE" or head[36:40] != b"data":
+        return False
+    riff = int.from_bytes(head[4:8], "little")
+    data = int.from_bytes(head[40:44], "little")
+    return riff + 8 == size and data + 44 == size
+
+
 def _drop_existing(args, keys):
     """--skip-existing: a re-run after an interruption (or a re-queued shard of a failed
     rank) only does what is missing.  The sharding above is computed on the full table, so
@@ -130,10 +149,7 @@ def _drop_existing(args, keys):
     left = []
     for k in keys:
         path = os.path.join(args.dst_dir, f"{k}.wav")
-        try:
-            done = os.path.getsize(path) > 44
-        except OSError:
-            done = False
+        done = _complete_wav(path)
         if not done:
             left.append(k)
     if len(left) != len(keys):
@@ -225,7 +241,8 @@ def run_offline(args, shard):
     if _fast_path_ok(args) and shard.world == 1:
         # the streaming pipeline gets its buffers, streams and events from the library: a
         # single-process run never imports torch (0.9 s of a 2 s run on 192 utterances)
-        _ffi.TORCH_FREE = True
+        # (more than 8 channels run the unfused engine through torch tensors)
+        _ffi.set_torch_free(wav_reader.first_channels_at_most(8))
     engine = BatchEnhancer(beamformer=args.beamformer, frame_len=args.frame_len,
                            frame_hop=args.frame_hop, center=bool(args.center),
                            round_power_of_two=bool(args.round_power_of_two), window=args.window,

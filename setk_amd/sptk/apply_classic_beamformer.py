@@ -108,7 +108,8 @@ def run_offline(args, beamformer, utt2doa, shard):
     wav_reader = WaveReader(args.wav_scp, sr=args.sr)
     device = shard.device if shard.world > 1 else None
     if n_fft == 512 and shard.world == 1:
-        _ffi.TORCH_FREE = True  # the batch engine brings its own buffers and stream
+        # the batch engine brings its own buffers and stream (more than 8 channels: torch)
+        _ffi.set_torch_free(wav_reader.first_channels_at_most(8))
     done = 0
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
 

@@ -32,7 +32,7 @@ def run(args):
     }
     shard = Shard()
     if shard.world == 1:
-        _ffi.TORCH_FREE = True  # numpy arrays in and out of the library: nothing here needs torch
+        _ffi.set_torch_free()  # numpy arrays in and out of the library: nothing here needs torch
     reader = SpectrogramReader(args.wav_scp, round_power_of_two=args.round_power_of_two,
                                **stft_kwargs)
     num_done = 0

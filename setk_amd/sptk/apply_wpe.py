@@ -30,14 +30,17 @@ def run(args):
     shard = Shard()
     device = shard.device if shard.world > 1 else None
     n_fft = 2**int(np.ceil(np.log2(args.frame_len))) if args.round_power_of_two else args.frame_len
+    reader = WaveReader(args.wav_scp)  # 16 kHz tables like the reference (SpectrogramReader)
     if n_fft == 512 and shard.world == 1:
-        _ffi.TORCH_FREE = True  # the engine brings its own buffers and stream
+        # the engine brings its own buffers and stream; shapes outside the native step kernel
+        # (channels x taps > 96, R beyond LDS) run through torch and need it imported first
+        nch = next((reader.peek_channels(k) for k in reader.index_keys), None)
+        _ffi.set_torch_free(nch is not None and nch <= 8 and nch * args.taps <= 80)
     engine = BatchDereverb(taps=args.taps, delay=args.delay, context=args.context,
                            num_iters=args.num_iters, frame_len=args.frame_len,
                            frame_hop=args.frame_hop, center=bool(args.center),
                            round_power_of_two=bool(args.round_power_of_two), window=args.window,
                            device=device, pcm16=True)
-    reader = WaveReader(args.wav_scp)  # 16 kHz tables like the reference (SpectrogramReader)
     num_done = 0
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
 

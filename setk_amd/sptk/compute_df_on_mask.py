@@ -32,7 +32,7 @@ def run(args):
         "center": args.center,
         "transpose": False  # F x T
     }
-    _ffi.TORCH_FREE = True  # numpy arrays in and out of the library: nothing here needs torch
+    _ffi.set_torch_free()  # numpy arrays in and out of the library: nothing here needs torch
     feat_reader = SpectrogramReader(args.wav_scp, **stft_kwargs)
     mask_reader = {"numpy": NumpyReader, "kaldi": ScriptReader}[args.fmt](args.mask_scp)
     df_pair = [tuple(map(int, p.split(","))) for p in args.df_pair.split(";")]

@@ -98,7 +98,8 @@ def run_batched(args, shard):
     reader = WaveReader(args.wav_scp)
     if shard.world == 1:
         # CgmmEstimator.estimate brings its own buffers and stream: no torch in this process
-        _ffi.TORCH_FREE = True
+        # (bins that fit no resident configuration -- more than 8 channels -- go through torch)
+        _ffi.set_torch_free(reader.first_channels_at_most(8))
     est = CgmmEstimator(frame_len=args.frame_len, frame_hop=args.frame_hop,
                         center=bool(args.center), round_power_of_two=True, window=args.window,
                         num_iters=args.num_iters, update_alpha=bool(args.update_alpha),

@@ -55,14 +55,23 @@ def mm3(ah, al, bh, bl):
 
 
 # ---------------------------------------------------------------- constant tiles (fp64 -> fp16 pairs)
+def k1_n1():
+    """K index of the stage-1 data operand: k = 8 g + e <-> n1 = 4 g + e (e < 4: first half of
+    the frame), 16 + 4 g + e - 4 (e >= 4: second half).  A lane's registers e >= 4 of frame t are
+    its registers e < 4 of frame t + 1 when hop = 256: consecutive frames share them."""
+    k = np.arange(32)
+    g, e = k // 8, k % 8
+    return np.where(e < 4, 4 * g + e, 16 + 4 * g + e - 4)
+
+
 def stage1_tiles():
-    """B operands of stage 1: Mc[n1][c] = cos(2 pi n1 c / 32); Ms[n1][c] = -sin(2 pi n1 c / 32),
-    column 0 of Ms carries the k1 = 16 row (-1)^n1."""
-    n1 = np.arange(32)[:, None]
+    """B operands of stage 1 (rows in the K order of k1_n1): Mc[n1][c] = cos(2 pi n1 c / 32);
+    Ms[n1][c] = -sin(2 pi n1 c / 32), column 0 of Ms carries the k1 = 16 row (-1)^n1."""
+    n1 = k1_n1()[:, None]
     c = np.arange(16)[None, :]
     mc = np.cos(2 * np.pi * n1 * c / 32)
     ms = -np.sin(2 * np.pi * n1 * c / 32)
-    ms[:, 0] = (-1.0) ** np.arange(32)
+    ms[:, 0] = (-1.0) ** k1_n1()
     return mc, ms
 
 
@@ -136,7 +145,7 @@ def forward(xw, scale=1024.0):
     tr_im[:, 0] = 0.0  # column 0: Bi = 0 (its Ds carries A16, routed to the odd tile)
     part, kn2 = k2_part_n2()
     for b in range(nb):
-        a1 = xw[b].reshape(32, 16).T  # [n2][n1]
+        a1 = xw[b].reshape(32, 16).T[:, k1_n1()]  # [n2][k <-> n1]
         a1h, a1l = split16(a1)
         dc = mm3(a1h, a1l, mch, mcl)  # [n2][c]
         ds = mm3(a1h, a1l, msh, msl)

@@ -153,3 +153,34 @@ def test_non_power_of_two_cli(tmp_path):
     samps = pcm.T.astype(np.float32) / 32768
     ref = o.enhance_utterance(samps, mask, kind="mvdr", gauge=True, **kw)
     assert pcm16_rel_rms(y, ref) < 1e-3, pcm16_rel_rms(y, ref)
+
+
+def test_twelve_channel_cli_and_the_torch_free_mode(tmp_path):
+    """A 12-channel table through the adaptive CLI: the first header tells the CLI that this
+    corpus needs the unfused (torch) engine, so it does NOT enter the torch-free mode and the
+    result matches the oracle; with SETK_TORCH_FREE=1 forced, the late need for torch is refused
+    with a message instead of importing torch behind an already loaded library."""
+    import scipy.io.wavfile
+    from setk_amd.libs import wavio
+    td = str(tmp_path)
+    C = 12
+    mix, sp, nz = o.synth_utterance(91, C, 16000, return_parts=True)
+    mask = (0.05 + 0.9 * o.irm_mask(sp, nz)).astype(np.float32)
+    pcm = wavio.float_to_pcm16(mix.T)
+    wavio.write_pcm16(f"{td}/u.wav", pcm, 16000)
+    np.save(f"{td}/m.npy", mask)
+    open(f"{td}/wav.scp", "w").write(f"u {td}/u.wav\n")
+    open(f"{td}/mask.scp", "w").write(f"u {td}/m.npy\n")
+    cmd = [sys.executable, os.path.join(ROOT, "scripts/sptk/apply_adaptive_beamformer.py"),
+           "--mask-format", "numpy", f"{td}/wav.scp", f"{td}/mask.scp"]
+    env = {k: v for k, v in os.environ.items() if k != "SETK_TORCH_FREE"}
+    r = subprocess.run(cmd + [f"{td}/enh"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    sr, y = scipy.io.wavfile.read(f"{td}/enh/u.wav")
+    samps = pcm.T.astype(np.float32) / 32768
+    ref = o.enhance_utterance(samps, mask, kind="mvdr", gauge=True, **STFT_KW)
+    assert pcm16_rel_rms(y, ref) < 1e-3, pcm16_rel_rms(y, ref)
+    r = subprocess.run(cmd + [f"{td}/enh2"], capture_output=True, text=True, timeout=600,
+                       env=dict(env, SETK_TORCH_FREE="1"))
+    assert r.returncode != 0 and "torch-free" in r.stderr and "SETK_TORCH_FREE=0" in r.stderr, r.stderr[-2000:]
+    assert not os.path.exists(f"{td}/enh2/u.wav")

@@ -264,3 +264,47 @@ def test_two_rank_cli_on_the_stand_in(tmp_path):
     per_rank = [json.load(open(f"{td}/prof.json.rank{k}")) for k in range(2)]
     assert sum(p["utts"] for p in per_rank) == 8 and all(p["utts"] >= 2 for p in per_rank)
     assert all(p["mode"] == "pipeline" and p["world"] == 2 for p in per_rank)
+
+
+def test_eight_rank_cli_on_the_stand_in_balances_ragged_lengths(tmp_path):
+    """World size 8 as the driver's 8-GPU launch would run the CLI (BASELINE configs[2]: a batch
+    sharded over 8 GPUs), on CPU: gloo for the barrier and the counters, the HIP stand-in with
+    eight pretended devices for the rest.  128 utterances of ragged length (0.4 - 4 s): the
+    longest-first deal on the header durations leaves every rank within 2 % of the mean
+    number of samples, every utterance is written exactly once, and rank 0 reports the total
+    (reference mode: scripts/run_adapt_beamformer.sh:69-92, run.pl JOB=1:nj over split scps)."""
+    import json
+    import numpy as np
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "hoststub", "build.sh")], capture_output=True,
+                       text=True, timeout=900, env=dict(os.environ, PLAIN="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    td = str(tmp_path)
+    rng = np.random.default_rng(8)
+    lens = [int(n) for n in rng.integers(6400, 64000, size=128)]
+    _make_table(td, lens, channels=2)
+    world = 8
+    port = 29700 + (os.getpid() % 190)
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HOSTSTUB_DEVICES=str(world),
+                   SETK_ALLOW_HOSTSTUB="1", SETK_LIB=os.path.join(ROOT, "_abl", "libsetk_hoststub.so"),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py"),
+             "--mask-format", "numpy", "--batch-utts", "4", "--profile", f"{td}/prof.json",
+             f"{td}/wav.scp", f"{td}/mask.scp", f"{td}/out"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    errs = []
+    for p in procs:
+        _, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+        errs.append(e)
+    assert sorted(os.listdir(f"{td}/out")) == sorted(f"u{i}.wav" for i in range(len(lens)))
+    assert any(f"Processed {len(lens)} utterances out of {len(lens)}" in e for e in errs), errs[0][-1500:]
+    per_rank = [json.load(open(f"{td}/prof.json.rank{k}")) for k in range(world)]
+    assert sum(p["utts"] for p in per_rank) == len(lens)
+    assert all(p["mode"] == "pipeline" and p["world"] == world for p in per_rank)
+    loads = np.array([p["assigned_samples"] for p in per_rank], dtype=np.float64)
+    assert loads.sum() == sum(lens)
+    assert np.abs(loads / loads.mean() - 1).max() < 0.02, loads

@@ -98,6 +98,38 @@ def test_wavio_roundtrip_and_extensible(tmp_path):
     assert back.tolist() == [0, 16384, -16384, 32767, -32767, 1]
 
 
+def test_wav_writes_are_atomic_and_skip_existing_checks_completeness(tmp_path):
+    """--skip-existing trusts a {key}.wav only if its size is what its headers say; the writer
+    works under a temporary name and renames, so an interrupted run leaves no partial file
+    under the final name."""
+    from setk_amd.libs import wavio
+    from setk_amd.sptk.apply_adaptive_beamformer import _complete_wav
+    pcm = (np.arange(3000) % 200 - 100).astype(np.int16)
+    p = tmp_path / "k.wav"
+    wavio.write_pcm16(str(p), pcm, 16000)
+    assert sorted(os.listdir(tmp_path)) == ["k.wav"]  # no .part left behind
+    assert _complete_wav(str(p))
+    whole = p.read_bytes()
+    (tmp_path / "cut.wav").write_bytes(whole[: len(whole) // 2])  # what a killed writer used to leave
+    assert not _complete_wav(str(tmp_path / "cut.wav"))
+    (tmp_path / "hdr.wav").write_bytes(whole[:44])
+    assert not _complete_wav(str(tmp_path / "hdr.wav"))
+    assert not _complete_wav(str(tmp_path / "missing.wav"))
+    # a failing write must not clobber an existing good file
+    class Boom(Exception):
+        pass
+    real = os.writev
+    def bad(fd, bufs):
+        raise Boom()
+    os.writev = bad
+    try:
+        with pytest.raises(Boom):
+            wavio.write_pcm16(str(p), pcm[:10], 16000)
+    finally:
+        os.writev = real
+    assert p.read_bytes() == whole and sorted(os.listdir(tmp_path)) == ["cut.wav", "hdr.wav", "k.wav"]
+
+
 # ---------------------------------------------------------------------------
 # Kaldi I/O against the reference's vectors
 # ---------------------------------------------------------------------------

@@ -16,6 +16,10 @@ pass g2 SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_
 pass g3 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH
 pass g4 FETCH_SIZE
 pass g5 WRITE_SIZE
+pass g6 SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_FLAT SQ_INSTS_VALU_MFMA_F16
+pass g7 SQ_WAVES_LT_64 SQ_THREAD_CYCLES_VALU SQ_IFETCH_LEVEL SQ_INST_CYCLES_SALU SQ_WAIT_IFETCH SQ_CYCLES
+pass g8 TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr
+rocprofv3 -L > "$OUT/counters_all.txt" 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, collections, sys
 out = sys.argv[1]

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* frames, const uns
     for (int j = 0; j < 16; ++j) {
         const int b = b0 + j;
         float xw[8];
-        for (int e = 0; e < 8; ++e) xw[e] = b < nb ? frames[(size_t)b * 512 + 16 * (8 * g + e) + c] : 0.f;
+        for (int e = 0; e < 8; ++e) xw[e] = b < nb ? frames[(size_t)b * 512 + sample_of(lane, e)] : 0.f;
         f4 zr, zi, a16;
         forward(xw, win, K, zr, zi, a16);
         store_a16(a16s[wave], j, lane, a16);
@@ -123,11 +123,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void rate_kernel(const float
         int fr = (blockIdx.x * 7 + wave * 3) % nfr;
 #pragma unroll 1
         for (int it = 0; it < iters_t; ++it) {
-            const float* src = frames + (size_t)fr * 512 + 128 * g + c;
+            const float* src = frames + (size_t)fr * 512;
             fr = fr + 1 == nfr ? 0 : fr + 1;
             float xw[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xw[e] = src[16 * e];
+            for (int e = 0; e < 8; ++e) xw[e] = src[sample_of(lane, e)];
             f4 zr, zi, a16;
             forward(xw, win, K, zr, zi, a16);
             acc += a16;
