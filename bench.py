@@ -269,7 +269,10 @@ def main():
         k1_ms, k2_ms = stage_ms[0], stage_ms[2]
         achieved = b_k1 / (k1_ms * 1e-3) / 1e9
         pmc = pmc_leg(args) if (world == 1 and args.pmc) else None
-        roof = build_roofline(C, b_k1, b_k2, k1_ms, k2_ms, pmc)
+        rates = issue_rates_leg() if (world == 1 and args.pmc) else None
+        roof = build_roofline(C, b_k1, b_k2, k1_ms, k2_ms, pmc, rates)
+        if rates is not None:
+            roof["issue_rates"] = rates
         out = {
             "metric": "real-time-factor (audio-sec/wall-sec), 8-ch 16 kHz MVDR",
             "value": round(value, 1),
@@ -301,8 +304,13 @@ def main():
             "roofline": dict(roof, pipeline_achieved=round(
                 U * (4.0 * C * N + 4.0 * T * F + 4.0 * L) / (ms_per_step * 1e-3) / 1e9, 1)),
         }
+        if world == 1 and args.cpu_sample > 0:
+            # (ahead of the auxiliary legs: the driver's record keeps the head of the line)
+            out["cpu_baseline"] = cpu_baseline(args, C, N, rank * U, wave0)
         if sustained is not None:
             out["sustained"] = sustained
+        if world == 1 and args.sustain_sec > 0 and args.pmc:
+            out["power"] = power_leg(step, torch, min(3.0, max(1.0, args.sustain_sec)))
         if fresh is not None:
             out["uncached_call"] = fresh
         if full_batch is not None:
@@ -312,8 +320,6 @@ def main():
             audio = masks = waves = []
             torch.cuda.empty_cache()
             out["other_configs"] = other_configs(torch, _ffi, synth, dev)
-        if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args, C, N, rank * U, wave0)
         if world == 1 and args.e2e_utts > 0:
             # free the resident shard first: the CLI leg is its own process
             audio = masks = waves = None
@@ -329,11 +335,90 @@ SIMDS = 256 * 4            # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 XCDS = 8
 VALU_CYCLES_PER_INST = 2   # a wave64 VALU instruction occupies its SIMD-32 for two cycles
 # measured issue rate of a SIMD shared by n waves (plain fp32 VALU, profiles/r02t_valu_rate_pinned.txt)
-ISSUE_CYCLES_AT_WAVES = {1: 7.6, 2: 3.6, 3: 2.67, 4: 2.24}  # (3: profiles/r04f_valu_rate_pinned.txt)
-WAVES_PER_SIMD = {"pass1": 4, "pass2": 2}
-WAVES_WHY = {"pass1": "one 1024-thread workgroup per CU at the 128-VGPR budget",
-             "pass2": "two 256-thread workgroups per CU: 63.6 KB of LDS each, 256 VGPRs per wave"}
-KERNELS = {"pass1": "stft_covar_kernel", "pass2": "beamform_istft_kernel"}
+# fallback only (profiles/r04f_valu_rate_pinned.txt); the record carries the rates measured in
+# THIS run by tools/ubench/valu_rate3 --fma-only (issue_rates_leg)
+ISSUE_CYCLES_AT_WAVES = {1: 7.6, 2: 3.6, 3: 2.67, 4: 2.24}
+# kernel-name fragments per stage, most specific first; the form that ran is reported
+KERNELS = {"pass1": ["stft_covar_mc_kernel", "stft_covar_kernel"],
+           "pass2": ["beamform_istft_mc_kernel", "beamform_istft_kernel"]}
+WAVES_PER_SIMD = {"stft_covar_mc_kernel": 4, "stft_covar_kernel": 4,
+                  "beamform_istft_mc_kernel": 4, "beamform_istft_kernel": 2}
+WAVES_WHY = {"stft_covar_kernel": "one 1024-thread workgroup per CU at the 128-VGPR budget",
+             "stft_covar_mc_kernel": "one 1024-thread workgroup per CU at the 128-VGPR budget",
+             "beamform_istft_mc_kernel": "two 512-thread workgroups per CU at the 128-VGPR budget "
+                                         "(54 KB of LDS each: weights + operand tiles)",
+             "beamform_istft_kernel": "two 256-thread workgroups per CU: 63.6 KB of LDS each, 256 VGPRs per wave"}
+
+
+def issue_rates_leg():
+    """VALU issue rate of a SIMD shared by 1 / 2 / 3 / 4 waves, measured in THIS run with
+    pinned instruction streams (tools/ubench/valu_rate3 --fma-only, ~1 s; built on demand)."""
+    import re
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "tools", "ubench", "valu_rate3")
+    src = exe + ".hip"
+    try:
+        if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-o", exe, src],
+                           check=True, capture_output=True, timeout=300)
+        r = subprocess.run([exe, "--fma-only"], capture_output=True, text=True, timeout=120)
+        rates = {}
+        for m in re.finditer(r"v_fma_f32\s+waves/SIMD (\d+):.*?= ([\d.]+) per SIMD", r.stdout):
+            rates[int(m.group(1))] = float(m.group(2))
+        if len(rates) >= 3:
+            return {"cycles_per_inst_at_waves": rates, "how": "tools/ubench/valu_rate3 --fma-only in this run"}
+        return {"error": "valu_rate3 output not understood: " + r.stdout[-200:] + r.stderr[-200:]}
+    except Exception as e:  # noqa: BLE001 - a missing compiler must not take the bench down
+        return {"error": f"valu_rate3: {e}"}
+
+
+def power_leg(step, torch, seconds=2.0):
+    """Board power and shader clock while the timed step repeats (rocm-smi sampled from a
+    side thread): tells a power cap (clock well under 2.4 GHz at the cap) from a clock the
+    kernels simply do not need."""
+    import re
+    import subprocess
+    import threading
+    smi = "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return {"error": "rocm-smi not found"}
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                r = subprocess.run([smi, "--showpower", "--showclocks", "-d", "0"], capture_output=True,
+                                   text=True, timeout=10)
+                pw = re.search(r"Power \(W\):\s*([\d.]+)", r.stdout)
+                ck = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", r.stdout)
+                samples.append((float(pw.group(1)) if pw else None, int(ck.group(1)) if ck else None))
+            except Exception:  # noqa: BLE001
+                samples.append((None, None))
+    th = threading.Thread(target=sampler, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+        n += 50
+    stop.set()
+    th.join(timeout=15)
+    pw = [p for p, _ in samples if p is not None]
+    ck = [c for _, c in samples if c is not None]
+    cap = None
+    try:
+        r = subprocess.run([smi, "--showmaxpower", "-d", "0"], capture_output=True, text=True, timeout=10)
+        m = re.search(r"Max Graphics Package Power \(W\):\s*([\d.]+)", r.stdout)
+        cap = float(m.group(1)) if m else None
+    except Exception:  # noqa: BLE001
+        pass
+    return {"steps": n, "samples": len(samples), "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None,
+            "power_w_max": max(pw) if pw else None, "power_cap_w": cap,
+            "sclk_mhz_mean": round(sum(ck) / len(ck)) if ck else None,
+            "how": "rocm-smi --showpower --showclocks polled while the step repeats"}
 
 
 def pmc_leg(args):
@@ -355,7 +440,9 @@ def pmc_leg(args):
              "--steps", "3", "--warmup", "1", "--utts", str(args.utts), "--channels", str(args.channels),
              "--seconds", str(args.seconds), "--beamformer", args.beamformer,
              "--distinct", str(args.distinct)]
-    groups = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE"]]
+    groups = [["FETCH_SIZE"], ["WRITE_SIZE"],
+              ["SQ_INSTS_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES",
+               "SQ_VALU_MFMA_COEXEC_CYCLES"]]
     acc = {}
     td = tempfile.mkdtemp(prefix="setk_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -371,9 +458,11 @@ def pmc_leg(args):
                                  + (r.stderr or r.stdout)[-300:]}
             for fn in files:
                 for row in csv.DictReader(open(fn)):
-                    for key, kname in KERNELS.items():
-                        if kname in row["Kernel_Name"] and ", true>" not in row["Kernel_Name"]:
-                            d = acc.setdefault(key, {}).setdefault(row["Counter_Name"], [])
+                    for key, knames in KERNELS.items():
+                        kname = next((k for k in knames if k + "<" in row["Kernel_Name"]), None)
+                        if kname and ", true>" not in row["Kernel_Name"]:
+                            acc.setdefault(key, {})["__kernel__"] = kname
+                            d = acc[key].setdefault(row["Counter_Name"], [])
                             d.append((float(row["Counter_Value"]),
                                       int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
     finally:
@@ -389,6 +478,9 @@ def pmc_leg(args):
         rd, wr = mean("FETCH_SIZE"), mean("WRITE_SIZE")
         insts, gui, dns = mean("SQ_INSTS_VALU"), mean("GRBM_GUI_ACTIVE"), dur("GRBM_GUI_ACTIVE")
         res[key] = {
+            "kernel": c.get("__kernel__"),
+            "mfma_insts": mean("SQ_INSTS_MFMA"), "mfma_busy_cycles": mean("SQ_VALU_MFMA_BUSY_CYCLES"),
+            "mfma_valu_coexec_cycles": mean("SQ_VALU_MFMA_COEXEC_CYCLES"),
             "hbm_read_bytes": None if rd is None else 2.0 * rd * 1024.0,
             "hbm_write_bytes": None if wr is None else wr * 1024.0,
             "valu_insts": insts, "waves": mean("SQ_WAVES"),
@@ -400,13 +492,14 @@ def pmc_leg(args):
     return res
 
 
-def build_roofline(C, b_k1, b_k2, k1_ms, k2_ms, pmc):
+def build_roofline(C, b_k1, b_k2, k1_ms, k2_ms, pmc, rates=None):
     """The `roofline` object: the HBM numbers of the contract for the STFT+covariance
     kernel, and for BOTH streaming kernels the VALU-issue roofline they actually sit
     under: floor = wave-instructions / 1024 SIMDs x 2 cycles / clock.
     `bound` names the tighter of the two for pass 1."""
     achieved = b_k1 / (k1_ms * 1e-3) / 1e9
-    roof = {"kernel": f"stft_covar_kernel<{C}, false>", "bound": "hbm",
+    k1name = ((pmc or {}).get("pass1") or {}).get("kernel") or "stft_covar_kernel"
+    roof = {"kernel": f"{k1name}<{C}>" if "_mc_" in k1name else f"{k1name}<{C}, false>", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "alg_bytes_per_launch": b_k1, "kernel_ms": round(k1_ms, 4)}
@@ -416,7 +509,8 @@ def build_roofline(C, b_k1, b_k2, k1_ms, k2_ms, pmc):
     roof["pmc_method"] = pmc["method"]
     for key, alg, kms in (("pass1", b_k1, k1_ms), ("pass2", b_k2, k2_ms)):
         p = pmc.get(key) or {}
-        ent = {"kernel": KERNELS[key], "kernel_ms": round(kms, 4), "alg_bytes_per_launch": alg,
+        kname = p.get("kernel") or KERNELS[key][-1]
+        ent = {"kernel": kname, "kernel_ms": round(kms, 4), "alg_bytes_per_launch": alg,
                "hbm": {"achieved": round(alg / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                        "frac": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
         if p.get("hbm_read_bytes") is not None and p.get("hbm_write_bytes") is not None:
@@ -434,13 +528,26 @@ def build_roofline(C, b_k1, b_k2, k1_ms, k2_ms, pmc):
             # what the kernel's OCCUPANCY lets a SIMD issue: measured with pinned instruction
             # streams (tools/ubench/valu_rate2.hip, profiles/r02t_valu_rate_pinned.txt): one
             # plain fp32 VALU instruction per 7.6 / 3.6 / 2.24 cycles with 1 / 2 / 4 waves
-            waves = WAVES_PER_SIMD[key]
-            occ_floor = floor_ms * ISSUE_CYCLES_AT_WAVES[waves] / VALU_CYCLES_PER_INST
+            waves = WAVES_PER_SIMD[kname]
+            measured = (rates or {}).get("cycles_per_inst_at_waves") or {}
+            cpi = measured.get(waves, ISSUE_CYCLES_AT_WAVES[waves])
+            occ_floor = floor_ms * cpi / VALU_CYCLES_PER_INST
             ent["valu_issue"]["at_occupancy"] = {
-                "waves_per_simd": waves, "cycles_per_inst": ISSUE_CYCLES_AT_WAVES[waves],
+                "waves_per_simd": waves, "cycles_per_inst": cpi,
+                "cycles_per_inst_source": "measured in this run" if waves in measured else "profiles/r04f_valu_rate_pinned.txt",
                 "floor_ms": round(occ_floor, 4),
                 "frac": round(occ_floor / p["profiled_kernel_ms"], 4) if p.get("profiled_kernel_ms") else None,
-                "why": WAVES_WHY[key]}
+                "why": WAVES_WHY[kname]}
+            if p.get("mfma_insts"):
+                # the matrix pipe of a SIMD is busy SQ_VALU_MFMA_BUSY_CYCLES / 1024 cycles; what of
+                # it overlaps VALU issue is SQ_VALU_MFMA_COEXEC_CYCLES
+                mf_ms = p["mfma_busy_cycles"] / SIMDS / (p["clock_ghz"] * 1e9) * 1e3
+                co_ms = (p.get("mfma_valu_coexec_cycles") or 0.0) / SIMDS / (p["clock_ghz"] * 1e9) * 1e3
+                ent["mfma"] = {"insts": round(p["mfma_insts"]), "op": "v_mfma_f32_16x16x32_f16",
+                               "busy_ms_per_simd": round(mf_ms, 4), "coexec_with_valu_ms": round(co_ms, 4),
+                               "valu_plus_mfma_floor_ms": round(occ_floor + mf_ms - co_ms, 4),
+                               "frac_of_that_floor": round((occ_floor + mf_ms - co_ms) / p["profiled_kernel_ms"], 4)
+                               if p.get("profiled_kernel_ms") else None}
         roof[key] = ent
     p1 = roof.get("pass1", {})
     if "traffic" in p1.get("hbm", {}):

@@ -141,6 +141,164 @@ SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
     }
 }
 
+// y = M x for a Hermitian M held one column per lane (col[i] = M[i][j]):
+// lane j forms (M x)_j = sum_m conj(col[m]) x[m], the results are all-gathered.
+template <int C>
+SD void herm_matvec(const cd (&col)[C], const cd (&x)[C], cd (&y)[C]) {
+    cd mine = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int m = 0; m < C; ++m) mine = zadd(mine, zcmul(col[m], x[m]));
+#pragma unroll
+    for (int i = 0; i < C; ++i) y[i] = zshfl<Grp<C>::W>(mine, i);
+}
+
+// ---- the same sweeps in float32, polished in float64 --------------------------------------
+// What the reference computes with LAPACK's SINGLE precision cheevd (solve_pevd on complex64,
+// libs/beamformer.py:40-46) does not need 13 000 fp64 instructions per wavefront: the sweeps
+// run on a float32 copy of the matrix (scaled to max diag = 1), whose rotations are half the
+// instructions (the partner column arrives through the DPP operand of the fused multiply-adds
+// themselves, no separate moves of 64-bit halves) at twice the issue rate; the principal
+// column they find is then polished against the float64 matrix by two power steps (each
+// multiplies the error components by lambda_i / lambda_1 <= 1: it can only help) and its
+// eigenvalue is the float64 Rayleigh norm.  One-sided Jacobi is backward stable in its working
+// precision, so before the polish the vector is what LAPACK's float32 solver would give; after
+// it, bins with a clear gap are float64-accurate.
+template <int M>
+SD float fxor(float x) {
+    return __builtin_bit_cast(float, dpp_xor<M>(__builtin_bit_cast(int, x)));
+}
+// floor2: columns far below the principal one carry its rounding noise (eps32 |g_max| per
+// entry), so their inner products with it never fall under the RELATIVE bound; below
+// ~eps32 |g_max|^2 an inner product is noise and rotating on it would go on forever (de Rijk's
+// threshold).  What is left un-annihilated there moves the principal vector by ~1e-6 at most,
+// and the float64 power steps shrink exactly those components by lambda_small / lambda_max.
+template <int C, int M>
+SD bool jacobi_round_f32(float2 (&g)[C], int j, float floor2) {
+    const float tol2 = 1e-11f;  // |g_p^H g_q|^2 <= tol2 |g_p|^2 |g_q|^2: the float32 noise floor is ~1e-13
+    const int p = j ^ M;
+    float2 gp[C];
+    float m = 0.f;
+    float2 d = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        gp[i] = make_float2(fxor<M>(g[i].x), fxor<M>(g[i].y));
+        m = fmaf(g[i].x, g[i].x, fmaf(g[i].y, g[i].y, m));
+        d.x = fmaf(g[i].x, gp[i].x, fmaf(g[i].y, gp[i].y, d.x));   // conj(g) * gp
+        d.y = fmaf(g[i].x, gp[i].y, fmaf(-g[i].y, gp[i].x, d.y));
+    }
+    const float o = fxor<M>(m);
+    const float dd = fmaf(d.x, d.x, d.y * d.y);
+    if (dd > tol2 * m * o && dd > floor2) {
+        const float rabs = __builtin_amdgcn_rsqf(dd);
+        const float sigma = (j < p) ? 1.f : -1.f;
+        const float zeta = sigma * (o - m) * 0.5f * rabs;
+        const float t = copysignf(1.f, zeta) / (fabsf(zeta) + sqrtf(fmaf(zeta, zeta, 1.f)));
+        const float cs = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
+        const float f = sigma * cs * t * rabs;
+        const float2 ph = make_float2(d.x * f, -d.y * f);  // sigma * sn * conj(d) / |d|
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const float2 t0 = g[i];
+            g[i].x = fmaf(t0.x, cs, fmaf(-ph.x, gp[i].x, ph.y * gp[i].y));
+            g[i].y = fmaf(t0.y, cs, fmaf(-ph.x, gp[i].y, -ph.y * gp[i].x));
+        }
+        return true;
+    }
+    return false;
+}
+
+#ifndef SETK_SOLVE_FP64_ONLY
+#define SETK_SOLVE_FP64_ONLY 0
+#endif
+// a[i] = A[i][j] (lane j owns column j of the Hermitian PSD A, 8 lanes per problem)
+template <int C>
+SD void pevd_mixed(const cd (&a)[C], int j, cd (&out)[C], double& lam, int& noconv) {
+    constexpr int W = Grp<C>::W;
+    if constexpr (W != 8 || SETK_SOLVE_FP64_ONLY) {
+        cd g[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) g[i] = a[i];
+        jacobi_pevd<C>(g, j, out, lam, noconv);
+        return;
+    } else {
+        double dg = 0.0;
+#pragma unroll
+        for (int i = 0; i < C; ++i)
+            if (i == j) dg = a[i].x;
+#pragma unroll
+        for (int s = 1; s < W; s <<= 1) dg = fmax(dg, __shfl_xor(dg, s, W));
+        const double rs = (dg > 0.0) ? 1.0 / dg : 0.0;
+        float2 g[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) g[i] = make_float2((float)(a[i].x * rs), (float)(a[i].y * rs));
+        bool done = false;
+        for (int sweep = 0; sweep < 40 && !done; ++sweep) {
+            float mm = 0.f;
+#pragma unroll
+            for (int i = 0; i < C; ++i) mm = fmaf(g[i].x, g[i].x, fmaf(g[i].y, g[i].y, mm));
+            mm = fmaxf(mm, fxor<1>(mm));
+            mm = fmaxf(mm, fxor<2>(mm));
+            mm = fmaxf(mm, fxor<4>(mm));
+            const float floor2 = 1e-12f * mm * mm;  // (~(8 eps32 |g_max|^2)^2)
+            bool rot = false;
+            rot |= jacobi_round_f32<C, 1>(g, j, floor2);
+            rot |= jacobi_round_f32<C, 2>(g, j, floor2);
+            rot |= jacobi_round_f32<C, 3>(g, j, floor2);
+            rot |= jacobi_round_f32<C, 4>(g, j, floor2);
+            rot |= jacobi_round_f32<C, 5>(g, j, floor2);
+            rot |= jacobi_round_f32<C, 6>(g, j, floor2);
+            rot |= jacobi_round_f32<C, 7>(g, j, floor2);
+            done = !__any(rot);
+        }
+        // (no float64 fallback in this kernel: its working set alone costs a wave per SIMD; sweep
+        //  exhaustion is reported as SETK_NUM_NOCONV like jacobi_pevd's, and never seen in tests)
+        if (!done) noconv = 1;
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < C; ++i) m = fmaf(g[i].x, g[i].x, fmaf(g[i].y, g[i].y, m));
+        float best = m;
+        int bj = j;
+#pragma unroll
+        for (int s = 1; s < W; s <<= 1) {
+            const float ob = __shfl_xor(best, s, W);
+            const int oj = __shfl_xor(bj, s, W);
+            if (ob > best || (ob == best && oj < bj)) {
+                best = ob;
+                bj = oj;
+            }
+        }
+        cd v[C];
+        double nn = 0.0;
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            v[i] = make_double2((double)__shfl(g[i].x, bj, W), (double)__shfl(g[i].y, bj, W));
+            nn += zabs2(v[i]);
+        }
+        double inv = (nn > 0.0) ? 1.0 / sqrt(nn) : 0.0;
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = zscale(v[i], inv);
+        // two power steps against the float64 matrix; the last norm is the eigenvalue
+        lam = 0.0;
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) {
+            cd y[C];
+            herm_matvec<C>(a, v, y);
+            nn = 0.0;
+#pragma unroll
+            for (int i = 0; i < C; ++i) nn += zabs2(y[i]);
+            lam = sqrt(nn);
+            inv = (lam > 0.0) ? 1.0 / lam : 0.0;
+#pragma unroll
+            for (int i = 0; i < C; ++i) v[i] = zscale(y[i], inv);
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            out[i] = v[i];
+            if (!(lam > 0.0)) out[i] = make_double2((i == 0) ? 1.0 : 0.0, 0.0);
+        }
+    }
+}
+
 template <int C>
 SD void fix_gauge(cd (&v)[C]) {
     const double a = sqrt(zabs2(v[0]));
@@ -260,17 +418,6 @@ SD void gev_vector(const cd (&rs)[C], const cd* L, cd* Wk, int j, bool gauge, cd
     for (int i = 0; i < C; ++i) vout[i] = y[i];
 }
 
-// y = M x for a Hermitian M held one column per lane (col[i] = M[i][j]):
-// lane j forms (M x)_j = sum_m conj(col[m]) x[m], the results are all-gathered.
-template <int C>
-SD void herm_matvec(const cd (&col)[C], const cd (&x)[C], cd (&y)[C]) {
-    cd mine = make_double2(0.0, 0.0);
-#pragma unroll
-    for (int m = 0; m < C; ++m) mine = zadd(mine, zcmul(col[m], x[m]));
-#pragma unroll
-    for (int i = 0; i < C; ++i) y[i] = zshfl<Grp<C>::W>(mine, i);
-}
-
 // KIND is a template parameter: every beamformer gets its own register
 // allocation (a single runtime-switched kernel needed 354 VGPRs because the
 // allocator sees the union of all branches), and the matrices are fetched when
@@ -341,7 +488,7 @@ __global__ __launch_bounds__(64, (C > 8) ? 1 : SETK_SOLVE_WAVES) void solve_kern
         cd g[C];
         load_col(0, g);
         double lam;
-        jacobi_pevd<C>(g, j, w, lam, st_noconv);
+        pevd_mixed<C>(g, j, w, lam, st_noconv);
         if (gauge) fix_gauge<C>(w);
     } else if (kind == kKindPevd || kind == SETK_BF_GEVD) {
         {
@@ -358,7 +505,7 @@ __global__ __launch_bounds__(64, (C > 8) ? 1 : SETK_SOLVE_WAVES) void solve_kern
             cd g[C];
             load_col(0, g);
             double lam;
-            jacobi_pevd<C>(g, j, d, lam, st_noconv);
+            pevd_mixed<C>(g, j, d, lam, st_noconv);
         }
         if (gauge) fix_gauge<C>(d);
         {
@@ -382,7 +529,7 @@ __global__ __launch_bounds__(64, (C > 8) ? 1 : SETK_SOLVE_WAVES) void solve_kern
             cd g[C];
             load_col(0, g);
             double lam;
-            jacobi_pevd<C>(g, j, sv, lam, st_noconv);
+            pevd_mixed<C>(g, j, sv, lam, st_noconv);
             if (gauge) fix_gauge<C>(sv);
         } else {
             cd rn[C];

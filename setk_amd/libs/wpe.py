@@ -140,15 +140,22 @@ def wpe(reverb, taps=10, delay=3, context=1, num_iters=3):
     return outs[0].astype(np.complex128)
 
 
-def wpe_batch(reverbs, taps=10, delay=3, context=1, num_iters=3):
-    """wpe() for a list of utterances with the same channel count: one launch per
-    iteration over every (bin, utterance).  reverbs: F x N x T_u arrays -> list of
-    dereverberated F x N x T_u complex128 arrays; an utterance whose tap correlation is
-    singular comes back as None (the CLI skips it like the reference's LinAlgError)."""
+def wpe_batch(reverbs, taps=10, delay=3, context=1, num_iters=3, dtype=np.complex64):
+    """wpe() for a list of utterances with the same channel count (a setk_amd extension: the
+    reference has no batched entry): one launch per iteration over every (bin, utterance).
+    reverbs: F x N x T_u arrays -> list of dereverberated F x N x T_u arrays; an utterance
+    whose tap correlation is singular comes back as None (the CLI skips it like the
+    reference's LinAlgError).  The results are complex64 -- what the device computes and
+    stores between iterations -- unless `dtype=np.complex128` asks for the reference's promoted
+    type: that widening alone (20 MB per 4-ch 10 s utterance, on the host) used to cost more
+    than the kernels and made the batched call slower per utterance than wpe() (round-3
+    review).  Samples-in / samples-out users should take engine.BatchDereverb, which keeps the
+    spectra on the device."""
     if not len(reverbs):
         return []
     outs, status = _run_fnt(reverbs, taps, delay, context, num_iters)
-    return [None if status[u].any() else outs[u].astype(np.complex128) for u in range(len(outs))]
+    return [None if status[u].any() else (outs[u] if np.dtype(dtype) == np.complex64 else outs[u].astype(dtype))
+            for u in range(len(outs))]
 
 
 def facted_wpd(obs, cgmm_iters=10, wpd_iters=3, taps=10, delay=3, context=1, update_alpha=False):

@@ -76,10 +76,13 @@ def test_wpe_batch_equals_single_calls():
             for T in (90, 61, 140)]
     revs.insert(2, np.zeros((257, 3, 50), np.complex64))
     outs = W.wpe_batch(revs, taps=5, delay=2, context=1, num_iters=2)
-    assert outs[2] is None
+    wide = W.wpe_batch(revs, taps=5, delay=2, context=1, num_iters=2, dtype=np.complex128)
+    assert outs[2] is None and wide[2] is None
     for k in (0, 1, 3):
         single = W.wpe(revs[k], taps=5, delay=2, context=1, num_iters=2)
-        assert outs[k].dtype == np.complex128 and np.array_equal(outs[k], single), k
+        # complex64 (what the device stores) unless the reference's promoted type is asked for
+        assert outs[k].dtype == np.complex64 and np.array_equal(outs[k].astype(np.complex128), single), k
+        assert wide[k].dtype == np.complex128 and np.array_equal(wide[k], single), k
 
 
 def test_wpe_too_many_taps_is_refused():

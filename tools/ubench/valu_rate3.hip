@@ -5,6 +5,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -o valu_rate3 tools/ubench/valu_rate3.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <string>
 #include <vector>
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
@@ -82,9 +83,13 @@ void run(const char* name, int threads, int fma_per_instr) {
     (void)hipFree(d); (void)hipFree(c);
 }
 
-int main() {
-    for (int th : {256, 512, 1024}) {
+int main(int argc, char** argv) {
+    // --fma-only: the plain-fp32 issue rate at 1 / 2 / 3 / 4 waves per SIMD (bench.py measures the
+    // `at_occupancy` ceilings of its roofline block with it, in the run itself)
+    const bool fma_only = argc > 1 && std::string(argv[1]) == "--fma-only";
+    for (int th : {256, 512, 768, 1024}) {
         run<0>("v_fma_f32", th, 1);
+        if (fma_only) continue;
         run<1>("v_pk_fma_f32", th, 2);
         run<2>("v_pk_mul_f32", th, 2);
         run<3>("v_pk_add_f32", th, 2);
