@@ -58,6 +58,11 @@ extern "C" {
 #define SETK_NUM_SINGULAR 1 /* noise covariance not positive definite        */
 #define SETK_NUM_NOCONV 2   /* Jacobi sweep limit reached                    */
 #define SETK_NUM_NONFINITE 3
+#define SETK_NUM_RANKDEF 4  /* WPE only, NOT an error: the tap correlation was rank deficient
+                              (fewer frames than channels x taps, a silent or duplicated channel),
+                              columns at the noise level were dropped and a filter was produced;
+                              numpy.linalg.solve in the reference also goes through on such
+                              input, with a different, noise-determined filter */
 
 /* beamformer kinds (apply_adaptive_beamformer.py:22, --beamformer) */
 #define SETK_BF_MVDR 0

@@ -21,6 +21,14 @@ LIB_PATH = os.environ.get("SETK_LIB", os.path.join(_HERE, "libsetk_hip.so"))
 SETK_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM = -1, -2, -3, -4
 NUM_OK, NUM_SINGULAR, NUM_NOCONV, NUM_NONFINITE = 0, 1, 2, 3
+NUM_RANKDEF = 4  # WPE: rank-deficient tap correlation, columns dropped -- a note, not an error
+
+
+def wpe_failed(status):
+    """Boolean array: the bins whose WPE status is an error (SETK_NUM_RANKDEF is only a note)."""
+    import numpy as _np
+    st = _np.asarray(status)
+    return (st != NUM_OK) & (st != NUM_RANKDEF)
 BF_MVDR, BF_GEVD, BF_PMWF, BF_MPDR, BF_MPDR_WHITEN = 0, 1, 2, 3, 4
 RANK1_NONE, RANK1_EIG, RANK1_GEV = 0, 1, 2
 FLAG_BAN, FLAG_CLAMP_MASK, FLAG_POST_MASK, FLAG_NO_GAUGE, FLAG_OUT_PCM16 = 1, 2, 4, 8, 16

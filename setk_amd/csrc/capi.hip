@@ -1751,14 +1751,18 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
         if (rc) return rc;
     }
     if (status) {
-        // worst status over the iterations, per utterance and bin
+        // worst status over the iterations, per utterance and bin: an error code (1..3) wins
+        // over the SETK_NUM_RANKDEF note (4)
         std::vector<int> st((size_t)n_utts * F * num_iters);
         HIP_TRY(h, hipMemcpyAsync(st.data(), d_st, st.size() * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
         std::vector<int> worst((size_t)n_utts * F, 0);
         for (int it = 0; it < num_iters; ++it)
-            for (size_t i = 0; i < worst.size(); ++i)
-                worst[i] = std::max(worst[i], st[(size_t)it * n_utts * F + i]);
+            for (size_t i = 0; i < worst.size(); ++i) {
+                const int v = st[(size_t)it * n_utts * F + i], w0 = worst[i];
+                const bool ev = v > 0 && v != SETK_NUM_RANKDEF, ew = w0 > 0 && w0 != SETK_NUM_RANKDEF;
+                worst[i] = (ev && ew) ? std::max(v, w0) : ev ? v : ew ? w0 : std::max(v, w0);
+            }
         if (is_device_ptr(status))
             HIP_TRY(h, hipMemcpy(status, worst.data(), worst.size() * sizeof(int),
                                  hipMemcpyHostToDevice));
@@ -1978,7 +1982,8 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     p1.mc_win = h->d_mc_win;
     // pass 1 on the matrix cores is opt-in (SETK_MC_PASS1=1): parity-green, but its transform
     // waves are the long pole of the tile pipeline (0.95 ms against 0.88)
-    const bool mc1 = h->mc_enabled && getenv("SETK_MC_PASS1") && atoi(getenv("SETK_MC_PASS1")) != 0;
+    const bool mc1 = h->mc_enabled && pass1_mc_supported(C, g.hop) && getenv("SETK_MC_PASS1") &&
+                     atoi(getenv("SETK_MC_PASS1")) != 0;
     if (mc1)
         HIP_TRY(h, launch_pass1_mc(C, p1, (int)items1.size(), s));
     else

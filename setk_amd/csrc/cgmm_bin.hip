@@ -956,13 +956,12 @@ hipError_t launch_cfg(const CgmmBinArgs* d_tbl, int n_utts, int F, int max_frame
     // 87 ms per 125 x 30 s against 61 ms for the streaming kernels, 45 ms without spills)
     constexpr int wps = C < 7 ? c.wps : ((c.nt <= 256 && c.u <= 5) ? 3 : 2);
     auto kern = cgmm_bin_em_kernel<C, c.nt, c.u, c.rf, wps>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // per launch, like wpe.hip and solve.hip: the attribute belongs to the CURRENT device's copy of
+    // the kernel, so a process-wide "already set" flag would skip the second device of a process
+    // (and two threads could race on it); the call itself is a table lookup
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(F, n_utts), dim3(c.nt), lds, s, d_tbl, num_iters, tlp);
     return hipGetLastError();
 }

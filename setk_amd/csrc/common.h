@@ -135,6 +135,7 @@ struct ScaleArgs {
 // launchers (implemented in the kernel TUs)
 hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s);
 hipError_t launch_pass1_mc(int C, const Pass1Args& a, int n_items, hipStream_t s);
+bool pass1_mc_supported(int C, int hop);
 hipError_t launch_pass2_mc(int C, const Pass2Args& a, int n_items, hipStream_t s);
 int pass2_mc_wgs_per_cu(int C);
 // STFT of whole utterances into the bin-major [F][C][Tp] layout of cgmm_bin.hip

@@ -119,7 +119,20 @@ MC_DEV void split8(const float (&v)[8], h8& hi, h8& lo) {
         lo[e + 1] = q[1];
     }
 }
-// the two halves of split8 as separate steps (hi first: see forward())
+// the two halves of split8 as separate steps (hi first: see forward()).
+// MCDFT_ASM_SPLIT: v_fma_mixlo_f16 / v_fma_mixhi_f16 round an fp32 fused multiply-add straight
+// into one half of a packed register -- the hi half of x * w in ONE instruction per element (no
+// separate multiply, no v_cvt_pk), the lo half fma(x, w, -hi) in one more: 16 instructions per
+// eight windowed samples where the compiler's form takes 24, 12 instead of 16 for the
+// mid-transform split.  Each block ends in `s_nop 1`: its results feed an MFMA, and hipcc pads
+// no hazards for instructions inside an asm statement (cdna_hip_programming.md section 5.7).
+// Measured (8-ch, 125 x 30 s): pass 2 0.745 ms with the asm blocks against 0.70 ms with the
+// compiler's own selection (it already forms v_fma_mix_f32 for the windowed samples and
+// schedules freely around single instructions; the blocks pin 9 instructions and their nop):
+// off by default, kept for the record.
+#ifndef MCDFT_ASM_SPLIT
+#define MCDFT_ASM_SPLIT 0
+#endif
 MC_DEV void split8_hi(const float (&v)[8], h8& hi) {
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
@@ -129,6 +142,23 @@ MC_DEV void split8_hi(const float (&v)[8], h8& hi) {
     }
 }
 MC_DEV void split8_lo(const float (&v)[8], h8 hi, h8& lo) {
+#if MCDFT_ASM_SPLIT
+    const u4 h = __builtin_bit_cast(u4, hi);
+    unsigned l0, l1, l2, l3;
+    asm("v_fma_mixlo_f16 %0, %4, 1.0, -%12 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %5, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %1, %6, 1.0, -%13 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %7, 1.0, -%13 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %2, %8, 1.0, -%14 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %9, 1.0, -%14 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %10, 1.0, -%15 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %11, 1.0, -%15 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+          "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+    lo = __builtin_bit_cast(h8, (u4){l0, l1, l2, l3});
+#else
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
         float la, lb;
@@ -137,16 +167,52 @@ MC_DEV void split8_lo(const float (&v)[8], h8 hi, h8& lo) {
         lo[e] = q[0];
         lo[e + 1] = q[1];
     }
+#endif
 }
 MC_DEV void split8_mul_hi(const float (&v)[8], const float (&w)[8], h8& hi) {
+#if MCDFT_ASM_SPLIT
+    unsigned h0, h1, h2_, h3;
+    asm("v_fma_mixlo_f16 %0, %4, %12, 0\n\t"
+        "v_fma_mixhi_f16 %0, %5, %13, 0\n\t"
+        "v_fma_mixlo_f16 %1, %6, %14, 0\n\t"
+        "v_fma_mixhi_f16 %1, %7, %15, 0\n\t"
+        "v_fma_mixlo_f16 %2, %8, %16, 0\n\t"
+        "v_fma_mixhi_f16 %2, %9, %17, 0\n\t"
+        "v_fma_mixlo_f16 %3, %10, %18, 0\n\t"
+        "v_fma_mixhi_f16 %3, %11, %19, 0\n\t"
+        "s_nop 1"
+        : "=&v"(h0), "=&v"(h1), "=&v"(h2_), "=&v"(h3)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+          "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+    hi = __builtin_bit_cast(h8, (u4){h0, h1, h2_, h3});
+#else
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
         const h2 p = __builtin_convertvector((f2){v[e] * w[e], v[e + 1] * w[e + 1]}, h2);
         hi[e] = p[0];
         hi[e + 1] = p[1];
     }
+#endif
 }
 MC_DEV void split8_mul_lo(const float (&v)[8], const float (&w)[8], h8 hi, h8& lo) {
+#if MCDFT_ASM_SPLIT
+    const u4 h = __builtin_bit_cast(u4, hi);
+    unsigned l0, l1, l2, l3;
+    asm("v_fma_mixlo_f16 %0, %4, %12, -%20 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %5, %13, -%20 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %1, %6, %14, -%21 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %7, %15, -%21 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %2, %8, %16, -%22 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %9, %17, -%22 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %10, %18, -%23 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %11, %19, -%23 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+          "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]),
+          "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+    lo = __builtin_bit_cast(h8, (u4){l0, l1, l2, l3});
+#else
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
         const h2 q = __builtin_convertvector(
@@ -154,6 +220,7 @@ MC_DEV void split8_mul_lo(const float (&v)[8], const float (&w)[8], h8 hi, h8& l
         lo[e] = q[0];
         lo[e + 1] = q[1];
     }
+#endif
 }
 // the same for products v[e] * w[e] (window): lo = fma(v, w, -hi) keeps the product's own
 // rounding error too

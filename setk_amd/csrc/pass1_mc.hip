@@ -58,12 +58,12 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_mc_kernel(Pass1Args a) {
     constexpr int ND = PairSplit<C>::ND, NO = PairSplit<C>::NO;
     constexpr int F = kBins, FP = kBinsPad;
     constexpr int SL = kMcSlot;
-    constexpr int PER = (NF + 7) / 8;     // transforms per transform wave and tile
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* xt0 = reinterpret_cast<cf*>(smem);                              // [2][NF][SL]
-    float* a16s = reinterpret_cast<float*>(xt0 + 2 * NF * SL);          // [8][16][kOddPitch]
-    float* nym = a16s + 8 * 16 * mc::kOddPitch;                         // [2][2][8] bin-256 weights
+    mc::u4* ktiles = reinterpret_cast<mc::u4*>(xt0 + 2 * NF * SL);      // [10][64]: the forward's 8 operand tiles, OT_H, OT_L
+    float* a16s = reinterpret_cast<float*>(ktiles + 10 * 64);           // [8][4][kOddPitch]
+    float* nym = a16s + 8 * 4 * mc::kOddPitch;                          // [2][2][8] bin-256 weights
     float* red = nym + 32;                                              // [16]
 
     const int tid = threadIdx.x;
@@ -75,6 +75,8 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_mc_kernel(Pass1Args a) {
     const bool clamp = (a.flags & 0x2) != 0;
     const bool has_mn = ud.mask_n != nullptr;
 
+    mc::stage_tiles(ktiles, a.mc_tab, mc::kW_MC_H, 8, tid, NT);
+    mc::stage_tiles(ktiles + 8 * 64, a.mc_tab, mc::kW_OT_H, 2, tid, NT);
     float mx = 0.f;
     const int ct = tid - 512;
     const int f = ct & 255, q = (ct >> 8) & 1;
@@ -87,92 +89,127 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_mc_kernel(Pass1Args a) {
     if (wave < 8) {
 #ifndef SETK_ONLY_CONS
         // ================= transform waves =================
+        // C divides 8: G = 8 / C waves per channel, each owns FPW = TB / G CONSECUTIVE frames of
+        // a tile.  With hop = 256 consecutive frames share half their samples in the same lane's
+        // registers (mc::sample_of), so the wave works on a stream of half-frames: NH per tile,
+        // held one tile ahead in H (16 - 20 registers; a half is requested for the NEXT tile the
+        // moment its slot is consumed, a whole tile period before its use).
+        constexpr int G = 8 / C;
+        constexpr int FPW = TB / G;
+        constexpr int NH = FPW + (G > 1 ? 1 : 0);  // halves a tile consumes (G == 1: the first one is carried over)
         const int lane = tid & 63;
         const int c16 = lane & 15, g = lane >> 4;
-        const int nv = (NF - wave + 7) / 8;  // transforms of this wave per tile (wave-uniform)
-        mc::Fwd K;
-        mc::load_fwd(K, a.mc_tab, lane);
-        const mc::h8 ot_h = mc::tab_h8(a.mc_tab, mc::kW_OT_H, lane);
-        const mc::h8 ot_l = mc::tab_h8(a.mc_tab, mc::kW_OT_L, lane);
+        const int ch = wave % C, gi = wave / C;   // wave-uniform
+        float tr[4], ti[4], tri[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            tr[r] = mc::tab_f(a.mc_tab, mc::kW_TR + r, lane);
+            ti[r] = mc::tab_f(a.mc_tab, mc::kW_TI + r, lane);
+            tri[r] = mc::tab_f(a.mc_tab, mc::kW_TRI + r, lane);
+        }
         float win[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) win[e] = gptr(a.mc_win)[e * 64 + lane];
-        float* a16w = a16s + wave * 16 * mc::kOddPitch;
+        float* a16w = a16s + wave * 4 * mc::kOddPitch;
         const int lane_bin = mc::bin_of(c16, g, 0);
         const bool st_ok = !(c16 == 0 && g >= 2);
         const bool st_256 = (c16 == 0 && g == 2);
+        gcfloat_p xa = gptr(ud.audio) + (size_t)ch * n_samp;
+        const int lo = 64 * g + c16;
+        const int pad = a.g.pad;
 
-        // samples (and the bin-256 mask entries of channel 0) travel SETK_P1MC_PF transforms
-        // ahead of their use: a wave issues its VALU instructions ~8 cycles apart whatever its
-        // neighbours do, so one transform lasts ~1000 cycles -- less than a loaded HBM round trip
-#ifndef SETK_P1MC_PF
-#define SETK_P1MC_PF 2
-#endif
-        struct Stage {
-            float raw[8];
-            float ms, mn;
-            bool ok;
-        };
-        Stage st[SETK_P1MC_PF];
-        // transform number jt (>= nv: of a later tile) counted from tile tb_tile
-        auto fetch = [&](Stage& S, int tb_tile, int jt) {
-            while (jt >= nv) {
-                jt -= nv;
-                tb_tile += TB;
-            }
-            S.ok = false;
-            S.ms = S.mn = 0.f;
-            if (tb_tile >= wi.t1) return;  // past the range: never consumed
-            const int i = wave + 8 * jt;
-            const int tt = i / C, c = i - tt * C;
-            const int t = tb_tile + tt;
-            S.ok = t < wi.t1;
-            load_raw_mc(S.raw, gptr(ud.audio) + (size_t)c * n_samp, n_samp, t * a.g.hop - a.g.pad, lane, S.ok);
-            if (c == 0 && lane == 0 && S.ok) {
-                S.ms = gptr(ud.mask_s)[(size_t)t * F + 256];
-                if (has_mn) S.mn = gptr(ud.mask_n)[(size_t)t * F + 256];
+        // half-frame u = padded positions [256 u, 256 u + 256): frame t = halves (t, t + 1);
+        // halves past the last frame repeat the last one (frames beyond t1 carry zero weights)
+        auto load_half = [&](float (&h)[4], int u) {
+            u = min(u, T);
+            const int s0 = 256 * u - pad;
+            if (s0 >= 0 && s0 + 256 <= n_samp) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = xa[s0 + lo + 16 * e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = xa[reflect_index(s0 + lo + 16 * e, n_samp)];
             }
         };
-        auto produce = [&](int b, int tb_tile) {
+        // half number i (< NH) of the tile that starts at frame tb
+        auto half_of = [&](int tb, int i) { return tb + gi * FPW + i + (G > 1 ? 0 : 1); };
+        float H[NH][4];
+        float prev[4];  // first half of the next transform (G == 1: across tiles too)
+        float ms[FPW], mn[FPW];  // bin-256 mask entries of the next tile (channel-0 waves, lane 0)
+        auto fetch_ny = [&](int tb) {
 #pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                if (j < nv) {
-                    const int i = wave + 8 * j;
-                    const int tt = i / C, c = i - tt * C;
-                    float x[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = st[0].raw[e];
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) mx = max3_abs(mx, x[e], x[e + 1]);
-                    if (c == 0 && lane == 0) {
-                        const float s = clamp ? fminf(st[0].ms, 1.f) : st[0].ms;
-                        nym[(b * 2 + 0) * 8 + tt] = s;
-                        nym[(b * 2 + 1) * 8 + tt] = st[0].ok ? (has_mn ? st[0].mn : 1.f - s) : 0.f;
-                    }
-#pragma unroll
-                    for (int d = 0; d + 1 < SETK_P1MC_PF; ++d) st[d] = st[d + 1];
-                    fetch(st[SETK_P1MC_PF - 1], tb_tile, j + SETK_P1MC_PF);
-                    mc::f4 zr, zi, a16;
-                    mc::forward(x, win, K, zr, zi, a16);
-                    cf* slot = xt0 + (b * NF + i) * SL;
-                    mc::lds_fp re = mc::to_lds(reinterpret_cast<float*>(slot + lane_bin));
-                    mc::lds_fp im = mc::opaque_next(re);
-                    if (st_ok) mc::store_bins(re, im, zr, zi);
-                    if (st_256) slot[256] = make_float2(zr[3], 0.f);
-                    mc::store_a16(a16w, j, lane, a16);
+            for (int j = 0; j < FPW; ++j) {
+                const int t = tb + gi * FPW + j;
+                ms[j] = mn[j] = 0.f;
+                if (ch == 0 && lane == 0 && t < wi.t1) {
+                    ms[j] = gptr(ud.mask_s)[(size_t)t * F + 256];
+                    if (has_mn) mn[j] = gptr(ud.mask_n)[(size_t)t * F + 256];
                 }
             }
-            // odd family X[16 + 32 q] of this wave's transforms (columns j < nv of the tile)
-            const mc::f4 d = mc::odd_tile(a16w, ot_h, ot_l, lane);
-            if (c16 < nv) {
-                cf* sj = xt0 + (b * NF + wave + 8 * c16) * SL;
+        };
+        if (G == 1) load_half(prev, wi.t0);
+#pragma unroll
+        for (int i = 0; i < NH; ++i) load_half(H[i], half_of(wi.t0, i));
+        fetch_ny(wi.t0);
+
+        auto produce = [&](int b, int tb) {
+#pragma unroll
+            for (int j = 0; j < FPW; ++j) {
+                const int i = (gi * FPW + j) * C + ch;  // slot of (frame tb + gi FPW + j, channel ch)
+                float x[8];
+                if (G > 1 && j == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) prev[e] = H[0][e];
+                    load_half(H[0], half_of(tb + TB, 0));
+                }
+                const int hs = j + (G > 1 ? 1 : 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[e] = prev[e];
+                    x[4 + e] = H[hs][e];
+                    prev[e] = H[hs][e];
+                }
+                mx = max3_abs(mx, x[4], x[5]);
+                mx = max3_abs(mx, x[6], x[7]);
+                if (G > 1 && j == 0) {
+                    mx = max3_abs(mx, x[0], x[1]);
+                    mx = max3_abs(mx, x[2], x[3]);
+                }
+                load_half(H[hs], half_of(tb + TB, hs));  // the same slot, one tile ahead
+                if (ch == 0 && lane == 0) {
+                    const int tt = gi * FPW + j;
+                    const float sv = clamp ? fminf(ms[j], 1.f) : ms[j];
+                    nym[(b * 2 + 0) * 8 + tt] = sv;
+                    nym[(b * 2 + 1) * 8 + tt] = (tb + tt < wi.t1) ? (has_mn ? mn[j] : 1.f - sv) : 0.f;
+                }
+                mc::f4 zr, zi, a16;
+                asm volatile("" ::: "memory");  // the operand tiles are re-read per transform, not kept
+                mc::forward_t(x, win, [&](int k) { return mc::lds_h8(ktiles, k, lane); }, tr, ti, tri, zr, zi, a16);
+                cf* slot = xt0 + (b * NF + i) * SL;
+                mc::lds_fp re = mc::to_lds(reinterpret_cast<float*>(slot + lane_bin));
+                mc::lds_fp im = mc::opaque_next(re);
+                if (st_ok) mc::store_bins(re, im, zr, zi);
+                if (st_256) slot[256] = make_float2(zr[3], 0.f);
+                mc::store_a16(a16w, j, lane, a16);
+            }
+            if (G == 1 && wi.t0 == tb) {
+                // (the very first half of the range was outside H: nothing else to do)
+            }
+            fetch_ny(tb + TB);
+            // odd family X[16 + 32 q] of this wave's transforms (columns j < FPW of the tile)
+            const mc::f4 d = mc::odd_tile(a16w, mc::lds_h8(ktiles, 8, lane), mc::lds_h8(ktiles, 9, lane), lane, FPW);
+            if (c16 < FPW) {
+                cf* sj = xt0 + (b * NF + (gi * FPW + c16) * C + ch) * SL;
                 sj[16 + 64 * g] = make_float2(d[0], d[1]);
                 sj[48 + 64 * g] = make_float2(d[2], d[3]);
             }
         };
-
-#pragma unroll
-        for (int d = 0; d < SETK_P1MC_PF; ++d) fetch(st[d], wi.t0, d);
+        // G == 1: the first half of the range's first frame also counts for max |x|
+        if (G == 1) {
+            mx = max3_abs(mx, prev[0], prev[1]);
+            mx = max3_abs(mx, prev[2], prev[3]);
+        }
+        wg_barrier();  // operand tiles staged
         produce(0, wi.t0);
         wg_barrier();
         int buf = 0;
@@ -219,6 +256,7 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_mc_kernel(Pass1Args a) {
             }
         };
         fetch_masks(wi.t0, cur_s, cur_n);
+        wg_barrier();  // operand tiles staged
         wg_barrier();  // tile 0 transformed
         int buf = 0;
 #pragma unroll 1
@@ -303,8 +341,8 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_mc_kernel(Pass1Args a) {
 template <int C>
 static hipError_t launch_pass1_mc_t(const Pass1Args& a, int n_items, hipStream_t s) {
     constexpr int NF = pass1_tile_frames(C) * C;
-    const size_t lds = (size_t)2 * NF * kMcSlot * sizeof(cf) +
-                       (8 * 16 * mc::kOddPitch + 32 + 16) * sizeof(float);
+    const size_t lds = (size_t)2 * NF * kMcSlot * sizeof(cf) + 10 * 1024 +
+                       (8 * 4 * mc::kOddPitch + 32 + 16) * sizeof(float);
     auto k = stft_covar_mc_kernel<C>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -313,15 +351,16 @@ static hipError_t launch_pass1_mc_t(const Pass1Args& a, int n_items, hipStream_t
     return hipGetLastError();
 }
 
+// channel counts that divide 8 and hop = n_fft / 2 (the half-frame stream of the transform
+// waves); everything else keeps pass1.hip
+bool pass1_mc_supported(int C, int hop) { return hop == kNfft / 2 && (C == 1 || C == 2 || C == 4 || C == 8); }
+
 hipError_t launch_pass1_mc(int C, const Pass1Args& a, int n_items, hipStream_t s) {
+    if (!pass1_mc_supported(C, a.g.hop)) return hipErrorInvalidValue;
     switch (C) {
         case 1: return launch_pass1_mc_t<1>(a, n_items, s);
         case 2: return launch_pass1_mc_t<2>(a, n_items, s);
-        case 3: return launch_pass1_mc_t<3>(a, n_items, s);
         case 4: return launch_pass1_mc_t<4>(a, n_items, s);
-        case 5: return launch_pass1_mc_t<5>(a, n_items, s);
-        case 6: return launch_pass1_mc_t<6>(a, n_items, s);
-        case 7: return launch_pass1_mc_t<7>(a, n_items, s);
         case 8: return launch_pass1_mc_t<8>(a, n_items, s);
     }
     return hipErrorInvalidValue;

@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict
         // a pivot at the noise level is a direction R does not span: its column is dropped
         // (L[.][k] = 0, y[k] = 0, G[k] = 0) instead of being divided by noise
         const double inv = (dkk > pfloor) ? 1.0 / sqrt(dkk) : 0.0;
+        if (!(dkk > pfloor) && tid == 0) *flag = SETK_NUM_RANKDEF;  // reported, not fatal
         // column k below the diagonal (the diagonal entry itself stays: others may still be
         // reading it as their pivot) and row k of r
         for (int i = k + 1 + tid; i < NK; i += 256) {
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict
     __syncthreads();
     const int bad = *flag;
     if (tid == 0 && a.status) a.status[f] = bad;
-    if (bad) {
+    if (bad && bad != SETK_NUM_RANKDEF) {
         // the reference raises LinAlgError for the whole utterance; leave x in place
         for (int i = tid; i < N * T; i += 256) a.out[(size_t)f * N * T + i] = xf[i];
         return;

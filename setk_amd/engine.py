@@ -420,6 +420,23 @@ class FixedBatchBeamformer(object):
         self.pcm16 = pcm16
         self.max_batch_samples = max_batch_samples
 
+    def set_weights(self, weights):
+        """Swap the weight table (B x F x M) and keep everything else -- the pinned slabs, the
+        device twin, the stream: what a caller does whose table grows from batch to batch
+        (apply_classic_beamformer: one entry per DoA seen so far)."""
+        weights = np.asarray(weights)
+        if weights.ndim == 2:
+            weights = weights[None]
+        weights = np.ascontiguousarray(weights, dtype=np.complex64)
+        if weights.shape[1:] != self.weights.shape[1:]:
+            raise ValueError(f"weights {weights.shape[1:]}, engine built for {self.weights.shape[1:]}")
+        if self._dw:
+            if self._slabs is not None:
+                self.ctx.stream_synchronize(self._slabs.stream)  # the old table may still be read
+            self.ctx.device_free(self._dw)
+            self._dw = 0
+        self.weights = weights
+
     @property
     def torch(self):
         if self._torch is None:
@@ -711,6 +728,7 @@ class BatchDereverb(object):
         # writer's rule (wavio.float_to_pcm16: rint(x * 32767) in float64, wrapping)
         self.pcm16 = bool(pcm16)
         self.taps, self.delay, self.context, self.num_iters = taps, delay, context, num_iters
+        self.rank_deficient_bins = 0  # SETK_NUM_RANKDEF notes seen so far (apply_wpe logs them)
         n_fft = nextpow2(frame_len) if round_power_of_two else frame_len
         self.stft = dict(frame_len=frame_len, frame_hop=frame_hop, n_fft=n_fft, center=center,
                          window=stft_window(window, frame_len))
@@ -799,8 +817,9 @@ class BatchDereverb(object):
                 ctx.istft(base + spec_out[k], C, T, None, None, b.d_out + off_out[k], stream=b.stream)
         host = b.fetch(n_out)
         out = []
+        self.rank_deficient_bins += int(np.count_nonzero(status == _ffi.NUM_RANKDEF))
         for k, L in enumerate(lens):
-            if status[k].any():
+            if _ffi.wpe_failed(status[k]).any():
                 out.append(None)
             elif self.pcm16:
                 out.append(np.frombuffer(host[off_out[k]:off_out[k] + 2 * C * L],
@@ -848,8 +867,8 @@ class BatchDereverb(object):
             q = torch.round(waves.double() * 32767.0).to(torch.int64).to(torch.int16)
             # channel-major C x L per utterance -> interleaved frames L x C
             host = torch.cat([q[o:o + C * L].view(C, L).t().reshape(-1) for o, L in views]).cpu().numpy()
-            return [None if status[u].any() else host[o:o + C * L].reshape(L, C)
+            return [None if _ffi.wpe_failed(status[u]).any() else host[o:o + C * L].reshape(L, C)
                     for u, (o, L) in enumerate(views)]
         host = waves.cpu().numpy()
-        return [None if status[u].any() else host[o:o + C * L].reshape(C, L)
+        return [None if _ffi.wpe_failed(status[u]).any() else host[o:o + C * L].reshape(C, L)
                 for u, (o, L) in enumerate(views)]

@@ -50,6 +50,17 @@ def compute_lambda(dereverb, ctx=0):
     return np.maximum(lam / counts, EPSILON)
 
 
+def _note_rankdef(status, what="WPE"):
+    """Rank-deficient tap correlations (fewer frames than channels x taps, a silent or duplicated
+    channel): the device drops the columns at the noise level and still returns a filter where
+    numpy.linalg.solve in the reference returns a different, noise-determined one -- say so."""
+    n = int(np.count_nonzero(np.asarray(status) == _ffi.NUM_RANKDEF))
+    if n:
+        logger.warning(f"{what}: rank-deficient tap correlation in {n} bins; columns at the noise level "
+                       "were dropped (the reference's numpy.linalg.solve gives a noise-determined filter there)")
+    return n
+
+
 def _to_ctf(fnt):
     """F x N x T -> the library's [C][T][F] complex64."""
     return np.ascontiguousarray(np.transpose(fnt, (1, 2, 0)), dtype=np.complex64)
@@ -62,9 +73,10 @@ def _run(spec_ctf, taps, delay, context, num_iters, lambda_enh=None, want_inv_la
     inv = np.empty((T, F), dtype=np.float32) if want_inv_lambda else None
     _ffi.default_context().wpe(spec_ctf, C, T, F, taps, delay, context, num_iters, out,
                                lambda_enh=lambda_enh, inv_lambda_out=inv, status=status)
-    if status.any():
+    _note_rankdef(status)
+    if _ffi.wpe_failed(status).any():
         raise np.linalg.LinAlgError(
-            f"Singular matrix (tap correlation, {int(np.count_nonzero(status))} bins)")
+            f"Singular matrix (tap correlation, {int(np.count_nonzero(_ffi.wpe_failed(status)))} bins)")
     return out, inv
 
 
@@ -106,9 +118,10 @@ def wpe_step(reverb, yt, lambda_, taps=None, delay=None):
     out = np.empty_like(spec)
     status = np.zeros(F, dtype=np.int32)
     _ffi.default_context().wpe_step(spec, N, T, F, taps, delay, lam, out, status=status)
-    if status.any():
+    _note_rankdef(status)
+    if _ffi.wpe_failed(status).any():
         raise np.linalg.LinAlgError(
-            f"Singular matrix (tap correlation, {int(np.count_nonzero(status))} bins)")
+            f"Singular matrix (tap correlation, {int(np.count_nonzero(_ffi.wpe_failed(status)))} bins)")
     return np.transpose(out, (2, 0, 1))
 
 
@@ -134,9 +147,10 @@ def wpe(reverb, taps=10, delay=3, context=1, num_iters=3):
     F, N, T = reverb.shape
     logger.info(f"WPE: F = {F}, N = {N}, T = {T}")
     outs, status = _run_fnt([reverb], taps, delay, context, num_iters)
-    if status.any():
+    _note_rankdef(status)
+    if _ffi.wpe_failed(status).any():
         raise np.linalg.LinAlgError(
-            f"Singular matrix (tap correlation, {int(np.count_nonzero(status))} bins)")
+            f"Singular matrix (tap correlation, {int(np.count_nonzero(_ffi.wpe_failed(status)))} bins)")
     return outs[0].astype(np.complex128)
 
 
@@ -154,7 +168,9 @@ def wpe_batch(reverbs, taps=10, delay=3, context=1, num_iters=3, dtype=np.comple
     if not len(reverbs):
         return []
     outs, status = _run_fnt(reverbs, taps, delay, context, num_iters)
-    return [None if status[u].any() else (outs[u] if np.dtype(dtype) == np.complex64 else outs[u].astype(dtype))
+    _note_rankdef(status)
+    bad = _ffi.wpe_failed(status)
+    return [None if bad[u].any() else (outs[u] if np.dtype(dtype) == np.complex64 else outs[u].astype(dtype))
             for u in range(len(outs))]
 
 

@@ -111,23 +111,30 @@ def run_offline(args, beamformer, utt2doa, shard):
         # the batch engine brings its own buffers and stream (more than 8 channels: torch)
         _ffi.set_torch_free(wav_reader.first_channels_at_most(8))
     done = 0
+    # ONE engine for the run (pinned slabs, device twin and stream are allocated once, not per
+    # batch), the DS / SD weights computed once per DoA (SD: an N x N solve per bin) and the
+    # engine's table replaced only when a batch brings a DoA not seen before
+    wcache, order = {}, []
+    state = {"engine": None, "rows": 0}
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
 
         def flush(pending):
             if not pending:
                 return 0
-            doas = sorted({d for (_, _, d) in pending})
-            weights = np.stack([beamformer.weight(d, num_bins, c=args.speed, sr=args.sr)
-                                for d in doas])
-            engine = FixedBatchBeamformer(weights, frame_len=args.frame_len,
-                                          frame_hop=args.frame_hop, center=bool(args.center),
-                                          round_power_of_two=bool(args.round_power_of_two),
-                                          window=args.window, pcm16=True, device=device,
-                                          renorm=bool(args.normalize))
-            try:
-                outs = engine.run([(s, doas.index(d)) for (_, s, d) in pending])
-            finally:
-                engine.close()
+            for (_, _, d) in pending:
+                if d not in wcache:
+                    wcache[d] = beamformer.weight(d, num_bins, c=args.speed, sr=args.sr)
+                    order.append(d)
+            if state["engine"] is None:
+                state["engine"] = FixedBatchBeamformer(
+                    np.stack([wcache[d] for d in order]), frame_len=args.frame_len,
+                    frame_hop=args.frame_hop, center=bool(args.center),
+                    round_power_of_two=bool(args.round_power_of_two), window=args.window, pcm16=True,
+                    device=device, renorm=bool(args.normalize))
+            elif state["rows"] != len(order):
+                state["engine"].set_weights(np.stack([wcache[d] for d in order]))
+            state["rows"] = len(order)
+            outs = state["engine"].run([(s, order.index(d)) for (_, s, d) in pending])
             for (key, _, _), pcm in zip(pending, outs):
                 writer.write_pcm16(key, pcm)
             return len(pending)
@@ -152,7 +159,11 @@ def run_offline(args, beamformer, utt2doa, shard):
             if len(pending) >= args.batch_utts:
                 done += flush(pending)
                 pending = []
-        done += flush(pending)
+        try:
+            done += flush(pending)
+        finally:
+            if state["engine"] is not None:
+                state["engine"].close()
     return done, len(wav_reader)
 
 

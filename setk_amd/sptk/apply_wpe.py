@@ -54,7 +54,13 @@ def run(args):
                 groups.setdefault(_channels_and_size(samps)[0], []).append((key, samps))
             for _, items in groups.items():
                 try:
+                    seen = engine.rank_deficient_bins
                     outs = engine.run([s for _, s in items])
+                    if engine.rank_deficient_bins > seen:
+                        # (per batch: the utterances of one launch share the status fetch)
+                        logger.warning(f"{items[0][0]} .. {items[-1][0]}: rank-deficient tap correlation in "
+                                       f"{engine.rank_deficient_bins - seen} bins, columns at the noise level "
+                                       "dropped (the reference's solve returns a noise-determined filter there)")
                 except SetkUnsupported as e:
                     # a shape beyond the device kernels' limits (channels x taps): skip the
                     # utterances like a numerical failure instead of ending the run

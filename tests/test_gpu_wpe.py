@@ -111,6 +111,27 @@ def test_wpe_rank_deficient_goes_through_like_lu():
     fnt = (rng.standard_normal((5, 4, 10)) + 1j * rng.standard_normal((5, 4, 10))).astype(np.complex64)
     out = W.wpe(fnt, taps=5, delay=1, context=0, num_iters=1)
     assert out.shape == fnt.shape and np.all(np.isfinite(out))
+    # ... and says so: SETK_NUM_RANKDEF in the status words (a note, not an error), a warning
+    # in the log (the divergence from numpy.linalg.solve used to be silent)
+    import logging
+    from setk_amd import _ffi
+    spec = np.ascontiguousarray(np.transpose(fnt, (1, 2, 0)))
+    st = np.zeros(5, dtype=np.int32)
+    _ffi.default_context().wpe(spec, 4, 10, 5, 5, 1, 0, 1, np.empty_like(spec), status=st)
+    assert (st == _ffi.NUM_RANKDEF).all() and not _ffi.wpe_failed(st).any()
+    full = (rng.standard_normal((5, 2, 200)) + 1j * rng.standard_normal((5, 2, 200))).astype(np.complex64)
+    spec = np.ascontiguousarray(np.transpose(full, (1, 2, 0)))
+    _ffi.default_context().wpe(spec, 2, 200, 5, 3, 1, 0, 1, np.empty_like(spec), status=st)
+    assert (st == 0).all()
+    records = []
+    h = logging.Handler()
+    h.emit = records.append
+    logging.getLogger("setk_amd.libs.wpe").addHandler(h)
+    try:
+        W.wpe(fnt, taps=5, delay=1, context=0, num_iters=1)
+    finally:
+        logging.getLogger("setk_amd.libs.wpe").removeHandler(h)
+    assert any("rank-deficient" in r.getMessage() for r in records)
     for seed, (C, T, taps) in enumerate([(4, 10, 5), (4, 16, 6), (2, 9, 12), (8, 30, 10), (6, 7, 3)]):
         rng = np.random.default_rng(200 + seed)
         fnt = (rng.standard_normal((64, C, T)) + 1j * rng.standard_normal((64, C, T))).astype(np.complex64)
