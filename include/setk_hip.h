@@ -100,6 +100,11 @@ int setk_create(setk_handle_t* out, int device_ordinal);
 int setk_destroy(setk_handle_t h);
 /* text of the last error on this handle (never NULL) */
 const char* setk_last_error(setk_handle_t h);
+/* PCI bus id of the handle's device ("0000:c1:00.0", NUL terminated, into out[len]): what a
+ * host needs to place its reader threads and pinned staging on the GPU's NUMA node
+ * (/sys/bus/pci/devices/<id>/numa_node; setk_amd/numa.py, --numa auto).  The reference has no
+ * such notion: its processes are CPU only (scripts/run_adapt_beamformer.sh:69-92). */
+int setk_device_pci_bus_id(setk_handle_t h, char* out, int len);
 
 /* ---- host-memory plumbing (used by the streaming host pipeline) -----------
  * Pin an existing host range (e.g. the mmap of a wave file in the page cache) so
@@ -249,6 +254,18 @@ int setk_beamform(setk_handle_t h, const float* weight, const float* spec,
 int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int num_frames,
                     int num_bins, int num_iters, const float* init_mask, float* gamma_out,
                     float* mask_out, int flags, void* stream);
+
+/* The general form: num_classes K in [2, 4], 1 <= C <= 16 channels -- CgmmTrainer with
+ * num_classes != 2 (cluster.py:427-434), and the K = 2 starts for arrays wider than 8.
+ * gamma0[K][F][T] float64 (host or device) is the start: for K > 2 the reference's
+ * np.random.uniform(size=[K, F, T]) / sum over K, drawn from the legacy global generator that
+ * estimate_cgmm_masks.py:28 seeds with --seed (the caller draws it: setk_amd/libs/cluster.py);
+ * NULL with K = 2 selects init_mask[T][F] or the deterministic start as in setk_cgmm_masks.
+ * gamma_out[K][T][F] float32 receives every class's posteriors.  float64 throughout, like
+ * the reference; a straightforward kernel (cgmm_k.hip), not the tuned K = 2 path. */
+int setk_cgmm_masks_k(setk_handle_t h, const float* spec, int num_channels, int num_frames,
+                      int num_bins, int num_classes, int num_iters, const double* gamma0,
+                      const float* init_mask, float* gamma_out, int flags, void* stream);
 
 /* Batched form: n_utts utterances per EM stage launch (device pointers only;
  * spec[u] = [C][num_frames[u]][spec_pitch] (0 = F), mask_out[u] = [num_frames[u]][F],

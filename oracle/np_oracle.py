@@ -590,12 +590,27 @@ def cgmm_masks(stft_mat, num_iters=20, init_mask=None):
     return np.transpose(gamma, (0, 2, 1))[0].astype(np.float32)
 
 
-def cgmm_gamma(stft_mat, num_iters=20, init_mask=None, update_alpha=False):
-    """CgmmTrainer(stft_mat, 2, update_alpha=...).train(num_iters): posteriors
-    K x F x T (float64).  update_alpha: Cgmm.update, libs/cluster.py:246-257."""
+def cgmm_gamma(stft_mat, num_iters=20, init_mask=None, update_alpha=False, num_classes=2, seed=None,
+               gamma0=None):
+    """CgmmTrainer(stft_mat, num_classes, update_alpha=...).train(num_iters): posteriors
+    K x F x T (float64).  update_alpha: Cgmm.update, libs/cluster.py:246-257.
+    num_classes != 2: the random start of libs/cluster.py:427-434 -- np.random.uniform from
+    the legacy GLOBAL generator, which estimate_cgmm_masks.py:28 seeds once per run; `seed`
+    re-seeds it here (None: whatever state the generator is in, as for the second utterance
+    of a run), `gamma0` K x F x T passes a start in directly."""
     obs = np.einsum("mft->fmt", stft_mat)
     F, M, T = obs.shape
-    if init_mask is None:  # libs/cluster.py:419-425
+    K = int(num_classes)
+    if K != 2 or gamma0 is not None:
+        if gamma0 is None:
+            if seed is not None:
+                np.random.seed(seed)
+            gamma0 = np.random.uniform(size=[K, F, T])
+            gamma0 = gamma0 / np.sum(gamma0, 0, keepdims=True)
+        gamma = np.asarray(gamma0, dtype=np.float64)
+        den = np.maximum(np.sum(gamma, axis=-1, keepdims=True), EPSILON)
+        R = np.einsum("...t,...xt,...yt->...xy", gamma, obs, obs.conj()) / den[..., None]
+    elif init_mask is None:  # libs/cluster.py:419-425
         Rs = np.einsum("...dt,...et->...de", obs, obs.conj()) / T
         Rn = np.stack([np.eye(M, M, dtype=complex) for _ in range(F)])
         R = np.stack([Rs, Rn])
@@ -607,7 +622,7 @@ def cgmm_gamma(stft_mat, num_iters=20, init_mask=None, update_alpha=False):
     cov = _Covariance(R)
     phi = np.einsum("...xt,...xy,...yt->...t", obs.conj(), cov.inv(), obs)
     phi = np.maximum(np.abs(phi), EPSILON) / M
-    alpha = np.ones([2, F]) / 2
+    alpha = np.ones([K, F]) / K
 
     def predict(cov, phi):  # libs/cluster.py:261-287, 214-235
         log_pdf = -M * np.log(phi) - cov.logdet()

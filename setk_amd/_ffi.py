@@ -89,7 +89,7 @@ def import_torch(what="this path"):
 def exported_symbols():
     """Names declared in include/setk_hip.h (checked by the CPU test-suite)."""
     return [
-        "setk_abi_version", "setk_create", "setk_destroy", "setk_last_error",
+        "setk_abi_version", "setk_create", "setk_destroy", "setk_last_error", "setk_device_pci_bus_id",
         "setk_memcpy_d2h_async", "setk_device_alloc", "setk_device_free", "setk_host_alloc",
         "setk_host_free", "setk_stream_create", "setk_stream_destroy", "setk_stream_synchronize",
         "setk_stream_wait_event", "setk_event_create", "setk_event_destroy", "setk_event_record",
@@ -97,7 +97,7 @@ def exported_symbols():
         "setk_host_register", "setk_host_unregister", "setk_memcpy_h2d_async",
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_stft_batch", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
-        "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_float_to_pcm16", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks",
+        "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_float_to_pcm16", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks", "setk_cgmm_masks_k",
         "setk_cgmm_masks_batch", "setk_cgmm_estimate_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
         "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_wpe_batch", "setk_wpe_batch_fnt", "setk_set_profiling",
@@ -132,6 +132,8 @@ def load_library():
     lib.setk_destroy.argtypes = [H]
     lib.setk_last_error.argtypes = [H]
     lib.setk_last_error.restype = c_char_p
+    lib.setk_device_pci_bus_id.argtypes = [H, ctypes.c_char_p, c_int]
+    lib.setk_device_pci_bus_id.restype = c_int
     lib.setk_host_register.argtypes = [H, c_void_p, ctypes.c_size_t]
     lib.setk_host_unregister.argtypes = [H, c_void_p]
     lib.setk_memcpy_h2d_async.argtypes = [H, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]
@@ -166,6 +168,7 @@ def load_library():
     lib.setk_rank1.argtypes = [H, fp, fp, c_int, c_int, fp, fp, c_void_p]
     lib.setk_beamform.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, c_void_p]
     lib.setk_cgmm_masks.argtypes = [H, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, c_void_p]
+    lib.setk_cgmm_masks_k.argtypes = [H, fp, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, c_void_p]
     lib.setk_cgmm_masks_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int), c_int,
                                           c_int, POINTER(c_void_p), POINTER(c_void_p), c_int,
                                           c_int, c_void_p]
@@ -456,6 +459,17 @@ class Context:
                                       _ptr(init_mask), _ptr(gamma_out), _ptr(mask_out),
                                       CGMM_UPDATE_ALPHA if update_alpha else 0,
                                       current_stream_ptr() if stream is None else stream))
+
+    def cgmm_masks_k(self, spec, C, T, F, K, num_iters, gamma0, init_mask, gamma_out, stream=None,
+                     update_alpha=False):
+        """General CGMM (K <= 4 classes, C <= 16 channels): spec [C][T][F] complex64, gamma0
+        [K][F][T] float64 or None (K = 2: init_mask [T][F] or the deterministic start),
+        gamma_out [K][T][F] float32."""
+        self.check(
+            self._lib.setk_cgmm_masks_k(self._h, _ptr(spec), int(C), int(T), int(F), int(K),
+                                        int(num_iters), _ptr(gamma0), _ptr(init_mask), _ptr(gamma_out),
+                                        CGMM_UPDATE_ALPHA if update_alpha else 0,
+                                        current_stream_ptr() if stream is None else stream))
 
     def cgmm_masks_batch(self, C, spec_ptrs, num_frames, F, num_iters, init_ptrs, out_ptrs,
                          stream=None, update_alpha=False, spec_pitch=0):

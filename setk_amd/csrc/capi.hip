@@ -375,6 +375,12 @@ int setk_destroy(setk_handle_t h) {
 
 const char* setk_last_error(setk_handle_t h) { return h ? h->err.c_str() : "null handle"; }
 
+int setk_device_pci_bus_id(setk_handle_t h, char* out, int len) {
+    if (!h || !out || len < 13) return SETK_ERR_INVALID;
+    HIP_TRY(h, hipDeviceGetPCIBusId(out, len, h->device));
+    return SETK_OK;
+}
+
 int setk_set_profiling(setk_handle_t h, int enable) {
     if (!h) return SETK_ERR_INVALID;
     h->profiling = enable != 0;
@@ -1522,6 +1528,41 @@ int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int nu
         if (rc) return rc;
     }
     if (om.host || (gamma_out && og.host)) HIP_TRY(h, hipStreamSynchronize(s));
+    return SETK_OK;
+}
+
+int setk_cgmm_masks_k(setk_handle_t h, const float* spec, int num_channels, int num_frames,
+                      int num_bins, int num_classes, int num_iters, const double* gamma0,
+                      const float* init_mask, float* gamma_out, int flags, void* stream) {
+    if (!h || !spec || !gamma_out || num_frames <= 0 || num_bins <= 0 || num_iters < 0)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    const int C = num_channels, T = num_frames, F = num_bins, K = num_classes;
+    if (!cgmm_k_supported(C, K))
+        return fail(h, SETK_ERR_UNSUPPORTED, "general CGMM: 1 <= num_channels <= 16, 2 <= num_classes <= 4");
+    if (K != 2 && !gamma0) return fail(h, SETK_ERR_INVALID, "num_classes > 2 needs the start gamma0");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h, s);
+    const float *d_spec, *d_init = nullptr, *d_g0f = nullptr;
+    int rc = stage_in(h, spec, (size_t)C * T * F * 2, s, &d_spec);
+    if (rc) return rc;
+    if (gamma0) {  // (stage_in counts floats: a double is two)
+        rc = stage_in(h, reinterpret_cast<const float*>(gamma0), (size_t)K * F * T * 2, s, &d_g0f);
+        if (rc) return rc;
+    } else if (init_mask) {
+        rc = stage_in(h, init_mask, (size_t)T * F, s, &d_init);
+        if (rc) return rc;
+    }
+    OutBuf og;
+    rc = stage_out(h, gamma_out, (size_t)K * T * F * 4, &og);
+    if (rc) return rc;
+    double* d_work = static_cast<double*>(arena_alloc(h, cgmm_k_work_bytes(K, T, F)));
+    if (!d_work) return fail(h, SETK_ERR_NOMEM, "arena");
+    HIP_TRY(h, launch_cgmm_k(d_spec, reinterpret_cast<const double*>(d_g0f), d_init, static_cast<float*>(og.dev),
+                             d_work, C, T, F, K, num_iters, (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0, s));
+    rc = copy_back(h, og, s);
+    if (rc) return rc;
+    if (og.host) HIP_TRY(h, hipStreamSynchronize(s));
     return SETK_OK;
 }
 

@@ -182,6 +182,12 @@ size_t cgmm_args_bytes();
 size_t cgmm_scratch_bytes(int C, int T, int F);
 hipError_t launch_cgmm_batch(int C, const void* d_tbl, int n_utts, int F, int max_frames,
                              int num_iters, hipStream_t s);
+// general EM: any number of classes (<= 4), up to 16 channels (cgmm_k.hip)
+size_t cgmm_k_work_bytes(int K, int T, int F);
+bool cgmm_k_supported(int C, int K);
+hipError_t launch_cgmm_k(const float* spec, const double* gamma0, const float* init_mask, float* gamma_out,
+                         double* work, int C, int T, int F, int K, int num_iters, int update_alpha,
+                         hipStream_t s);
 // bin-resident EM (cgmm_bin.hip)
 size_t cgmm_bin_args_bytes();
 int cgmm_bin_pitch(int T);

@@ -1,16 +1,22 @@
 """
-Mirror of the CGMM part of scripts/sptk/libs/cluster.py (CgmmTrainer,
-:396-465) for the configuration estimate_cgmm_masks.py uses by default:
-K = 2 classes, alpha fixed at 1/2 or re-estimated (update_alpha), deterministic
-start or an initial mask.
-The EM iterations run in libsetk_hip.so (setk_cgmm_masks, csrc/cgmm.hip).
+Mirror of the CGMM part of scripts/sptk/libs/cluster.py (CgmmTrainer, :396-465): K = 2
+classes with the deterministic start or an initial mask (what estimate_cgmm_masks.py uses by
+default: the tuned kernels of csrc/cgmm_bin.hip / cgmm.hip behind setk_cgmm_masks), and
+num_classes 3 or 4 with the reference's random start (csrc/cgmm_k.hip behind
+setk_cgmm_masks_k, which also serves K = 2 on arrays of 9 - 16 channels); alpha fixed at 1 / K
+or re-estimated (update_alpha).  The EM iterations run in libsetk_hip.so.
+
+The K > 2 start is the reference's (cluster.py:429-434): gamma = np.random.uniform(size=[K, F,
+T]) normalised over K, drawn from numpy's legacy GLOBAL generator -- which
+estimate_cgmm_masks.py:28 seeds with --seed (777) once per run -- so the draw is made here,
+on the host, from that same generator, in the same order (one draw per utterance): a run with
+the same seed and the same table starts every utterance exactly as the reference does.
 
 permu_aligner (:48-91, --solve-permu) is host post-processing of the K x T x F
 posteriors, as in the reference: a per-bin assignment of classes to the running
 centroids of overlapping bands (a few milliseconds of numpy per utterance).
 
-Not mirrored (out of this path's scope): K > 2 (the device EM keeps two
-classes' accumulators in registers), CACGMM.
+Not mirrored (out of this path's scope): CACGMM, resuming from a pickled model.
 """
 import numpy as np
 
@@ -27,29 +33,48 @@ class CgmmTrainer(object):
     train(num_iters) -> posteriors K x F x T (float64 like the reference)."""
 
     def __init__(self, obs, num_classes, gamma=None, cgmm=None, update_alpha=False):
-        if num_classes != 2:
-            raise _ffi.SetkUnsupported("the device CGMM implements num_classes = 2")
+        if not 2 <= int(num_classes) <= 4:
+            raise _ffi.SetkUnsupported(f"the device CGMM implements 2 <= num_classes <= 4, got {num_classes}")
         if cgmm is not None:
             raise _ffi.SetkUnsupported("resuming from a pickled cgmm model is not implemented")
         self.update_alpha = bool(update_alpha)
+        self.num_classes = int(num_classes)
         M, F, T = obs.shape
         logger.info(f"CGMM instance: F = {F:d}, T = {T:}, M = {M}")
         self.shape = (M, F, T)
         self.spec = np.ascontiguousarray(np.transpose(obs, (0, 2, 1)), dtype=np.complex64)
-        self.init = None
-        if gamma is not None:
-            gamma = np.asarray(gamma)
-            if gamma.shape != (F, T):
-                raise ValueError(f"initial mask must be F x T, got {gamma.shape}")
-            self.init = np.ascontiguousarray(gamma.T, dtype=np.float32)
+        self.init = None    # K = 2: initial speech mask T x F
+        self.gamma0 = None  # full start K x F x T (float64)
+        if self.num_classes == 2:
+            if gamma is not None:
+                gamma = np.asarray(gamma)
+                if gamma.shape != (F, T):
+                    raise ValueError(f"initial mask must be F x T, got {gamma.shape}")
+                self.init = np.ascontiguousarray(gamma.T, dtype=np.float32)
+        elif gamma is not None:
+            gamma = np.asarray(gamma, dtype=np.float64)
+            if gamma.shape != (self.num_classes, F, T):
+                raise ValueError(f"initial gamma must be K x F x T, got {gamma.shape}")
+            self.gamma0 = np.ascontiguousarray(gamma)
+        else:
+            # cluster.py:429-434, from numpy's legacy global generator (seeded by the CLI)
+            g = np.random.uniform(size=[self.num_classes, F, T])
+            self.gamma0 = np.ascontiguousarray(g / np.sum(g, 0, keepdims=True))
+            logger.info(f"Random initialized, num_classes = {self.num_classes}")
         self.gamma = None
 
     def train(self, num_iters):
         M, F, T = self.shape
-        gamma = np.empty((2, T, F), dtype=np.float32)
-        mask = np.empty((T, F), dtype=np.float32)
-        _ffi.default_context().cgmm_masks(self.spec, M, T, F, num_iters, self.init, gamma, mask,
-                                          update_alpha=self.update_alpha)
+        K = self.num_classes
+        ctx = _ffi.default_context()
+        gamma = np.empty((K, T, F), dtype=np.float32)
+        if K == 2 and M <= 8:
+            mask = np.empty((T, F), dtype=np.float32)
+            ctx.cgmm_masks(self.spec, M, T, F, num_iters, self.init, gamma, mask,
+                           update_alpha=self.update_alpha)
+        else:
+            ctx.cgmm_masks_k(self.spec, M, T, F, K, num_iters, self.gamma0, self.init, gamma,
+                             update_alpha=self.update_alpha)
         self.gamma = np.transpose(gamma, (0, 2, 1)).astype(np.float64)
         return self.gamma
 

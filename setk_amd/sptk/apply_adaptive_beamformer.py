@@ -85,6 +85,9 @@ _OPTIONS = (
                                  help="[setk_amd] batches in flight in the host pipeline")),
     (("--read-threads",), dict(default=0, type=int,
                                help="[setk_amd] file reader threads (0: half the cores, <= 12)")),
+    (("--numa",), dict(default="auto", type=str,
+                       help="[setk_amd] host placement: auto = reader / writer threads and the pinned "
+                            "staging on the NUMA node of this rank's GPU; off; or a node number")),
     (("--skip-existing",), dict(default=False, type=lambda v: str(v).lower() in ("true", "1", "yes"),
                                 help="[setk_amd] resume: utterances whose {dst_dir}/{key}.wav already "
                                      "exists (non-empty) are not enhanced again")),
@@ -249,9 +252,15 @@ def run_offline(args, shard):
                            ban=bool(args.ban), pmwf_ref=args.pmwf_ref,
                            rank1_appro=args.rank1_appro, post_mask=bool(args.mask),
                            vad_proportion=args.vad_proportion, pcm16=True, device=device)
+    # before any thread pool or pinned slab exists: they inherit the placement
+    from setk_amd import numa
+    placement = numa.bind(engine.ctx, getattr(args, "numa", "auto"))
+    if placement.get("bound"):
+        logger.info(f"rank {shard.rank}: bound to NUMA node {placement['node']} "
+                    f"({placement['cpus']} CPUs, GPU {placement.get('pci_bus_id')})")
     keys = _drop_existing(args, shard.assign_by_duration(wav_reader))
     summary = dict(mode="batch", utts=0, rank=shard.rank, world=shard.world,
-                   assigned_samples=shard.assigned_weight)
+                   assigned_samples=shard.assigned_weight, numa=placement)
     num_done = 0
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
         if _fast_path_ok(args):

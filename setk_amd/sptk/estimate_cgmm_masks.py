@@ -4,9 +4,11 @@ Speech / noise mask estimation with the CGMM model on the MI355X.
 
 Drop-in for funcwj/setk ``scripts/sptk/estimate_cgmm_masks.py`` (same
 positional arguments, options, defaults, outputs {dst_dir}/{key}.npy float32
-T x F, skip-if-exists behaviour :38).  --num-classes other than 2 is outside the
-implemented path; --solve-permu aligns the two classes over frequency on the host
-(libs/cluster.permu_aligner) and takes the one-utterance-at-a-time path.
+T x F, skip-if-exists behaviour :38).  --num-classes 2 runs the tuned batch kernels;
+3 and 4 start from the reference's seeded random posteriors (--seed, drawn on the host from
+numpy's legacy generator exactly as the reference does) and run the general device EM
+(csrc/cgmm_k.hip); --solve-permu aligns the classes over frequency on the host
+(libs/cluster.permu_aligner); both take the one-utterance-at-a-time path.
 """
 import argparse
 from pathlib import Path
@@ -48,15 +50,17 @@ def build_parser():
 
 
 def run(args):
-    if args.num_classes != 2:
-        raise _ffi.SetkUnsupported("only --num-classes 2 (the reference draws the K > 2 start "
-                                   "from numpy's unseeded generator)")
+    # estimate_cgmm_masks.py:28 of the reference: the K > 2 start is drawn from numpy's legacy
+    # global generator, seeded once per run
+    np.random.seed(args.seed)
+    if not 2 <= args.num_classes <= 4:
+        raise _ffi.SetkUnsupported(f"--num-classes {args.num_classes}: the device EM implements 2 .. 4")
     stft_kwargs = dict(frame_len=args.frame_len, frame_hop=args.frame_hop,
                        round_power_of_two=args.round_power_of_two, window=args.window,
                        center=args.center, transpose=False)
     shard = Shard()
     n_fft = 2**int(np.ceil(np.log2(args.frame_len))) if args.round_power_of_two else args.frame_len
-    if n_fft == 512 and not args.init_mask and not args.solve_permu:
+    if n_fft == 512 and not args.init_mask and not args.solve_permu and args.num_classes == 2:
         return run_batched(args, shard)
     reader = SpectrogramReader(args.wav_scp, **stft_kwargs)
     MaskReader = {"numpy": NumpyReader, "kaldi": ScriptReader}

@@ -288,6 +288,24 @@ def test_cgmm_update_alpha_equals_live_reference():
         assert np.max(np.abs(o.cgmm_gamma(obs, 5, update_alpha=ua) - ref)) < 1e-9
 
 
+@pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+def test_cgmm_three_classes_seeded_start_equals_live_reference():
+    """num_classes != 2: the reference starts from np.random.uniform(size=[K, F, T]) of the legacy
+    GLOBAL generator, which its CLI seeds with --seed (estimate_cgmm_masks.py:28, 95-98) -- a
+    reproducible start (the round-3 text called it unseeded: wrong).  The oracle draws from the
+    same generator in the same order: first utterance after the seed, then the second."""
+    libs = rh.load()
+    obs1 = o.multichannel_stft(o.synth_utterance(62, 4, 9000), transpose=False, **STFT_KW)
+    obs2 = o.multichannel_stft(o.synth_utterance(63, 4, 7000), transpose=False, **STFT_KW)
+    np.random.seed(777)
+    ref1 = libs.cluster.CgmmTrainer(obs1, 3).train(4)
+    ref2 = libs.cluster.CgmmTrainer(obs2, 3, update_alpha=True).train(4)
+    got1 = o.cgmm_gamma(obs1, 4, num_classes=3, seed=777)
+    got2 = o.cgmm_gamma(obs2, 4, num_classes=3, update_alpha=True)  # generator state carried over
+    assert ref1.shape == got1.shape == (3,) + obs1.shape[1:]
+    assert np.max(np.abs(got1 - ref1)) < 1e-9 and np.max(np.abs(got2 - ref2)) < 1e-9
+
+
 CLASSIC_RUNS = {
     "ds.circular": dict(kind="ds", geometry="circular", doa=77.5, num_arounded=4),
     "sd.circular.norm": dict(kind="sd", geometry="circular", doa=200.0, num_arounded=4, normalize=True),
