@@ -319,9 +319,12 @@ int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
  * float32 [T][F] array: passed to setk_covar as the mask it yields the
  * power-weighted covariance of facted_wpd (:160-162, up to a per-bin scale that
  * cancels in the MVDR weight).  status[F] (may be NULL) receives SETK_NUM_*;
- * SETK_NUM_SINGULAR is numpy's LinAlgError.  Limits: channels <= 16, channels * taps <= 96
- * and the LDS-resident correlation (NK^2 + NK N + 16 (NK + N) complex128 <= 160 KB:
- * 8 channels x 10 taps, 16 x 4); beyond them SETK_ERR_UNSUPPORTED names the bound. */
+ * SETK_NUM_SINGULAR is numpy's LinAlgError, SETK_NUM_RANKDEF a note (columns at the noise
+ * level were dropped; the result is finite).  Limits: channels <= 16, NK = channels * taps
+ * <= 256.  While R fits LDS (NK^2 + NK N + 16 (NK + N) complex128 <= 160 KB: up to 8
+ * channels x 10 taps, 16 x 4) a workgroup never leaves its CU; beyond that (8 x 12, 16 x 6,
+ * 16 x 10 ...) R is factored in global scratch of the handle's arena (NK^2 complex128 per
+ * bin and utterance in flight).  NK > 256: SETK_ERR_UNSUPPORTED names the bound. */
 int setk_wpe(setk_handle_t h, const float* spec, int num_channels, int num_frames,
              int num_bins, int taps, int delay, int context, int num_iters,
              const float* lambda_enh, float* out, float* inv_lambda_out,

@@ -1757,6 +1757,16 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
         d_timing = static_cast<long long*>(arena_alloc(h, (size_t)n_utts * F * 4 * sizeof(long long)));
         if (!d_timing) return fail(h, SETK_ERR_NOMEM, "arena");
     }
+    // channels x taps beyond LDS: R in global scratch, [F][NK][NK] complex128 per utterance of a
+    // launch; the launches of an iteration then cover as many utterances as ~2 GB of it hold
+    const size_t wide_utt = wpe_wide_bytes_per_bin(C, taps) * (size_t)F;
+    int per_launch = n_utts;
+    char* d_rwork = nullptr;
+    if (wide_utt) {
+        per_launch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_utts, ((size_t)2 << 30) / wide_utt));
+        d_rwork = static_cast<char*>(arena_alloc(h, wide_utt * per_launch));
+        if (!d_rwork) return fail(h, SETK_ERR_NOMEM, "arena");
+    }
     for (int it = 0; it < num_iters; ++it) {
         for (int u = 0; u < n_utts; ++u) {
             Utt& q = us[u];
@@ -1771,12 +1781,15 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
                 HIP_TRY(h, launch_wpe_lambda(cur, C, q.T, F, context, q.lam, s));
             wpe_fill_args(tbl.data() + (size_t)u * ab, q.x_fct, q.lam, q.bufs[it & 1],
                           d_st + ((size_t)it * n_utts + u) * F, C, q.T, taps, delay,
-                          d_timing ? d_timing + (size_t)u * F * 4 : nullptr);
+                          d_timing ? d_timing + (size_t)u * F * 4 : nullptr,
+                          d_rwork ? d_rwork + wide_utt * (size_t)(u % per_launch) : nullptr);
         }
         void* d_tbl;
         rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
         if (rc) return rc;
-        HIP_TRY(h, launch_wpe_step_batch(d_tbl, n_utts, C, F, taps, s));
+        for (int u0 = 0; u0 < n_utts; u0 += per_launch)
+            HIP_TRY(h, launch_wpe_step_batch(static_cast<char*>(d_tbl) + (size_t)u0 * ab,
+                                             std::min(per_launch, n_utts - u0), C, F, taps, s));
     }
     for (int u = 0; u < n_utts; ++u) {
         Utt& q = us[u];

@@ -227,7 +227,10 @@ hipError_t launch_wpe_lambda_from_enh(const float* enh_tf, int T, int F, double*
 hipError_t launch_wpe_inv_lambda(const double* lam, int T, int F, float* out, hipStream_t s);
 size_t wpe_args_bytes();
 void wpe_fill_args(void* dst, const float* x_fct, const double* lam, float* out_fct, int* status,
-                   int N, int T, int taps, int delay, long long* timing = nullptr);
+                   int N, int T, int taps, int delay, long long* timing = nullptr,
+                   void* rwork = nullptr);
+// bytes of global scratch per (utterance, bin) when channels x taps does not fit LDS, else 0
+size_t wpe_wide_bytes_per_bin(int N, int taps);
 hipError_t launch_wpe_step_batch(const void* d_tbl, int n_utts, int N, int F, int taps,
                                  hipStream_t s);
 

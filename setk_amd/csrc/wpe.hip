@@ -41,8 +41,10 @@ WD void zfmac(zd& acc, zd a, zd b) {
     acc.y = fma(a.y, b.x, fma(-a.x, b.y, acc.y));
 }
 
-constexpr int kWpeMaxNK = 96;  // LDS: NK^2 * 16 B <= 147 KB
-constexpr int kWpeTC = 16;     // smallest chunk of frames staged at a time
+constexpr int kWpeMaxNK = 96;       // R in LDS: NK^2 * 16 B <= 147 KB
+constexpr int kWpeMaxNKWide = 256;  // R in global memory (the reference has no bound: libs/wpe.py:58-81)
+constexpr int kWpeTC = 16;          // smallest chunk of frames staged at a time
+constexpr int kWpeWideNTW = 12;     // tiles per wavefront and correlation pass of the wide form
 
 // [C][T][F] (the library's spectrogram layout) <-> [F][C][T]
 __global__ __launch_bounds__(256) void wpe_to_fct_kernel(const float2* __restrict__ spec, int C,
@@ -132,6 +134,7 @@ struct WpeArgs {
     float2* out;        // [F][N][T]
     int* status;        // [F]
     long long* timing;  // SETK_WPE_TIMING: [F][4] cycles (correlation, factor, back-solve, filter)
+    double2* rwork;     // wide form only: [F][NK][NK] complex128, this utterance's R / L
     int N, T, taps, delay;
 };
 
@@ -151,7 +154,11 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // rows and its neighbour the other column part, one lane swap away.  Only the tiles J <= I of R
 // are computed; the NT = RT (RT + 1) / 2 + RT XT tiles (RT = ceil(NK / 8), XT = ceil(N / 8)) are
 // dealt round-robin to the four wavefronts, NTW = ceil(NT / 4) accumulators each.
-template <int NTW>
+//
+// WIDE (channels x taps beyond what LDS holds, up to 16 x 16): R lives in global memory
+// (NK^2 complex128 per workgroup, L2 / MALL resident while it is factored), the correlation
+// walks the frames once per group of 4 NTW tiles, everything else is the same code.
+template <int NTW, bool WIDE>
 __global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict__ tbl, int TC) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     const WpeArgs a = tbl[blockIdx.y];
@@ -162,8 +169,9 @@ __global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict
     // - k of channel n), the chunk's own frames x[n][t0 .. t0 + TC) for r, and a strip of zeros
     // that the rows / columns past NK (partial tiles) and the channels past N point at
     const int W = TC + taps - 1;
-    zd* R = reinterpret_cast<zd*>(wsm);          // [NK][NK] row major; L in place (strictly lower)
-    zd* G = R + (size_t)NK * NK;                 // [NK][N]  r, then y, then G
+    // R: [NK][NK] row major; L in place (strictly lower).  G: [NK][N]  r, then y, then G
+    zd* R = WIDE ? a.rwork + (size_t)blockIdx.x * NK * NK : reinterpret_cast<zd*>(wsm);
+    zd* G = WIDE ? reinterpret_cast<zd*>(wsm) : reinterpret_cast<zd*>(wsm) + (size_t)NK * NK;
     zd* XS = G + (size_t)NK * N;                 // [N][W] | [N][TC] | zeros [TC]
     double* ilam = reinterpret_cast<double*>(XS + (size_t)N * (W + TC) + TC);  // [TC]
     double* idiag = ilam + TC;                   // [NK] 1 / L[k][k]
@@ -187,12 +195,15 @@ __global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict
     // row, frame lane / 16 of the step; B = column (n, q)
     const int ai = lane & 15, ag = ai & 3, av = ai >> 2;
     const int kq = lane >> 4;
+    for (int i = tid; i < TC; i += 256) XS[zoff + i] = zmk(0.0, 0.0);
+    // (one trip unless WIDE: the dispatcher picks NTW >= ceil(NTT / 4) for the LDS form)
+    for (int tb = 0; tb < NTT; tb += 4 * NTW) {
     v4d acc[NTW];
     int baseA[NTW], baseB[NTW];
 #pragma unroll
     for (int q = 0; q < NTW; ++q) {
         acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-        const int t = wv + 4 * q;
+        const int t = tb + wv + 4 * q;
         int I = 0, J = 0;
         bool isx = false;
         if (t < NTR) {
@@ -211,7 +222,6 @@ __global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict
         baseA[q] = 2 * (ea + kq) + (av & 1);
         baseB[q] = 2 * (eb + kq) + (ai & 1);
     }
-    for (int i = tid; i < TC; i += 256) XS[zoff + i] = zmk(0.0, 0.0);
     for (int t0 = 0; t0 < T; t0 += TC) {
         __syncthreads();
         for (int i = tid; i < N * (W + TC); i += 256) {
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict
     // part 1
 #pragma unroll
     for (int q = 0; q < NTW; ++q) {
-        const int t = wv + 4 * q;
+        const int t = tb + wv + 4 * q;
         double nb[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) nb[v] = __shfl_xor(acc[q][v], 1);
@@ -274,6 +284,7 @@ __global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict
             }
         }
     }
+    }  // tile groups
     __syncthreads();
 
     // ---- Cholesky R = L L^H (strictly lower triangle in place, 1 / L[k][k] aside), right-
@@ -342,31 +353,35 @@ __global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict
     // ---- L^H G = y: one wavefront per right-hand side, y in registers (rows lane and
     // lane + 64), no workgroup barrier inside ----
     {
+        constexpr int NY = WIDE ? kWpeMaxNKWide / 64 : 2;
         const int lane = tid & 63, w = tid >> 6;
         for (int c = w; c < N; c += 4) {
-            zd y0 = (lane < NK) ? G[(size_t)lane * N + c] : zmk(0.0, 0.0);
-            zd y1 = (lane + 64 < NK) ? G[(size_t)(lane + 64) * N + c] : zmk(0.0, 0.0);
+            zd y[NY];
+#pragma unroll
+            for (int j = 0; j < NY; ++j)
+                y[j] = (lane + 64 * j < NK) ? G[(size_t)(lane + 64 * j) * N + c] : zmk(0.0, 0.0);
             for (int k = NK - 1; k >= 0; --k) {
-                const zd src = (k >= 64) ? y1 : y0;
+                zd src = y[0];
+#pragma unroll
+                for (int j = 1; j < NY; ++j)
+                    if ((k >> 6) == j) src = y[j];
                 const double inv = idiag[k];
                 const zd g = zmk(__shfl(src.x, k & 63) * inv, __shfl(src.y, k & 63) * inv);
                 // y[i] -= conj(L[k][i]) g  (i < k);  y[k] = g
-                if (lane < k) {
-                    const zd l = R[(size_t)k * NK + lane];
-                    y0 = zmk(y0.x - (l.x * g.x + l.y * g.y), y0.y - (l.x * g.y - l.y * g.x));
-                } else if (lane == k) {
-                    y0 = g;
-                }
-                if (k > 64) {
-                    if (lane + 64 < k) {
-                        const zd l = R[(size_t)k * NK + lane + 64];
-                        y1 = zmk(y1.x - (l.x * g.x + l.y * g.y), y1.y - (l.x * g.y - l.y * g.x));
+#pragma unroll
+                for (int j = 0; j < NY; ++j) {
+                    const int i = lane + 64 * j;
+                    if (64 * j < k && i < k) {
+                        const zd l = R[(size_t)k * NK + i];
+                        y[j] = zmk(y[j].x - (l.x * g.x + l.y * g.y), y[j].y - (l.x * g.y - l.y * g.x));
+                    } else if (i == k) {
+                        y[j] = g;
                     }
                 }
-                if (lane + 64 == k) y1 = g;
             }
-            if (lane < NK) G[(size_t)lane * N + c] = y0;
-            if (lane + 64 < NK) G[(size_t)(lane + 64) * N + c] = y1;
+#pragma unroll
+            for (int j = 0; j < NY; ++j)
+                if (lane + 64 * j < NK) G[(size_t)(lane + 64 * j) * N + c] = y[j];
         }
     }
     __syncthreads();
@@ -421,9 +436,24 @@ __global__ __launch_bounds__(256) void wpe_step_kernel(const WpeArgs* __restrict
     }
 }
 
+// does R fit LDS next to r and the smallest chunk?
+bool wpe_is_wide(int N, int taps) {
+    const size_t NK = (size_t)N * taps, W = (size_t)kWpeTC + taps - 1;
+    return NK > (size_t)kWpeMaxNK ||
+           (NK * NK + NK * N + N * (W + kWpeTC) + kWpeTC) * sizeof(zd) + (kWpeTC + NK) * sizeof(double) + 16 >
+               160 * 1024;
+}
+
 size_t wpe_lds_bytes_tc(int N, int taps, int TC) {
     const size_t NK = (size_t)N * taps, W = (size_t)TC + taps - 1;
-    return (NK * NK + NK * N + N * (W + TC) + TC) * sizeof(zd) + (TC + NK) * sizeof(double) + 16;
+    const size_t r = wpe_is_wide(N, taps) ? 0 : NK * NK;
+    return (r + NK * N + N * (W + TC) + TC) * sizeof(zd) + (TC + NK) * sizeof(double) + 16;
+}
+
+// bytes of global scratch one utterance needs per bin (0: R is LDS resident)
+size_t wpe_wide_bytes_per_bin(int N, int taps) {
+    const size_t NK = (size_t)N * taps;
+    return wpe_is_wide(N, taps) ? NK * NK * sizeof(zd) : 0;
 }
 
 // frames per staged chunk: the largest of 64 / 32 / 16 that leaves R, r and the chunk in
@@ -438,20 +468,19 @@ size_t wpe_lds_bytes(int N, int taps) { return wpe_lds_bytes_tc(N, taps, wpe_chu
 
 bool wpe_supported(int N, int taps) {
     const int NK = N * taps;
-    return N >= 1 && N <= 16 && taps >= 1 && NK <= kWpeMaxNK &&
+    return N >= 1 && N <= 16 && taps >= 1 && NK <= kWpeMaxNKWide &&
            wpe_lds_bytes(N, taps) <= 160 * 1024;
 }
 
-// what exactly a shape is refused for (the LDS bound is the tighter one from 8 channels up:
-// C = 8 allows 10 taps, C = 16 allows 4)
+// what exactly a shape is refused for (R itself moves to global memory when it does not fit
+// LDS -- 8 channels x 11 taps, 16 x 5 and up; the bound that remains is NK <= 256)
 const char* wpe_limit_message(int N, int taps) {
     static thread_local char buf[256];
     const int NK = N * taps;
     snprintf(buf, sizeof(buf),
-             "WPE on the device needs 1 <= channels <= 16, channels * taps <= %d and "
-             "(NK^2 + NK N + %d (2 N + 1) + N (taps - 1)) complex128 entries <= 160 KB of LDS "
-             "(channels = %d, taps = %d: NK = %d, %zu bytes)",
-             kWpeMaxNK, kWpeTC, N, taps, NK, wpe_lds_bytes(N, taps));
+             "WPE on the device needs 1 <= channels <= 16 and channels * taps <= %d "
+             "(channels = %d, taps = %d: NK = %d)",
+             kWpeMaxNKWide, N, taps, NK);
     return buf;
 }
 
@@ -494,13 +523,14 @@ hipError_t launch_wpe_inv_lambda(const double* lam, int T, int F, float* out, hi
 size_t wpe_args_bytes() { return sizeof(WpeArgs); }
 
 void wpe_fill_args(void* dst, const float* x_fct, const double* lam, float* out_fct, int* status,
-                   int N, int T, int taps, int delay, long long* timing) {
+                   int N, int T, int taps, int delay, long long* timing, void* rwork) {
     WpeArgs a;
     a.x = reinterpret_cast<const float2*>(x_fct);
     a.lam = lam;
     a.out = reinterpret_cast<float2*>(out_fct);
     a.status = status;
     a.timing = timing;
+    a.rwork = static_cast<double2*>(rwork);
     a.N = N;
     a.T = T;
     a.taps = taps;
@@ -515,8 +545,9 @@ hipError_t launch_wpe_step_batch(const void* d_tbl, int n_utts, int N, int F, in
     void (*kern)(const WpeArgs*, int) = nullptr;
     const int RT = (N * taps + 7) / 8, XT = (N + 7) / 8;
     const int ntw = (RT * (RT + 1) / 2 + RT * XT + 3) / 4;  // tiles per wavefront, <= 26
+    if (wpe_is_wide(N, taps)) kern = wpe_step_kernel<kWpeWideNTW, true>;
 #define SETK_WPE_CASE(n) \
-    if (!kern && ntw <= n) kern = wpe_step_kernel<n>
+    if (!kern && ntw <= n) kern = wpe_step_kernel<n, false>
     SETK_WPE_CASE(1);
     SETK_WPE_CASE(2);
     SETK_WPE_CASE(3);

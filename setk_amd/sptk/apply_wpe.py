@@ -32,10 +32,10 @@ def run(args):
     n_fft = 2**int(np.ceil(np.log2(args.frame_len))) if args.round_power_of_two else args.frame_len
     reader = WaveReader(args.wav_scp)  # 16 kHz tables like the reference (SpectrogramReader)
     if n_fft == 512 and shard.world == 1:
-        # the engine brings its own buffers and stream; shapes outside the native step kernel
-        # (channels x taps > 96, R beyond LDS) run through torch and need it imported first
+        # the engine brings its own buffers and stream; more than 8 channels (the unfused STFT
+        # path) run through torch and need it imported first
         nch = next((reader.peek_channels(k) for k in reader.index_keys), None)
-        _ffi.set_torch_free(nch is not None and nch <= 8 and nch * args.taps <= 80)
+        _ffi.set_torch_free(nch is not None and nch <= 8 and nch * args.taps <= 256)
     engine = BatchDereverb(taps=args.taps, delay=args.delay, context=args.context,
                            num_iters=args.num_iters, frame_len=args.frame_len,
                            frame_hop=args.frame_hop, center=bool(args.center),

@@ -352,6 +352,43 @@ def test_bench_contract_single_and_two_ranks():
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
 
 
+def test_bench_eight_ranks_at_the_full_shard_size():
+    """World size 8 without 8 GPUs: `python bench.py --gpus 8` exactly as the driver would
+    start it (default shard: 125 utterances of 8-ch 30 s per rank = BASELINE configs[2]'s 1000
+    over the job), the eight ranks sharing this box's one GPU behind a gloo rendezvous.  The
+    contract's aggregation is what is checked: eight per-rank times, the maximum as the job's,
+    the value = audio of all ranks over it."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    env = dict(os.environ, SETK_BENCH_SHARE_GPU="1", SETK_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--distinct", "2", "--sustain-sec", "0"],
+                       capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["steps"] == 3 and rec["scaling"] == "weak"
+    per = rec["per_rank_ms_per_step"]
+    assert len(per) == 8 and all(v > 0 for v in per)
+    # the job's time is the slowest rank's plus the closing barrier (gloo here: a fraction of a
+    # millisecond over three steps), never less
+    assert max(per) - 1e-3 <= rec["ms_per_step"] <= 1.1 * max(per) + 1.0
+    cfg = rec["config"]
+    assert cfg["utts_per_gpu"] == 125 and cfg["channels"] == 8 and cfg["seconds"] == 30.0
+    assert "1000 at 8 GPUs" in cfg["workload"] and cfg["parallelism"] == "utterance-sharded x8"
+    audio = 8 * 125 * 30.0
+    assert abs(rec["value"] * rec["ms_per_step"] / 1e3 - audio) / audio < 1e-3
+    assert abs(rec["per_gpu_value"] * 8 - rec["value"]) / rec["value"] < 1e-3
+    for k in range(8):
+        assert f"[bench rank {k}/8]" in r.stderr
+    # nothing that belongs to one GPU's record leaks into the multi-rank line
+    for key in ("cpu_baseline", "full_batch", "other_configs", "end_to_end"):
+        assert key not in rec
+
+
 def test_pcm16_device_ingest_is_bit_identical(tmp_path):
     """setk_pcm16_to_float == read_wav's host decode (int16 / 32768, C x N), and the
     batch engine fed with the stored frames returns the samples it returns for

@@ -85,12 +85,41 @@ def test_wpe_batch_equals_single_calls():
         assert wide[k].dtype == np.complex128 and np.array_equal(wide[k], single), k
 
 
-def test_wpe_too_many_taps_is_refused():
+def test_wpe_beyond_256_tap_rows_is_refused():
     from setk_amd import _ffi
     from setk_amd.libs import wpe as W
-    fnt = np.zeros((9, 8, 50), np.complex64)
+    fnt = np.zeros((9, 16, 50), np.complex64)
     with pytest.raises(_ffi.SetkUnsupported):
-        W.wpe(fnt, taps=13)
+        W.wpe(fnt, taps=17)
+
+
+@pytest.mark.parametrize("N,taps", [(8, 12), (16, 6), (16, 10), (8, 11), (16, 16)])
+def test_wpe_wide_shapes_match_the_oracle(N, taps):
+    """Channels x taps whose R does not fit the 160 KB of a CU (the reference has no bound,
+    libs/wpe.py:58-81): R is factored in global memory, everything else is the LDS form's
+    code.  Against the complex128 oracle on reverberant (AR-filtered) data, two iterations,
+    plus the batch entry with a second, shorter utterance."""
+    from oracle import np_oracle as o
+    from setk_amd.libs import wpe as W
+    rng = np.random.default_rng(100 * N + taps)
+    F, T = 6, 60 * taps + 300
+    def scene(T):
+        x = rng.standard_normal((F, N, T)) + 1j * rng.standard_normal((F, N, T))
+        for t in range(4, T):                      # a few reflections per channel
+            x[:, :, t] += 0.5 * x[:, :, t - 3] - 0.3j * np.roll(x[:, :, t - 4], 1, axis=1)
+        return x.astype(np.complex64)
+    rev = scene(T)
+    ref = o.wpe(rev.astype(np.complex128), taps=taps, delay=3, context=1, num_iters=2)
+    got = W.wpe(rev, taps=taps, delay=3, context=1, num_iters=2)
+    err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert err < 1e-4, (N, taps, err)
+    # the filter did something: the result differs from the input by far more than that
+    assert np.linalg.norm(got - rev) / np.linalg.norm(rev) > 1e-2
+    short = scene(T // 2 + 7)
+    outs = W.wpe_batch([rev, short], taps=taps, delay=3, context=1, num_iters=2)
+    assert np.array_equal(outs[0].astype(np.complex128), got)
+    ref2 = o.wpe(short.astype(np.complex128), taps=taps, delay=3, context=1, num_iters=2)
+    assert np.linalg.norm(outs[1] - ref2) / np.linalg.norm(ref2) < 1e-4
 
 
 def test_wpe_singular_is_linalg_error():
