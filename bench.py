@@ -319,7 +319,7 @@ def main():
             del audio, masks, waves
             audio = masks = waves = []
             torch.cuda.empty_cache()
-            out["other_configs"] = other_configs(torch, _ffi, synth, dev)
+            out["other_configs"] = other_configs(torch, _ffi, synth, dev, args if args.pmc else None, rates)
         if world == 1 and args.e2e_utts > 0:
             # free the resident shard first: the CLI leg is its own process
             audio = masks = waves = None
@@ -423,8 +423,9 @@ def power_leg(step, torch, seconds=2.0):
             "how": "rocm-smi --showpower --showclocks polled while the step repeats"}
 
 
-def pmc_leg(args):
-    """Counters of THIS run's workload: three timed steps of the same configuration
+def pmc_leg(args, child=None, kernels=None):
+    """Counters of THIS run's workload (or of `child`, a command line, for the kernels
+    `kernels` = {key: [name fragments]}): three timed steps of the same configuration
     re-run as a child under `rocprofv3 --pmc`, one pass per counter group (counters
     only -- never mixed with API tracing), parsed from the counter_collection csv.
     HBM bytes follow MI355X_MICROARCH.md (HBM section): read = 2 x FETCH_SIZE KB (gfx950
@@ -438,10 +439,11 @@ def pmc_leg(args):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {"error": "rocprofv3 not found"}
-    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "1", "--gpus", "1",
-             "--steps", "3", "--warmup", "1", "--utts", str(args.utts), "--channels", str(args.channels),
-             "--seconds", str(args.seconds), "--beamformer", args.beamformer,
-             "--distinct", str(args.distinct)]
+    kernels = kernels or KERNELS
+    child = child or [sys.executable, os.path.abspath(__file__), "--pmc-child", "1", "--gpus", "1",
+                      "--steps", "3", "--warmup", "1", "--utts", str(args.utts), "--channels", str(args.channels),
+                      "--seconds", str(args.seconds), "--beamformer", args.beamformer,
+                      "--distinct", str(args.distinct)]
     groups = [["FETCH_SIZE"], ["WRITE_SIZE"],
               ["SQ_INSTS_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES",
                "SQ_VALU_MFMA_COEXEC_CYCLES"]]
@@ -460,7 +462,7 @@ def pmc_leg(args):
                                  + (r.stderr or r.stdout)[-300:]}
             for fn in files:
                 for row in csv.DictReader(open(fn)):
-                    for key, knames in KERNELS.items():
+                    for key, knames in kernels.items():
                         kname = next((k for k in knames if k + "<" in row["Kernel_Name"]), None)
                         if kname and ", true>" not in row["Kernel_Name"]:
                             acc.setdefault(key, {})["__kernel__"] = kname
@@ -473,7 +475,7 @@ def pmc_leg(args):
                      "counter group; read = 2 x FETCH_SIZE KB, write = WRITE_SIZE KB "
                      "(MI355X_MICROARCH.md HBM section); clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time",
            "seconds_spent": round(time.perf_counter() - t0, 1)}
-    for key in KERNELS:
+    for key in kernels:
         c = acc.get(key, {})
         mean = lambda name: (sum(v for v, _ in c[name]) / len(c[name])) if c.get(name) else None
         dur = lambda name: (sum(d for _, d in c[name]) / len(c[name])) if c.get(name) else None
@@ -572,7 +574,7 @@ def build_roofline(C, b_k1, b_k2, k1_ms, k2_ms, pmc, rates=None, solve_ms=None):
     return roof
 
 
-def other_configs(torch, _ffi, synth, dev):
+def other_configs(torch, _ffi, synth, dev, pmc_args=None, rates=None):
     """The other GPU configurations BASELINE.json names, timed briefly (inputs resident
     in HBM, 10 steps each) so that one record carries all of them:
     configs[1] 4-ch 10 s MVDR (500 utterances), configs[3] 8-ch 30 s GEV (125),
@@ -664,9 +666,12 @@ def other_configs(torch, _ffi, synth, dev):
         "workload": "6-ch 30 s x 125 utterances, CGMM (K = 2, 20 EM iterations) -> MVDR, "
                     "inputs resident in HBM",
         "ms_per_step": round(1e3 * dt, 3), "value": round(U * 30.0 / dt, 1)}
+    T4 = ctx.num_frames(N)
     ctx.close()
     del audio, waves
     torch.cuda.empty_cache()
+    if pmc_args is not None:
+        res["configs[4] 6-ch CGMM->MVDR"]["roofline"] = cgmm_roofline(pmc_args, C, T4, U, rates)
     # the paths around the fused hot path (SURVEY 8f-4 consumers, unfused engine)
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -675,6 +680,41 @@ def other_configs(torch, _ffi, synth, dev):
     except Exception as e:  # pragma: no cover
         res["consumers_and_unfused"] = {"error": repr(e)[:300]}
     return res
+
+
+def cgmm_roofline(args, C, T, U, rates):
+    """The EM kernel of configs[4] (cgmm_bin_em_kernel: all iterations of one (utterance, bin)
+    in one workgroup) under the same two ceilings as the streaming kernels, from counters
+    collected in this run: tools/bench_cgmm.py at the configs[4] shape as a child of
+    `rocprofv3 --pmc`.  Algorithmic bytes: the bin-major spectrogram read once + the masks
+    written once."""
+    child = [sys.executable, os.path.join(ROOT, "tools", "bench_cgmm.py"), "--utts", str(U),
+             "--channels", str(C), "--seconds", "30", "--iters", "20", "--steps", "1"]
+    pmc = pmc_leg(args, child=child, kernels={"em": ["cgmm_bin_em_kernel"]})
+    if "error" in pmc or not (pmc.get("em") or {}).get("valu_insts"):
+        return {"pmc": pmc}
+    p = pmc["em"]
+    F = 257
+    alg = U * (8.0 * C * T * F + 4.0 * T * F)
+    kms = p["profiled_kernel_ms"]
+    ent = {"kernel": "cgmm_bin_em_kernel", "profiled_kernel_ms": kms, "launches_profiled": p["launches"],
+           "alg_bytes_per_launch": alg, "seconds_spent": pmc.get("seconds_spent"),
+           "hbm": {"achieved": round(alg / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                   "frac": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    if p.get("hbm_read_bytes") is not None and p.get("hbm_write_bytes") is not None:
+        ent["hbm"].update(read_bytes=round(p["hbm_read_bytes"]), write_bytes=round(p["hbm_write_bytes"]),
+                          traffic_over_algorithmic=round((p["hbm_read_bytes"] + p["hbm_write_bytes"]) / alg, 3))
+    floor_ms = p["valu_insts"] / SIMDS * VALU_CYCLES_PER_INST / (p["clock_ghz"] * 1e9) * 1e3
+    measured = (rates or {}).get("cycles_per_inst_at_waves") or {}
+    cpi = measured.get(3, ISSUE_CYCLES_AT_WAVES[3])
+    ent["valu_issue"] = {"insts": round(p["valu_insts"]), "clock_ghz": p["clock_ghz"],
+                         "floor_ms": round(floor_ms, 3), "frac": round(floor_ms / kms, 4),
+                         "at_occupancy": {"waves_per_simd": 3, "cycles_per_inst": cpi,
+                                          "floor_ms": round(floor_ms * cpi / VALU_CYCLES_PER_INST, 3),
+                                          "frac": round(floor_ms * cpi / VALU_CYCLES_PER_INST / kms, 4),
+                                          "why": "three 256-thread workgroups per CU: 46.5 KB of LDS each, 168 VGPRs"}}
+    ent["bound"] = "valu_issue"
+    return ent
 
 
 def time_full_batch(args, ctx, opts, torch, audio, masks, C, N, L):

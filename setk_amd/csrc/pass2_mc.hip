@@ -218,8 +218,13 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
     // first and the last group of an utterance; frames past the last one repeat it (computed
     // to keep the group uniform, never emitted).
     auto load_full = [&](float (&v)[8], int t, int c, auto edge) __attribute__((always_inline)) {
+#ifdef SETK_P2MC_ABL_L2  // ablation: every wave reads the same 1 MB (L2 resident) -- wrong results
+        gcfloat_p x = gptr(a.utts[0].audio) + (size_t)c * n_samp;
+        const int s0 = (min(t, T - 1) & 127) * hop + 4096, o = 64 * g + c16;
+#else
         gcfloat_p x = gptr(ud.audio) + (size_t)c * n_samp;
         const int s0 = min(t, T - 1) * hop - a.g.pad, o = 64 * g + c16;
+#endif
         if (!decltype(edge)::value) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -236,7 +241,14 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
     };
     auto load_half = [&](float (&v)[8], int t, int c, auto edge) __attribute__((always_inline)) {
         gcfloat_p x = gptr(ud.audio) + (size_t)c * n_samp;
+#ifdef SETK_P2MC_ABL_REHALF  // ablation: re-read the half just loaded (cache hit) -- wrong results
+        const int s0 = min(t, T - 1) * hop - a.g.pad, o = 64 * g + c16;
+#elif defined(SETK_P2MC_ABL_L2)
+        x = gptr(a.utts[0].audio) + (size_t)c * n_samp;
+        const int s0 = (min(t, T - 1) & 127) * hop + 4096 + 256, o = 64 * g + c16;
+#else
         const int s0 = min(t, T - 1) * hop - a.g.pad + 256, o = 64 * g + c16;
+#endif
         if (!decltype(edge)::value) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[4 + e] = x[s0 + o + 16 * e];

@@ -614,6 +614,21 @@ class CgmmEstimator(object):
                 return masks
             except _ffi.SetkUnsupported:
                 pass  # a bin of the longest utterance does not fit a CU: streaming kernels
+        if C > 8:
+            # 9 - 16 channels: the general float64 EM (setk_cgmm_masks_k), one utterance at a time
+            # on spectrograms of the stand-alone transform (any n_fft the plan accepts)
+            masks = []
+            for k, a in enumerate(audio):
+                T = ctx.num_frames(a.shape[1])
+                spec = torch.empty((C, T, F), dtype=torch.complex64, device=dev)
+                ctx.stft(a, spec)
+                gamma = torch.empty((2, T, F), dtype=torch.float32, device=dev)
+                init = None if init_masks is None else init_masks[k]
+                ctx.cgmm_masks_k(spec, C, T, F, 2, self.num_iters, None, init, gamma,
+                                 update_alpha=self.update_alpha)
+                masks.append(gamma[0])
+            torch.cuda.current_stream().synchronize()
+            return masks
         specs, masks, frames = [], [], []
         # rows padded to 128 bytes: the EM kernels stream 32-bin (256-byte) segments per
         # wavefront and a 2056-byte row pitch makes every segment straddle an extra line

@@ -378,3 +378,27 @@ def test_cgmm_cli_three_classes_with_permutation_alignment(tmp_path):
         want = permu_aligner(np.transpose(gamma, (0, 2, 1)))[0]
         mask = np.load(os.path.join(td, "mask", f"u{k}.npy"))
         assert mask.shape == want.shape and np.mean(np.abs(mask - want)) < 5e-4, (k, np.mean(np.abs(mask - want)))
+
+
+def test_cgmm_cli_twelve_channels_default_options(tmp_path):
+    """estimate_cgmm_masks.py with its defaults on a 12-channel table: the batched estimator
+    hands arrays wider than 8 to the general EM (one utterance at a time) instead of refusing."""
+    import scipy.io.wavfile
+    td = str(tmp_path)
+    pcms = []
+    with open(os.path.join(td, "wav.scp"), "w") as f:
+        for k, n in enumerate((16000, 11000)):
+            mix = o.synth_utterance(730 + k, 12, n)
+            pcm = np.rint(mix.T.astype(np.float64) * 32767).astype(np.int16)
+            scipy.io.wavfile.write(os.path.join(td, f"w{k}.wav"), 16000, pcm)
+            f.write(f"w{k} {td}/w{k}.wav\n")
+            pcms.append(pcm)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts/sptk/estimate_cgmm_masks.py"),
+                        "--num-iters", "5", os.path.join(td, "wav.scp"), os.path.join(td, "mask")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for k, pcm in enumerate(pcms):
+        samps = pcm.astype(np.float32).T / np.float32(32768.0)
+        ref = o.cgmm_gamma(o.multichannel_stft(samps, transpose=False, **STFT_KW), 5)[0].T
+        mask = np.load(os.path.join(td, "mask", f"w{k}.npy"))
+        assert mask.shape == ref.shape and np.mean(np.abs(mask - ref)) < 1e-4, np.mean(np.abs(mask - ref))

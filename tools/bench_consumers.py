@@ -101,6 +101,23 @@ def run(utts=16, seconds=10.0):
                                   "(stand-alone operators, host arrays in / out)",
                       "ms_per_utt": round(1e3 * dt / utts, 2),
                       "value": round(utts * seconds / dt, 1)}
+    # ---- the general EM (K = 3, and K = 2 on a 12-channel array) and the wide WPE form ----
+    from setk_amd.libs.cluster import CgmmTrainer
+    for label, C, K in (("cgmm_general_k3_4ch", 4, 3), ("cgmm_general_k2_12ch", 12, 2)):
+        obs = np.transpose(device_stft(synth.synth_utterance(3300 + C, C, N), 512, 256, True, True, "hann"),
+                           (0, 2, 1))                                        # C x F x T
+        np.random.seed(777)
+        dt = timed(lambda: CgmmTrainer(obs, K).train(20), 1)
+        res[label] = {"workload": f"{C}-ch {seconds:g} s, CGMM K = {K}, 20 EM iterations, general float64 "
+                                  "device EM (cgmm_k.hip), numpy in / numpy out, one utterance",
+                      "ms_per_utt": round(1e3 * dt, 1), "value": round(seconds / dt, 1)}
+    wide = np.ascontiguousarray(np.transpose(
+        device_stft(synth.synth_utterance(3400, 16, N), 512, 128, True, True, "hann"), (2, 0, 1)))
+    dt = timed(lambda: W.wpe(wide, taps=10, delay=3, context=1, num_iters=3), 1)
+    res["wpe_16ch_10taps_wide"] = {
+        "workload": f"16-ch {seconds:g} s, hop 128, 10 taps x 3 iterations (NK = 160: R in global scratch), "
+                    "numpy in / numpy out, one utterance",
+        "ms_per_utt": round(1e3 * dt, 1), "value": round(seconds / dt, 1)}
     return res
 
 
