@@ -72,6 +72,41 @@ def test_enhance_matches_oracle(ctx, kind, C, N):
     assert rms(wav, ref) / rms(ref) < 1e-3, rms(wav, ref) / rms(ref)
 
 
+@pytest.mark.parametrize("switch", ["SETK_MC_PASS1=1", "SETK_MC_PASS2=0", "SETK_LEGACY_FFT=1"])
+@pytest.mark.parametrize("kind,C,N", [("mvdr", 8, 20000), ("gevd", 4, 16000), ("pmwf-0", 2, 7000),
+                                      ("mvdr", 1, 6000), ("mpdr", 8, 9001)])
+def test_alternative_kernel_forms_hold_the_same_bar(ctx, switch, kind, C, N):
+    """The forms behind the environment switches are products too: pass 1 with its transforms
+    on the matrix cores (opt-in: slower), pass 2 as fp32 butterflies, both
+    passes as butterflies.  Each against the oracle at the 1e-3 bar, and against the default
+    form at 1e-5 (the two transform arithmetics differ by 1e-7 per spectrum)."""
+    import os
+    from setk_amd import _ffi
+    mix, sp, nz = o.synth_utterance(60 + C, C, N, return_parts=True)
+    mask = o.irm_mask(sp, nz)
+    opts = lambda: _ffi.BfOpts(flags=_ffi.FLAG_CLAMP_MASK | _ffi.FLAG_POST_MASK, **KINDS[kind])
+    (base,), st = run_batch(ctx, opts(), [mix], [mask])
+    assert st == [0]
+    name, val = switch.split("=")
+    old = os.environ.get(name)
+    os.environ[name] = val
+    try:
+        # (SETK_LEGACY_FFT is read when the transform is planned: its own handle)
+        c2 = _ffi.Context(0)
+        c2.stft_plan(512, 256, 512, True)
+        (wav,), st = run_batch(c2, opts(), [mix], [mask])
+        c2.close()
+    finally:
+        if old is None:
+            del os.environ[name]
+        else:
+            os.environ[name] = old
+    assert st == [0]
+    ref = o.enhance_utterance(mix, mask, kind=kind, gauge=True, post_mask=True)
+    assert rms(wav, ref) / rms(ref) < 1e-3, rms(wav, ref) / rms(ref)
+    assert rms(wav, base) / rms(base) < 1e-5, rms(wav, base) / rms(base)
+
+
 @pytest.mark.parametrize("flags", ["ban", "post", "itf", "pcm16"])
 def test_enhance_flags(ctx, flags):
     from setk_amd import _ffi
