@@ -292,6 +292,13 @@ class Context:
         self.check(fn(self._h, *args, ctypes.byref(p)))
         return p.value or 0
 
+    def pci_bus_id(self):
+        """PCI address of the handle's device ("0000:23:00.0"): the key to its NUMA node in
+        sysfs (setk_amd/numa.py)."""
+        buf = ctypes.create_string_buffer(32)
+        self.check(self._lib.setk_device_pci_bus_id(self._h, buf, 32))
+        return buf.value.decode().lower()
+
     def device_alloc(self, nbytes):
         return self._out_ptr(self._lib.setk_device_alloc, ctypes.c_size_t(int(nbytes)))
 

@@ -49,12 +49,10 @@ def node_count():
 
 def device_node(ctx):
     """(pci bus id, NUMA node or None) of the context's device."""
-    buf = ctypes.create_string_buffer(32)
     try:
-        ctx.check(ctx._lib.setk_device_pci_bus_id(ctx._h, buf, 32))
+        bus = ctx.pci_bus_id()
     except Exception:  # noqa: BLE001
         return None, None
-    bus = buf.value.decode().lower()
     node = _read(f"/sys/bus/pci/devices/{bus}/numa_node")
     try:
         node = int(node)

@@ -172,6 +172,24 @@ def cgmm(ctx, C, lens, init, alpha):
     release()
 
 
+def cgmm_general(ctx, C, T, K, init):
+    """setk_cgmm_masks_k: K classes from a K x F x T float64 start, or K = 2 from a mask / the
+    deterministic start (host and device pointers)."""
+    spec = cplx(C, T, F)
+    gamma = np.empty((K, T, F), np.float32)
+    g0 = None
+    if K > 2 or init == "gamma0":
+        g0 = rng.random((K, F, T))
+        g0 /= g0.sum(0, keepdims=True)
+    mask = rng.random((T, F)).astype(np.float32) if init == "mask" else None
+    ctx.cgmm_masks_k(spec, C, T, F, K, 2, g0, mask, gamma, update_alpha=(K == 3))
+    ctx.cgmm_masks_k(to_dev(spec), C, T, F, K, 1, None if g0 is None else to_dev(g0),
+                     None if mask is None else to_dev(mask), dmalloc(gamma.nbytes))
+    expect((ValueError, NotImplementedError), ctx.cgmm_masks_k, spec, C, T, F, 5, 1, None, None, gamma)
+    expect((ValueError, NotImplementedError), ctx.cgmm_masks_k, spec, C, T, F, 3, 1, None, None, gamma)
+    release()
+
+
 def wpe(ctx, C, T, taps, delay):
     spec = cplx(C, T, F)
     out = np.empty_like(spec)
@@ -277,8 +295,14 @@ def main():
                                  (3, [1200000], False, False), (5, [700], False, False),
                                  (7, [100000], False, False), (6, [4000000], False, False)):
         cgmm(ctx, C, lens, init, alpha)
-    for C, T, taps, delay in ((2, 200, 10, 3), (6, 300, 10, 3), (8, 120, 5, 1), (1, 64, 3, 0), (4, 50, 20, 3)):
+    for C, T, K, init in ((4, 70, 3, ""), (2, 33, 4, ""), (12, 50, 2, ""), (16, 40, 2, "mask"), (9, 64, 2, "gamma0"),
+                          (1, 20, 2, "")):
+        cgmm_general(ctx, C, T, K, init)
+    # (the last three: R beyond LDS, factored in the arena's global scratch)
+    for C, T, taps, delay in ((2, 200, 10, 3), (6, 300, 10, 3), (8, 120, 5, 1), (1, 64, 3, 0), (4, 50, 20, 3),
+                              (8, 150, 12, 3), (16, 90, 6, 2), (16, 40, 16, 0)):
         wpe(ctx, C, T, taps, delay)
+    assert ":" in ctx.pci_bus_id()
     # argument errors must come back as error codes, not crashes
     expect((ValueError, NotImplementedError), ctx.covar, cplx(2, 4, F), np.ones((4, F), np.float32), 0, 4, F,
            np.empty((F, 2, 2), np.complex64))
