@@ -343,13 +343,13 @@ KERNELS = {"pass1": ["stft_covar_mc_kernel", "stft_covar_kernel"],
            "pass2": ["beamform_istft_mc_kernel", "beamform_istft_kernel"],
            "solve": ["solve_kernel"]}
 WAVES_PER_SIMD = {"stft_covar_mc_kernel": 4, "stft_covar_kernel": 4,
-                  "beamform_istft_mc_kernel": 4, "beamform_istft_kernel": 2, "solve_kernel": 4}
+                  "beamform_istft_mc_kernel": 4, "beamform_istft_kernel": 2, "solve_kernel": 2}
 WAVES_WHY = {"stft_covar_kernel": "one 1024-thread workgroup per CU at the 128-VGPR budget",
              "stft_covar_mc_kernel": "one 1024-thread workgroup per CU at the 128-VGPR budget",
              "beamform_istft_mc_kernel": "two 512-thread workgroups per CU at the 128-VGPR budget "
                                          "(54 KB of LDS each: weights + operand tiles)",
              "beamform_istft_kernel": "two 256-thread workgroups per CU: 63.6 KB of LDS each, 256 VGPRs per wave",
-             "solve_kernel": "32 125 problems x 8 lanes = 4 016 waves in ONE round over 1 024 SIMDs (3.9 per SIMD)"}
+             "solve_kernel": "226 VGPRs per wave: two waves per SIMD (32 125 problems x 8 lanes = 4 016 waves, two rounds)"}
 
 
 def issue_rates_leg():

@@ -411,7 +411,7 @@ SD void gev_vector(const cd (&rs)[C], const cd* L, cd* Wk, int j, bool gauge, cd
     }
     cd y[C];
     double lam;
-    jacobi_pevd<C>(c, j, y, lam, noconv);
+    pevd_mixed<C>(c, j, y, lam, noconv);  // (C~ is Hermitian PSD like Rs: same mixed-precision solver)
     if (gauge) fix_gauge<C>(y);
     bwd_solve<C>(L, y);
 #pragma unroll
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(64, (C > 8) ? 1 : SETK_SOLVE_WAVES) void solve_kern
 #pragma unroll
                 for (int i = 0; i < C; ++i) g[i] = rs[i];
                 double lam;
-                jacobi_pevd<C>(g, j, pv, lam, st_noconv);
+                pevd_mixed<C>(g, j, pv, lam, st_noconv);
             } else {
                 cd v[C];
                 gev_vector<C>(rs, L, Wk, j, false, v, st_noconv);
