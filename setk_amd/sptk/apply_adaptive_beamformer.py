@@ -91,6 +91,10 @@ _OPTIONS = (
     (("--skip-existing",), dict(default=False, type=lambda v: str(v).lower() in ("true", "1", "yes"),
                                 help="[setk_amd] resume: utterances whose {dst_dir}/{key}.wav already "
                                      "exists (non-empty) are not enhanced again")),
+    (("--requeue",), dict(default=False, type=lambda v: str(v).lower() in ("true", "1", "yes"),
+                          help="[setk_amd] with --skip-existing: deal only the MISSING utterances over the "
+                               "ranks (a re-launch after a rank died shares that rank's leftovers among "
+                               "all of them; what `python -m setk_amd.launch` passes on its retries)")),
     (("--profile",), dict(default="", type=str,
                           help="[setk_amd] write a JSON run summary (wall clock from the first "
                                "scp read to the last wav close, stage times, bytes) here")),
@@ -143,6 +147,46 @@ def _complete_wav(path):
     return riff + 8 == size and data + 44 == size
 
 
+def _arm_fault_injection(shard, writer):
+    """Test hook of the re-queue path (tests/test_host_asan.py): SETK_FAULT_INJECT=
+    "<rank>:<n>[:<attempt>]" makes that rank die WITHOUT any clean-up -- as a killed process
+    or a lost GPU would -- after its n-th wave file (in attempt <attempt> of
+    `python -m setk_amd.launch`, default 0).  Unset: nothing happens."""
+    spec = os.environ.get("SETK_FAULT_INJECT", "")
+    if not spec:
+        return
+    parts = spec.split(":")
+    rank, after = int(parts[0]), int(parts[1])
+    attempt = int(parts[2]) if len(parts) > 2 else 0
+    if rank != shard.rank or attempt != int(os.environ.get("SETK_LAUNCH_ATTEMPT", "0")):
+        return
+    count = [0]
+
+    def wrap(inner):
+        def write(*a, **k):
+            r = inner(*a, **k)
+            count[0] += 1
+            if count[0] >= after:
+                logger.error(f"SETK_FAULT_INJECT: rank {shard.rank} dies after {count[0]} files")
+                os._exit(17)
+            return r
+        return write
+    writer.record = wrap(writer.record)   # every finished file passes through record()
+
+
+def _deal(args, shard, reader):
+    """This rank's utterances.  Default: the deal is computed on the FULL table (every rank keeps
+    the utterances it had) and --skip-existing then drops what is already there.  --requeue
+    (a re-launch after a failure): the missing utterances are found first -- by every rank, from
+    the same directory listing: nobody writes before the barrier below -- and only they are dealt,
+    so the leftovers of a rank that died are shared by all ranks instead of waiting for it."""
+    if getattr(args, "skip_existing", False) and getattr(args, "requeue", False) and shard.world > 1:
+        left = _drop_existing(args, list(reader.index_keys))
+        shard.barrier()
+        return shard.assign_by_duration(reader, keys=left)
+    return _drop_existing(args, shard.assign_by_duration(reader))
+
+
 def _drop_existing(args, keys):
     """--skip-existing: a re-run after an interruption (or a re-queued shard of a failed
     rank) only does what is missing.  The sharding above is computed on the full table, so
@@ -176,7 +220,7 @@ def run_online(args, shard):
     beamformer = cls(num_bins, args.channels, args.alpha)
     logger.info(f"Using online {args.beamformer} beamformer, chunk size = {args.chunk_size:d}")
     num_done = 0
-    keys = _drop_existing(args, shard.assign_by_duration(reader))
+    keys = _deal(args, shard, reader)
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
         for key in keys:
             if key not in tgt:
@@ -258,11 +302,12 @@ def run_offline(args, shard):
     if placement.get("bound"):
         logger.info(f"rank {shard.rank}: bound to NUMA node {placement['node']} "
                     f"({placement['cpus']} CPUs, GPU {placement.get('pci_bus_id')})")
-    keys = _drop_existing(args, shard.assign_by_duration(wav_reader))
+    keys = _deal(args, shard, wav_reader)
     summary = dict(mode="batch", utts=0, rank=shard.rank, world=shard.world,
                    assigned_samples=shard.assigned_weight, numa=placement)
     num_done = 0
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
+        _arm_fault_injection(shard, writer)
         if _fast_path_ok(args):
             num_done, stats = _run_pipeline(args, engine, writer, wav_reader, tgt, itf, keys)
             summary.update(mode="pipeline", stages=stats)

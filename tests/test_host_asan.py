@@ -308,3 +308,40 @@ def test_eight_rank_cli_on_the_stand_in_balances_ragged_lengths(tmp_path):
     loads = np.array([p["assigned_samples"] for p in per_rank], dtype=np.float64)
     assert loads.sum() == sum(lens)
     assert np.abs(loads / loads.mean() - 1).max() < 0.02, loads
+
+
+def test_launcher_requeues_what_a_dead_rank_left(tmp_path):
+    """`python -m setk_amd.launch --nproc 2`: in the first attempt rank 1 dies (os._exit, no
+    clean-up) after its second wave file, which takes the attempt down; the launcher starts the
+    job again with --skip-existing --requeue, the new attempt deals ONLY the missing utterances
+    over both ranks, and at the end every utterance exists exactly once and complete."""
+    import json
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "hoststub", "build.sh")], capture_output=True,
+                       text=True, timeout=900, env=dict(os.environ, PLAIN="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    td = str(tmp_path)
+    lens = [16000, 64000, 8000, 30011, 16000, 12345, 48000, 9000, 20000, 21000, 22000, 23000]
+    _make_table(td, lens)
+    env = dict(os.environ, HOSTSTUB_DEVICES="2", SETK_ALLOW_HOSTSTUB="1", OMP_NUM_THREADS="1",
+               SETK_LIB=os.path.join(ROOT, "_abl", "libsetk_hoststub.so"), SETK_FAULT_INJECT="1:2:0",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "setk_amd.launch", "--nproc", "2", "--retries", "2",
+                        os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py"),
+                        "--mask-format", "numpy", "--batch-utts", "1", "--pipeline-depth", "1",
+                        "--profile", f"{td}/prof.json", f"{td}/wav.scp", f"{td}/mask.scp", f"{td}/out"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "attempt 1 of 3" in r.stderr and "re-queueing what is missing" in r.stderr
+    assert "attempt 2 of 3" in r.stderr and "attempt 3 of 3" not in r.stderr
+    assert "SETK_FAULT_INJECT: rank 1 dies after 2 files" in r.stderr
+    out = sorted(os.listdir(f"{td}/out"))
+    assert out == sorted(f"u{i}.wav" for i in range(len(lens))), out     # no .part left, nothing missing
+    from setk_amd.sptk.apply_adaptive_beamformer import _complete_wav
+    assert all(_complete_wav(f"{td}/out/{f}") for f in out)
+    # the second attempt dealt only what was missing, over BOTH ranks
+    per_rank = [json.load(open(f"{td}/prof.json.rank{k}")) for k in range(2)]
+    redone = sum(p["utts"] for p in per_rank)
+    assert 0 < redone <= len(lens) - 2 and all(p["utts"] >= 1 for p in per_rank), per_rank
+    assert "already in" in r.stderr   # --skip-existing saw the first attempt's files
