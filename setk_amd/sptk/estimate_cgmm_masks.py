@@ -4,7 +4,8 @@ Speech / noise mask estimation with the CGMM model on the MI355X.
 
 Drop-in for funcwj/setk ``scripts/sptk/estimate_cgmm_masks.py`` (same
 positional arguments, options, defaults, outputs {dst_dir}/{key}.npy float32
-T x F, skip-if-exists behaviour :38).  --num-classes 2 runs the tuned batch kernels;
+T x F -- K x T x F for more than two classes, :62-64 --, skip-if-exists behaviour :38).
+--num-classes 2 runs the tuned batch kernels;
 3 and 4 start from the reference's seeded random posteriors (--seed, drawn on the host from
 numpy's legacy generator exactly as the reference does) and run the general device EM
 (csrc/cgmm_k.hip); --solve-permu aligns the classes over frequency on the host
@@ -86,7 +87,8 @@ def run(args):
             if args.solve_permu:
                 masks = permu_aligner(masks)
                 logger.info("Permutation alignment done on each frequency")
-            writer.write(key, masks[0].astype(np.float32))
+            # the speech mask for two classes, every class's mask (K x T x F) otherwise (:62-64)
+            writer.write(key, (masks[0] if args.num_classes == 2 else masks).astype(np.float32))
             logger.info(f"Training utterance {key} ... Done")
     shard.barrier()
     if shard.world > 1:

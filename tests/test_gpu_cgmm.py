@@ -375,9 +375,10 @@ def test_cgmm_cli_three_classes_with_permutation_alignment(tmp_path):
     for k, pcm in enumerate(pcms):
         samps = pcm.astype(np.float32).T / np.float32(32768.0)
         gamma = o.cgmm_gamma(o.multichannel_stft(samps, transpose=False, **STFT_KW), 5, num_classes=3)
-        want = permu_aligner(np.transpose(gamma, (0, 2, 1)))[0]
+        want = permu_aligner(np.transpose(gamma, (0, 2, 1)))   # K x T x F: every class is saved (:62-64)
         mask = np.load(os.path.join(td, "mask", f"u{k}.npy"))
-        assert mask.shape == want.shape and np.mean(np.abs(mask - want)) < 5e-4, (k, np.mean(np.abs(mask - want)))
+        assert mask.shape == want.shape and mask.shape[0] == 3
+        assert np.mean(np.abs(mask - want)) < 5e-4, (k, np.mean(np.abs(mask - want)))
 
 
 def test_cgmm_cli_twelve_channels_default_options(tmp_path):
@@ -402,3 +403,58 @@ def test_cgmm_cli_twelve_channels_default_options(tmp_path):
         ref = o.cgmm_gamma(o.multichannel_stft(samps, transpose=False, **STFT_KW), 5)[0].T
         mask = np.load(os.path.join(td, "mask", f"w{k}.npy"))
         assert mask.shape == ref.shape and np.mean(np.abs(mask - ref)) < 1e-4, np.mean(np.abs(mask - ref))
+
+
+def _mask_report(tag, got, ref):
+    d = np.abs(got - ref)
+    big = d > 1e-3
+    undecided = (ref > 0.02) & (ref < 0.98)
+    print(f"[{tag}] mean |d| {d.mean():.2e}, max |d| {d.max():.2e}, cells > 1e-3: {int(big.sum())} of "
+          f"{d.size} ({int((big & undecided).sum())} undecided; {undecided.mean():.1%} of all cells are undecided)")
+    return d, big, undecided
+
+
+def test_spatial_clustering_doc_pipelines_on_the_device(tmp_path):
+    """The reference's spatial-clustering doc pipelines on its two real recordings, through the
+    command line: noisy.wav (5 ch, K = 2: the bin-resident EM) and 2spk.wav (7 ch, --num-classes 3
+    --solve-permu true, seed 777: the general EM + the host aligner), against what the unmodified
+    reference saved (tests/golden/doc_spatial_clustering.npz).  As on egs.wav the device's
+    float32 STFT (1e-7 from librosa's) is amplified by the EM on undecided cells; to separate
+    that from the EM itself the device EM is also run on the ORACLE's spectrogram."""
+    import scipy.io.wavfile
+    from setk_amd.libs.cluster import CgmmTrainer, permu_aligner
+    g = load_golden("doc_spatial_clustering.npz")
+    td = str(tmp_path)
+    for name in ("noisy", "2spk"):
+        scipy.io.wavfile.write(os.path.join(td, f"{name}.wav"), 16000, g["pcm_" + name])
+        with open(os.path.join(td, f"{name}.scp"), "w") as f:
+            f.write(f"{name} {td}/{name}.wav\n")
+    cli = os.path.join(ROOT, "scripts/sptk/estimate_cgmm_masks.py")
+    r = subprocess.run([sys.executable, cli, "--num-iters", "20", "--frame-len", "512",
+                        os.path.join(td, "noisy.scp"), os.path.join(td, "mask")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(os.path.join(td, "mask", "noisy.npy"))
+    ref = g["saved_noisy"]
+    assert got.shape == ref.shape == (251, 257) and got.dtype == np.float32
+    d, big, undecided = _mask_report("doc noisy K=2", got, ref)
+    assert d.mean() < 2e-4 and big.mean() < 1e-2 and (big & ~undecided).sum() <= 0.2 * max(big.sum(), 1)
+    r = subprocess.run([sys.executable, cli, "--num-iters", "20", "--frame-len", "512", "--num-classes", "3",
+                        "--solve-permu", "true", os.path.join(td, "2spk.scp"), os.path.join(td, "mask")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(os.path.join(td, "mask", "2spk.npy"))
+    ref = g["saved_2spk"]
+    assert got.shape == ref.shape == (3, 251, 257) and got.dtype == np.float32     # every class (:62-64)
+    d, big, undecided = _mask_report("doc 2spk K=3 + permu", got, ref)
+    assert d.mean() < 1e-3 and big.mean() < 3e-2
+    # the EM itself, on the same input as the reference's (the oracle's float64 STFT as complex64)
+    for name, K in (("noisy", 2), ("2spk", 3)):
+        samps = (g["pcm_" + name].astype(np.float32) / 32768.0).T.copy()
+        obs = o.multichannel_stft(samps, transpose=False, **STFT_KW)
+        np.random.seed(777)
+        gam = np.transpose(CgmmTrainer(obs, K).train(20), (0, 2, 1))
+        same = gam[0] if K == 2 else permu_aligner(gam)
+        d, big, _ = _mask_report(f"doc {name}: device EM on the oracle's STFT", same.astype(np.float32),
+                                 g["saved_" + name])
+        assert d.mean() < 1e-4 and big.mean() < 2e-3

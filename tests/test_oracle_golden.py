@@ -344,3 +344,26 @@ def test_classic_beamformer_goldens():
             ref = g[f"{k}.{name}"]
             assert y.shape == ref.shape, (k, name)
             assert pcm16_rel_rms(ref, y) < 2e-4, (k, name, pcm16_rel_rms(ref, y))
+
+
+def test_spatial_clustering_doc_pipelines_on_real_recordings():
+    """doc/spatial_clustering/README.md on the reference's two real recordings (first 4 s):
+    K = 2 on noisy.wav (5 ch) and K = 3, seed 777, --solve-permu on 2spk.wav (7 ch), run through
+    the UNMODIFIED reference by oracle/make_golden.py.  The oracle (and, for K = 3, the
+    product's host-side aligner on the oracle's posteriors) reproduces what the reference CLI
+    saves: T x F for two classes, K x T x F otherwise (estimate_cgmm_masks.py:62-64)."""
+    from setk_amd.libs.cluster import permu_aligner
+    g = load_golden("doc_spatial_clustering.npz")
+    samps = (g["pcm_noisy"].astype(np.float32) / 32768.0).T.copy()
+    stft = o.multichannel_stft(samps, transpose=False, **STFT_KW)
+    m = o.cgmm_masks(stft, 20)
+    assert m.shape == g["saved_noisy"].shape == (251, 257)
+    d = np.abs(m - g["saved_noisy"])
+    assert d.mean() < 1e-5 and d.max() < 1e-3, (d.mean(), d.max())
+    samps = (g["pcm_2spk"].astype(np.float32) / 32768.0).T.copy()
+    stft = o.multichannel_stft(samps, transpose=False, **STFT_KW)
+    gamma = o.cgmm_gamma(stft, 20, num_classes=3, seed=777)           # K x F x T
+    saved = permu_aligner(np.transpose(gamma, (0, 2, 1))).astype(np.float32)
+    assert saved.shape == g["saved_2spk"].shape == (3, 251, 257)
+    d = np.abs(saved - g["saved_2spk"])
+    assert d.mean() < 1e-5 and d.max() < 1e-3, (d.mean(), d.max())
