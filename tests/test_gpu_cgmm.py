@@ -438,7 +438,8 @@ def test_spatial_clustering_doc_pipelines_on_the_device(tmp_path):
     ref = g["saved_noisy"]
     assert got.shape == ref.shape == (251, 257) and got.dtype == np.float32
     d, big, undecided = _mask_report("doc noisy K=2", got, ref)
-    assert d.mean() < 2e-4 and big.mean() < 1e-2 and (big & ~undecided).sum() <= 0.2 * max(big.sum(), 1)
+    # measured: mean 2.8e-6, max 2.5e-3, 15 cells of 64 507 above 1e-3, all of them undecided
+    assert d.mean() < 5e-5 and d.max() < 2e-2 and big.mean() < 2e-3 and (big & ~undecided).sum() <= 0.2 * max(big.sum(), 1)
     r = subprocess.run([sys.executable, cli, "--num-iters", "20", "--frame-len", "512", "--num-classes", "3",
                         "--solve-permu", "true", os.path.join(td, "2spk.scp"), os.path.join(td, "mask")],
                        capture_output=True, text=True, timeout=600)
@@ -447,7 +448,8 @@ def test_spatial_clustering_doc_pipelines_on_the_device(tmp_path):
     ref = g["saved_2spk"]
     assert got.shape == ref.shape == (3, 251, 257) and got.dtype == np.float32     # every class (:62-64)
     d, big, undecided = _mask_report("doc 2spk K=3 + permu", got, ref)
-    assert d.mean() < 1e-3 and big.mean() < 3e-2
+    # measured: mean 5.9e-6, max 8.9e-3, 132 cells of 193 521 above 1e-3, all of them undecided
+    assert d.mean() < 1e-4 and d.max() < 5e-2 and big.mean() < 5e-3 and (big & ~undecided).sum() <= 0.2 * max(big.sum(), 1)
     # the EM itself, on the same input as the reference's (the oracle's float64 STFT as complex64)
     for name, K in (("noisy", 2), ("2spk", 3)):
         samps = (g["pcm_" + name].astype(np.float32) / 32768.0).T.copy()
@@ -457,4 +459,5 @@ def test_spatial_clustering_doc_pipelines_on_the_device(tmp_path):
         same = gam[0] if K == 2 else permu_aligner(gam)
         d, big, _ = _mask_report(f"doc {name}: device EM on the oracle's STFT", same.astype(np.float32),
                                  g["saved_" + name])
-        assert d.mean() < 1e-4 and big.mean() < 2e-3
+        # measured: K = 2 (float32 quadratic forms) mean 5.4e-7, max 2.8e-4; K = 3 (float64 EM) 5e-13 / 6e-8
+        assert d.mean() < (1e-5 if K == 2 else 1e-9) and d.max() < (1e-3 if K == 2 else 1e-5)
