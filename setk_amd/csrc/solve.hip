@@ -50,8 +50,13 @@ constexpr int kKindPevd = 100;  // internal: plain solve_pevd(Rs[, Rn])
 constexpr double kEpsF32 = 1.1920928955078125e-07;
 
 // one rotation of column j against column j ^ M; returns true if it rotated
+// floor2: de Rijk's threshold as in jacobi_round_f32 -- inner products at the rounding level of
+// the LARGEST column (eps64 |g_max|^2) are noise; on a rank-deficient matrix (a real recording
+// of a few coherent sources on many microphones) the columns of the null space never meet the
+// relative bound and the sweeps would run to their limit (SETK_NUM_NOCONV on 100+ bins of a
+// 16-channel recording before this bound existed).
 template <int C, int M>
-SD bool jacobi_round(cd (&g)[C], int j) {
+SD bool jacobi_round(cd (&g)[C], int j, double floor2) {
     const double tol2 = 1e-16;  // see jacobi_pevd
     const int p = j ^ M;
     cd gp[C];
@@ -65,7 +70,7 @@ SD bool jacobi_round(cd (&g)[C], int j) {
         d = zadd(d, zcmul(g[i], gp[i]));
     }
     const double dd = zabs2(d);
-    if (dd > tol2 * m * o && dd > 0.0) {
+    if (dd > tol2 * m * o && dd > floor2) {
         const double absd = sqrt(dd);
         const double sigma = (j < p) ? 1.0 : -1.0;
         const double zeta = sigma * (o - m) / (2.0 * absd);
@@ -96,23 +101,29 @@ SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
     constexpr int W = Grp<C>::W;
     bool done = false;
     for (int sweep = 0; sweep < 40 && !done; ++sweep) {
+        double mm = 0.0;
+#pragma unroll
+        for (int i = 0; i < C; ++i) mm += zabs2(g[i]);
+#pragma unroll
+        for (int sft = 1; sft < W; sft <<= 1) mm = fmax(mm, __shfl_xor(mm, sft, W));
+        const double floor2 = 1e-28 * mm * mm;  // (~(64 eps64 |g_max|^2)^2)
         bool rot = false;
-        rot |= jacobi_round<C, 1>(g, j);
-        rot |= jacobi_round<C, 2>(g, j);
-        rot |= jacobi_round<C, 3>(g, j);
-        rot |= jacobi_round<C, 4>(g, j);
-        rot |= jacobi_round<C, 5>(g, j);
-        rot |= jacobi_round<C, 6>(g, j);
-        rot |= jacobi_round<C, 7>(g, j);
+        rot |= jacobi_round<C, 1>(g, j, floor2);
+        rot |= jacobi_round<C, 2>(g, j, floor2);
+        rot |= jacobi_round<C, 3>(g, j, floor2);
+        rot |= jacobi_round<C, 4>(g, j, floor2);
+        rot |= jacobi_round<C, 5>(g, j, floor2);
+        rot |= jacobi_round<C, 6>(g, j, floor2);
+        rot |= jacobi_round<C, 7>(g, j, floor2);
         if constexpr (W == 16) {
-            rot |= jacobi_round<C, 8>(g, j);
-            rot |= jacobi_round<C, 9>(g, j);
-            rot |= jacobi_round<C, 10>(g, j);
-            rot |= jacobi_round<C, 11>(g, j);
-            rot |= jacobi_round<C, 12>(g, j);
-            rot |= jacobi_round<C, 13>(g, j);
-            rot |= jacobi_round<C, 14>(g, j);
-            rot |= jacobi_round<C, 15>(g, j);
+            rot |= jacobi_round<C, 8>(g, j, floor2);
+            rot |= jacobi_round<C, 9>(g, j, floor2);
+            rot |= jacobi_round<C, 10>(g, j, floor2);
+            rot |= jacobi_round<C, 11>(g, j, floor2);
+            rot |= jacobi_round<C, 12>(g, j, floor2);
+            rot |= jacobi_round<C, 13>(g, j, floor2);
+            rot |= jacobi_round<C, 14>(g, j, floor2);
+            rot |= jacobi_round<C, 15>(g, j, floor2);
         }
         done = !__any(rot);
     }
@@ -328,23 +339,42 @@ SD int chol_lds(const cd (&col)[C], cd* L, double* piv, int j) {
     double scale = diag;
 #pragma unroll
     for (int s = 1; s < Grp<C>::W; s <<= 1) scale = fmax(scale, __shfl_xor(scale, s, Grp<C>::W));
-    int bad = !(scale > 0.0);
+    const int bad0 = !(scale > 0.0);
+    int bad = bad0;
     const double floor_piv = kEpsF32 * scale;
+    // Flooring a pivot in the middle of an unpivoted factorisation is only safe when little
+    // follows it: on a strongly rank-deficient matrix (a REAL 16-channel recording of two or
+    // three coherent sources: 10+ noise-level pivots in a row) what is left of the later
+    // columns is divided by sqrt(floor) again and again, and |L| grows until it overflows
+    // (doc/ssl/asset/egs.wav: NaN in 33 bins, growth 1e10 already on its first 8 channels).
+    // So a problem that meets the floor is factored again with the floor ADDED to its diagonal
+    // up front (8 eps_f32 max diag: above the negative rounding eigenvalues of a float32
+    // covariance) -- then the matrix IS positive definite, Cholesky needs no pivoting and |L|
+    // stays below sqrt(max diag).  Problems that never meet the floor are untouched.
+    double load = 0.0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool hit = false;
+        bad = bad0;
 #pragma unroll
-    for (int k = 0; k < C; ++k) {
-        cd s = make_double2(0.0, 0.0);
-        if (j >= k && j < C) {
-            s = make_double2(col[k].x, -col[k].y);  // M[j][k]
-            for (int m = 0; m < k; ++m) s = zsub(s, zmulc(L[m * C + j], L[m * C + k]));
+        for (int k = 0; k < C; ++k) {
+            cd s = make_double2(0.0, 0.0);
+            if (j >= k && j < C) {
+                s = make_double2(col[k].x, -col[k].y);  // M[j][k]
+                if (j == k) s.x += load;
+                for (int m = 0; m < k; ++m) s = zsub(s, zmulc(L[m * C + j], L[m * C + k]));
+            }
+            if (j == k) *piv = s.x;
+            __syncthreads();
+            double d = *piv;
+            if (!(d == d)) bad = 1;  // NaN
+            if (!(d >= floor_piv)) hit = true;
+            d = fmax(d, floor_piv);
+            const double rd = (d > 0.0) ? 1.0 / sqrt(d) : 0.0;
+            if (j >= k && j < C) L[k * C + j] = (j == k) ? make_double2(d * rd, 0.0) : zscale(s, rd);
+            __syncthreads();
         }
-        if (j == k) *piv = s.x;
-        __syncthreads();
-        double d = *piv;
-        if (!(d == d)) bad = 1;  // NaN
-        d = fmax(d, floor_piv);
-        const double rd = (d > 0.0) ? 1.0 / sqrt(d) : 0.0;
-        if (j >= k && j < C) L[k * C + j] = (j == k) ? make_double2(d * rd, 0.0) : zscale(s, rd);
-        __syncthreads();
+        if (attempt == 1 || !__any(hit && !bad0)) break;  // (wave-uniform: the barriers above need everyone)
+        load = (hit && !bad0) ? 8.0 * floor_piv : 0.0;
     }
     return bad;
 }

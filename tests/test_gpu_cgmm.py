@@ -405,7 +405,7 @@ def test_cgmm_cli_twelve_channels_default_options(tmp_path):
         assert mask.shape == ref.shape and np.mean(np.abs(mask - ref)) < 1e-4, np.mean(np.abs(mask - ref))
 
 
-def _mask_report(tag, got, ref):
+def _doc_mask_report(tag, got, ref):
     d = np.abs(got - ref)
     big = d > 1e-3
     undecided = (ref > 0.02) & (ref < 0.98)
@@ -437,7 +437,7 @@ def test_spatial_clustering_doc_pipelines_on_the_device(tmp_path):
     got = np.load(os.path.join(td, "mask", "noisy.npy"))
     ref = g["saved_noisy"]
     assert got.shape == ref.shape == (251, 257) and got.dtype == np.float32
-    d, big, undecided = _mask_report("doc noisy K=2", got, ref)
+    d, big, undecided = _doc_mask_report("doc noisy K=2", got, ref)
     # measured: mean 2.8e-6, max 2.5e-3, 15 cells of 64 507 above 1e-3, all of them undecided
     assert d.mean() < 5e-5 and d.max() < 2e-2 and big.mean() < 2e-3 and (big & ~undecided).sum() <= 0.2 * max(big.sum(), 1)
     r = subprocess.run([sys.executable, cli, "--num-iters", "20", "--frame-len", "512", "--num-classes", "3",
@@ -447,7 +447,7 @@ def test_spatial_clustering_doc_pipelines_on_the_device(tmp_path):
     got = np.load(os.path.join(td, "mask", "2spk.npy"))
     ref = g["saved_2spk"]
     assert got.shape == ref.shape == (3, 251, 257) and got.dtype == np.float32     # every class (:62-64)
-    d, big, undecided = _mask_report("doc 2spk K=3 + permu", got, ref)
+    d, big, undecided = _doc_mask_report("doc 2spk K=3 + permu", got, ref)
     # measured: mean 5.9e-6, max 8.9e-3, 132 cells of 193 521 above 1e-3, all of them undecided
     assert d.mean() < 1e-4 and d.max() < 5e-2 and big.mean() < 5e-3 and (big & ~undecided).sum() <= 0.2 * max(big.sum(), 1)
     # the EM itself, on the same input as the reference's (the oracle's float64 STFT as complex64)
@@ -457,7 +457,7 @@ def test_spatial_clustering_doc_pipelines_on_the_device(tmp_path):
         np.random.seed(777)
         gam = np.transpose(CgmmTrainer(obs, K).train(20), (0, 2, 1))
         same = gam[0] if K == 2 else permu_aligner(gam)
-        d, big, _ = _mask_report(f"doc {name}: device EM on the oracle's STFT", same.astype(np.float32),
+        d, big, _ = _doc_mask_report(f"doc {name}: device EM on the oracle's STFT", same.astype(np.float32),
                                  g["saved_" + name])
         # measured: K = 2 (float32 quadratic forms) mean 5.4e-7, max 2.8e-4; K = 3 (float64 EM) 5e-13 / 6e-8
         assert d.mean() < (1e-5 if K == 2 else 1e-9) and d.max() < (1e-3 if K == 2 else 1e-5)

@@ -310,3 +310,38 @@ def test_full_size_properties(ctx):
     assert st == [0]
     x = mix[0, :y1.shape[0]]
     assert rms(y1, x * (np.max(np.abs(mix[0])) / np.max(np.abs(x)))) / rms(x) < 1e-4
+
+
+@pytest.mark.parametrize("kind", ["pmwf-0", "mvdr", "gevd"])
+def test_rank_deficient_real_recording_through_the_fused_path(ctx, kind):
+    """The first 8 channels of doc/ssl/asset/egs.wav (two or three coherent sources: the noise
+    covariance is singular to float32 in ~100 bins).  The reference goes through on LAPACK's
+    noise-level pivots and its output is a rounding artefact there (it moves by O(1) under a
+    1e-7 input perturbation); the fused path must go through too -- no status, nothing
+    non-finite, bounded weights (the floored-pivot Cholesky of rounds 1 - 3 grew |L| by 1e10 on
+    this input) -- agree with the oracle where the problem is well posed, and stay within the
+    reference's own sensitivity elsewhere."""
+    from setk_amd import _ffi
+    g = load_golden("doc_wide_16ch.npz")
+    samps = np.ascontiguousarray((g["pcm"][:, :8].astype(np.float32) / 32768.0).T)
+    mask = g["mask"]
+    opts = _ffi.BfOpts(flags=_ffi.FLAG_CLAMP_MASK, **KINDS[kind])
+    (wav,), st = run_batch(ctx, opts, [samps], [mask])
+    assert st == [0] and np.isfinite(wav).all()
+    assert np.abs(wav).max() > 1e-4
+    try:
+        ref = o.enhance_utterance(samps, mask, kind=kind, gauge=True)
+    except np.linalg.LinAlgError as e:
+        # GEV: LAPACK's hegvd refuses a noise covariance whose Cholesky meets a non-positive
+        # pivot -- the reference then SKIPS the utterance (apply_adaptive_beamformer.py:170-172);
+        # the product beamforms it on the regularised factorisation (DESIGN section 2)
+        print(f"[8ch real, {kind}] the reference raises here ({e}); the product goes through")
+        assert kind == "gevd"
+        return
+    rng = np.random.default_rng(1)
+    moved = o.enhance_utterance(samps * (1 + 1e-7 * rng.standard_normal(samps.shape)).astype(np.float32),
+                                mask, kind=kind, gauge=True)
+    sens = rms(moved, ref) / rms(ref)
+    err = rms(wav, ref) / rms(ref)
+    print(f"[8ch real, {kind}] vs oracle {err:.3g}; oracle under a 1e-7 input perturbation {sens:.3g}")
+    assert err < max(1e-3, 3.0 * sens)

@@ -367,3 +367,22 @@ def test_spatial_clustering_doc_pipelines_on_real_recordings():
     assert saved.shape == g["saved_2spk"].shape == (3, 251, 257)
     d = np.abs(saved - g["saved_2spk"])
     assert d.mean() < 1e-5 and d.max() < 1e-3, (d.mean(), d.max())
+
+
+def test_wide_real_recording_through_the_reference_clis():
+    """A real 16-channel recording (doc/ssl/asset/egs.wav, 2 s) through the unmodified
+    estimate_cgmm_masks.py and apply_adaptive_beamformer.py --beamformer pmwf-0
+    (make_golden.py wide): the oracle reproduces the saved mask and the saved wave file (PMWF is
+    gauge free) to the PCM16 floor of this quiet recording."""
+    g = load_golden("doc_wide_16ch.npz")
+    samps = (g["pcm"].astype(np.float32) / 32768.0).T.copy()
+    assert samps.shape == (16, 32000)
+    stft = o.multichannel_stft(samps, transpose=False, **STFT_KW)
+    m = o.cgmm_masks(stft, 20)
+    d = np.abs(m - g["mask"])
+    assert m.shape == g["mask"].shape == (126, 257) and d.mean() < 1e-5 and d.max() < 1e-3, (d.mean(), d.max())
+    wav = o.enhance_utterance(samps, g["mask"], kind="pmwf-0")
+    ref = pcm_to_float(g["pmwf0"])
+    assert wav.shape == ref.shape
+    # measured: every sample of the file equal (a quiet recording: one LSB is 3e-3 of its RMS)
+    assert np.mean(float_to_pcm(wav) != g["pmwf0"]) < 1e-3
