@@ -54,8 +54,11 @@ SR = 16000
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 0.1 s of warm-up and 0.4 s timed -- with 3 + 20 steps (46 ms in all, rounds 1 - 3)
+    # the timed region still sat on the clock / power ramp of a GPU that had been idle: the
+    # same build measured 1.83 - 1.86 ms per step there and 1.75 - 1.80 over the 3 s of `sustained`
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--utts", type=int, default=125, help="utterances per GPU")
     ap.add_argument("--channels", type=int, default=8)
     ap.add_argument("--seconds", type=float, default=30.0)
