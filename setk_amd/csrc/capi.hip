@@ -1924,7 +1924,7 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     const int quant2 = mc2 ? 8 : kSuperTile;
     const int target2 = mc2 ? choose_target(all_frames, h->mc_p2_items > 0 ? h->mc_p2_items : h->mc_cus * pass2_mc_wgs_per_cu(C), quant2, 64)
                             : choose_target(all_frames, h->p2_items, kSuperTile, kSuperTile * 4);
-    int nparts_total = 0;
+    int nparts_total = 0, max_parts = 0;
     for (int u = 0; u < n_utts; ++u) {
         UttDesc& ud = uds[u];
         memset(&ud, 0, sizeof(ud));
@@ -1943,6 +1943,7 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
         split_frames(ud.num_frames, target2, quant2, &r2);
         ud.part0 = nparts_total;
         ud.nparts = (int)r1.size();
+        max_parts = std::max(max_parts, ud.nparts);
         for (auto& r : r1)
             items1.push_back({u, r.first, r.second, nparts_total++, r.second == ud.num_frames});
         for (auto& r : r2) items2.push_back({u, r.first, r.second, 0, r.second == ud.num_frames});
@@ -2051,7 +2052,14 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     fa.num_channels = C;
     fa.with_ry = mpdr ? 1 : 0;
     fa.num_scale = mc1 ? (float)((h->mc_peak / 1024.0) * (h->mc_peak / 1024.0)) : 1.f;
-    HIP_TRY(h, launch_finalize(fa, n_utts, s));
+    // With a few slabs per utterance (the shard of the bench: two) the solve sums them itself and
+    // this launch -- 26 us of an 87 us stage, mostly launch and tail -- falls away.  Not when the
+    // covariances are tapped, not for PMWF's reference search (pmwf_select_kernel reads Rn back
+    // for BAN), not for long utterances (32 slabs: the parallel reduction is the better one).
+    const bool fuse_reduce = !(taps && (taps->Rs || taps->Rn)) && max_parts <= 4 &&
+                             !(kind == SETK_BF_PMWF && opts->pmwf_ref < 0) &&
+                             !(getenv("SETK_FUSED_REDUCE") && atoi(getenv("SETK_FUSED_REDUCE")) == 0);
+    if (!fuse_reduce) HIP_TRY(h, launch_finalize(fa, n_utts, s));
     OutBuf tap_rs, tap_rn, tap_w;
     if (taps && taps->Rs) {
         rc = stage_out(h, taps->Rs, (size_t)n_utts * kBins * C * C * sizeof(float2), &tap_rs);
@@ -2085,6 +2093,9 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     sa.rank1 = opts->rank1;
     sa.pmwf_ref = opts->pmwf_ref;
     sa.pmwf_beta = opts->pmwf_beta;
+    sa.partials = fuse_reduce ? d_part : nullptr;
+    sa.utts = d_uds;
+    sa.num_scale = fa.num_scale;
     if (kind == SETK_BF_PMWF && opts->pmwf_ref < 0) {
         sa.snr_acc =
             static_cast<double*>(arena_alloc(h, (size_t)n_utts * kBins * C * 2 * sizeof(double)));

@@ -102,6 +102,12 @@ struct SolveArgs {
     int planes;           // planes per utterance in covar
     int kind, flags, rank1, pmwf_ref;
     float pmwf_beta;
+    // fused partial reduction (enhance_batch with few slabs per utterance and no covariance
+    // taps): the solve sums pass 1's partial slabs itself, exactly as covar_finalize_kernel
+    // would have (same order, same float32 expressions), and that launch falls away
+    const float* partials;  // null: read `covar`
+    const UttDesc* utts;
+    float num_scale;
 };
 
 struct Pass2Args {

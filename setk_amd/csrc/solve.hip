@@ -492,6 +492,27 @@ __global__ __launch_bounds__(64, (C > 8) ? 1 : SETK_SOLVE_WAVES) void solve_kern
     // ---- column j of a Hermitian matrix from the packed planes (pair `which`:
     // 0 speech, 1 noise, 2 observation) ----
     const float* base = a.covar + (size_t)u * a.planes * pitch + f;
+    // fused reduction of pass 1's partial slabs (covar_finalize_kernel's sums and scales,
+    // evaluated here: same order over the slabs, same float32 expressions)
+    const bool fused = a.partials != nullptr;
+    const int planes_in = 4 * NP + 2;
+    const size_t slab = (size_t)planes_in * pitch;
+    const float* P = nullptr;
+    int nparts = 0;
+    float scale_of[3] = {0.f, 0.f, 0.f};
+    if (fused) {
+        const UttDesc ud = a.utts[u];
+        P = a.partials + (size_t)ud.part0 * slab + f;
+        nparts = ud.nparts;
+        float den0 = 0.f, den1 = 0.f;
+        for (int p = 0; p < nparts; ++p) {
+            den0 += P[p * slab + (size_t)(4 * NP + 0) * pitch];
+            den1 += P[p * slab + (size_t)(4 * NP + 1) * pitch];
+        }
+        scale_of[0] = a.num_scale / fmaxf(den0, 1e-6f);
+        scale_of[1] = a.num_scale / fmaxf(den1, 1e-6f);
+        scale_of[2] = a.num_scale / fmaxf((float)ud.num_frames, 1e-6f);
+    }
     bool finite = true;
     auto load_col = [&](int which, cd (&m)[C]) {
 #pragma unroll
@@ -501,8 +522,27 @@ __global__ __launch_bounds__(64, (C > 8) ? 1 : SETK_SOLVE_WAVES) void solve_kern
                 const int lo = i < j ? i : j, hi = i < j ? j : i;
                 const int e = pair_index(lo, hi, C);
                 const double sgn = (i <= j) ? 1.0 : -1.0;  // (i,j) stored for i<=j
-                const float re = base[(size_t)((2 * which + 0) * NP + e) * pitch];
-                const float im = base[(size_t)((2 * which + 1) * NP + e) * pitch];
+                float re, im;
+                if (!fused) {
+                    re = base[(size_t)((2 * which + 0) * NP + e) * pitch];
+                    im = base[(size_t)((2 * which + 1) * NP + e) * pitch];
+                } else if (which < 2) {
+                    float ar = 0.f, ai = 0.f;
+                    for (int p = 0; p < nparts; ++p) {
+                        ar += P[p * slab + (size_t)((2 * which + 0) * NP + e) * pitch];
+                        ai += P[p * slab + (size_t)((2 * which + 1) * NP + e) * pitch];
+                    }
+                    re = ar * scale_of[which];
+                    im = ai * scale_of[which];
+                } else {  // Ry: the speech and noise numerators of every slab, over the frame count
+                    float ar = 0.f, ai = 0.f;
+                    for (int p = 0; p < nparts; ++p) {
+                        ar += P[p * slab + (size_t)(0 * NP + e) * pitch] + P[p * slab + (size_t)(2 * NP + e) * pitch];
+                        ai += P[p * slab + (size_t)(1 * NP + e) * pitch] + P[p * slab + (size_t)(3 * NP + e) * pitch];
+                    }
+                    re = ar * scale_of[2];
+                    im = ai * scale_of[2];
+                }
                 m[i] = make_double2(re, (i == j) ? 0.0 : sgn * im);
                 finite = finite && isfinite(re) && isfinite(im);
             }

@@ -379,3 +379,34 @@ def test_real_recordings_with_the_reference_masks(ctx, name, kind):
         bar = 3.0 * rms(moved, ref) / rms(ref)
     print(f"[real {name}, {kind}] vs oracle {err:.3g} (bar {bar:.3g})")
     assert err < bar
+
+
+@pytest.mark.parametrize("kind", ["mvdr", "gevd", "mpdr", "mpdr-whiten", "pmwf-1"])
+def test_fused_partial_reduction_equals_the_finalize_kernel(ctx, kind):
+    """With few partial slabs per utterance the solve sums pass 1's slabs itself
+    (covar_finalize_kernel's launch falls away); SETK_FUSED_REDUCE=0 keeps the separate kernel.
+    Same sums, same order, same float32 expressions: the waveforms are equal bit for bit."""
+    import os
+    from setk_amd import _ffi
+    outs = []
+    for sw in (None, "0"):
+        if sw is None:
+            os.environ.pop("SETK_FUSED_REDUCE", None)
+        else:
+            os.environ["SETK_FUSED_REDUCE"] = sw
+        try:
+            utts, masks = [], []
+            for i, (C, N) in enumerate([(8, 40000), (8, 9000)]):
+                mix, sp, nz = o.synth_utterance(300 + i, C, N, return_parts=True)
+                utts.append(mix)
+                masks.append(o.irm_mask(sp, nz))
+            opts = _ffi.BfOpts(flags=_ffi.FLAG_CLAMP_MASK, **KINDS[kind])
+            wavs, st = run_batch(ctx, opts, utts, masks)
+            assert st == [0, 0]
+            outs.append(wavs)
+        finally:
+            os.environ.pop("SETK_FUSED_REDUCE", None)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    ref = o.enhance_utterance(utts[0], masks[0], kind=kind, gauge=True)
+    assert rms(outs[0][0], ref) / rms(ref) < 1e-3
