@@ -41,8 +41,10 @@ SD cd zdiv(cd a, cd b) {
     return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
 }
 SD double zabs2(cd a) { return a.x * a.x + a.y * a.y; }
-// lanes per problem: 8 for C <= 8, 16 for 8 < C <= 16
-template <int C> struct Grp { static constexpr int W = (C > 8) ? 16 : 8; };
+// lanes per problem: 4 for C <= 4 (sixteen problems per wavefront: with 8 lanes half of them
+// idled through every step of a 4-channel solve -- configs[1]: 500 utterances x 257 bins),
+// 8 for C <= 8, 16 for 8 < C <= 16
+template <int C> struct Grp { static constexpr int W = (C > 8) ? 16 : (C > 4) ? 8 : 4; };
 template <int W>
 SD cd zshfl(cd v, int src) { return make_double2(__shfl(v.x, src, W), __shfl(v.y, src, W)); }
 
@@ -111,10 +113,12 @@ SD void jacobi_pevd(cd (&g)[C], int j, cd (&out)[C], double& lam, int& noconv) {
         rot |= jacobi_round<C, 1>(g, j, floor2);
         rot |= jacobi_round<C, 2>(g, j, floor2);
         rot |= jacobi_round<C, 3>(g, j, floor2);
-        rot |= jacobi_round<C, 4>(g, j, floor2);
-        rot |= jacobi_round<C, 5>(g, j, floor2);
-        rot |= jacobi_round<C, 6>(g, j, floor2);
-        rot |= jacobi_round<C, 7>(g, j, floor2);
+        if constexpr (W >= 8) {
+            rot |= jacobi_round<C, 4>(g, j, floor2);
+            rot |= jacobi_round<C, 5>(g, j, floor2);
+            rot |= jacobi_round<C, 6>(g, j, floor2);
+            rot |= jacobi_round<C, 7>(g, j, floor2);
+        }
         if constexpr (W == 16) {
             rot |= jacobi_round<C, 8>(g, j, floor2);
             rot |= jacobi_round<C, 9>(g, j, floor2);
@@ -225,7 +229,7 @@ SD bool jacobi_round_f32(float2 (&g)[C], int j, float floor2) {
 template <int C>
 SD void pevd_mixed(const cd (&a)[C], int j, cd (&out)[C], double& lam, int& noconv) {
     constexpr int W = Grp<C>::W;
-    if constexpr (W != 8 || SETK_SOLVE_FP64_ONLY) {
+    if constexpr (W > 8 || SETK_SOLVE_FP64_ONLY) {
         cd g[C];
 #pragma unroll
         for (int i = 0; i < C; ++i) g[i] = a[i];
@@ -249,16 +253,18 @@ SD void pevd_mixed(const cd (&a)[C], int j, cd (&out)[C], double& lam, int& noco
             for (int i = 0; i < C; ++i) mm = fmaf(g[i].x, g[i].x, fmaf(g[i].y, g[i].y, mm));
             mm = fmaxf(mm, fxor<1>(mm));
             mm = fmaxf(mm, fxor<2>(mm));
-            mm = fmaxf(mm, fxor<4>(mm));
+            if constexpr (W == 8) mm = fmaxf(mm, fxor<4>(mm));
             const float floor2 = 1e-12f * mm * mm;  // (~(8 eps32 |g_max|^2)^2)
             bool rot = false;
             rot |= jacobi_round_f32<C, 1>(g, j, floor2);
             rot |= jacobi_round_f32<C, 2>(g, j, floor2);
             rot |= jacobi_round_f32<C, 3>(g, j, floor2);
-            rot |= jacobi_round_f32<C, 4>(g, j, floor2);
-            rot |= jacobi_round_f32<C, 5>(g, j, floor2);
-            rot |= jacobi_round_f32<C, 6>(g, j, floor2);
-            rot |= jacobi_round_f32<C, 7>(g, j, floor2);
+            if constexpr (W == 8) {
+                rot |= jacobi_round_f32<C, 4>(g, j, floor2);
+                rot |= jacobi_round_f32<C, 5>(g, j, floor2);
+                rot |= jacobi_round_f32<C, 6>(g, j, floor2);
+                rot |= jacobi_round_f32<C, 7>(g, j, floor2);
+            }
             done = !__any(rot);
         }
         // (no float64 fallback in this kernel: its working set alone costs a wave per SIMD; sweep
@@ -760,7 +766,7 @@ __global__ __launch_bounds__(64, (C > 8) ? 1 : SETK_SOLVE_WAVES) void solve_kern
 
 hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
     const long n_prob = (long)a.n_utts * a.num_bins;
-    const int pw = a.num_channels > 8 ? 4 : 8;  // problems per wavefront
+    const int pw = a.num_channels > 8 ? 4 : (a.num_channels > 4 ? 8 : 16);  // problems per wavefront (64 / Grp<C>::W)
     const int blocks = (int)((n_prob + pw - 1) / pw);
     const int pitch = (a.num_bins == kBins) ? kBinsPad : ((a.num_bins + 7) / 8) * 8;
     // L only: MVDR, MPDR; + Wk: the reduced-pencil kinds; + Rs, Rn: PMWF SNR search
@@ -771,7 +777,7 @@ hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
     // without asking
 #define SETK_LAUNCH(c, k)                                                              \
     do {                                                                               \
-        const size_t lds = (size_t)lds_mats * pw * c * c * sizeof(cd) + 64;            \
+        const size_t lds = (size_t)lds_mats * pw * c * c * sizeof(cd) + pw * sizeof(double); \
         if (lds > (64u << 10)) {                                                       \
             hipError_t e = hipFuncSetAttribute(                                        \
                 reinterpret_cast<const void*>(solve_kernel<c, k>),                     \
