@@ -619,12 +619,12 @@ def other_configs(torch, _ffi, synth, dev, pmc_args=None, rates=None):
         ap, mp, wp = ([t.data_ptr() for t in x] for x in (audio, masks, waves))
         ns = [N] * U
         opts = _ffi.BfOpts(kind=kind, flags=_ffi.FLAG_CLAMP_MASK, pmwf_beta=0.0, pmwf_ref=-1, rank1=0)
-        for _ in range(3):
+        for _ in range(40):   # (steady clocks, as the headline's warm-up)
             ctx.enhance_batch(opts, C, ap, ns, mp, None, wp, want_status=False)
         st = ctx.enhance_batch(opts, C, ap, ns, mp, None, wp, want_status=True)
         ctx.set_profiling(True)
         torch.cuda.synchronize()
-        k = 10
+        k = 100
         t0 = time.perf_counter()
         for _ in range(k):
             ctx.enhance_batch(opts, C, ap, ns, mp, None, wp, want_status=False)
@@ -667,10 +667,11 @@ def other_configs(torch, _ffi, synth, dev, pmc_args=None, rates=None):
         torch.cuda.synchronize()
 
     cg_step()
+    cg_step()
     t0 = time.perf_counter()
-    for _ in range(3):
+    for _ in range(6):
         cg_step()
-    dt = (time.perf_counter() - t0) / 3
+    dt = (time.perf_counter() - t0) / 6
     res["configs[4] 6-ch CGMM->MVDR"] = {
         "workload": "6-ch 30 s x 125 utterances, CGMM (K = 2, 20 EM iterations) -> MVDR, "
                     "inputs resident in HBM",
