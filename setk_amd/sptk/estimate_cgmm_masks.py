@@ -69,9 +69,27 @@ def run(args):
     num_done = 0
     with NumpyWriter(args.dst_dir) as writer:
         dst_dir = Path(args.dst_dir)
-        for key in shard.assign_by_duration(reader):
-            if (dst_dir / f"{key}.npy").exists():
-                logger.info(f"Training utterance {key} ... Skip")
+        mine = shard.assign_by_duration(reader)
+        # The K > 2 start comes out of ONE generator that the reference advances utterance by
+        # utterance in table order (estimate_cgmm_masks.py:28, cluster.py:429-434).  With the
+        # table dealt over several ranks every rank walks the whole table and DISCARDS the draws
+        # of the utterances that are not its own (K x F x T doubles each, T from the wave
+        # header), so an 8-GPU run starts every utterance exactly as the one-process run does.
+        random_start = args.num_classes != 2 and not args.init_mask
+        walk = list(reader.index_keys) if (random_start and shard.world > 1) else mine
+        own = set(mine)
+        num_bins = n_fft // 2 + 1
+        # what exists is decided once, before any rank writes: the walk of every rank must skip
+        # the same utterances (the reference does not draw for an utterance it skips, :38)
+        existing = {key for key in walk if (dst_dir / f"{key}.npy").exists()}
+        shard.barrier()
+        for key in walk:
+            if key in existing:
+                if key in own:
+                    logger.info(f"Training utterance {key} ... Skip")
+                continue
+            if key not in own:
+                np.random.uniform(size=args.num_classes * num_bins * _num_frames(reader, key, args, n_fft))
                 continue
             stft = reader[key]
             if stft.ndim == 2:
@@ -96,6 +114,18 @@ def run(args):
     if shard.rank == 0:
         logger.info(f"Train {num_done:d} utterances over {len(reader):d}")
     shard.close()
+
+
+def _num_frames(reader, key, args, n_fft):
+    """STFT frames of an utterance from its wave header (librosa's count: 1 + N // hop with
+    centring, 1 + (N - n_fft) // hop without); pipes and globs are decoded for their length."""
+    n = reader.peek_nsamps(key)
+    if n is None:
+        samps = reader.read(key)
+        n = samps.shape[-1]
+    if args.center:
+        return 1 + n // args.frame_hop
+    return 1 + (n - n_fft) // args.frame_hop
 
 
 def run_batched(args, shard):

@@ -597,3 +597,44 @@ def test_cosine_windows_equal_scipy_bit_for_bit():
                           (scipy.signal.windows.hann(512, sym=False)**0.5).astype(np.float32))
     assert np.array_equal(stft_window("bartlett", 400),
                           scipy.signal.get_window("bartlett", 400, fftbins=True).astype(np.float32))
+
+
+def test_cgmm_seeded_start_is_independent_of_the_sharding(tmp_path):
+    """--num-classes 3 under several ranks: every rank walks the table and discards the draws of
+    the utterances that are not its own, so each utterance starts as in the reference's
+    one-process run.  Checked on the host logic alone: the frame count taken from the wave
+    header equals the oracle's STFT frame count, and discarding K x F x T uniforms leaves the
+    legacy generator where drawing the K x F x T array would have."""
+    import argparse
+    import scipy.io.wavfile
+    from oracle import np_oracle as o
+    from setk_amd.libs.data_handler import WaveReader
+    from setk_amd.sptk.estimate_cgmm_masks import _num_frames
+    td = str(tmp_path)
+    lens = [16000, 5000, 12345, 700, 513]
+    with open(f"{td}/wav.scp", "w") as f:
+        for i, n in enumerate(lens):
+            scipy.io.wavfile.write(f"{td}/u{i}.wav", 16000, np.zeros((n, 2), np.int16))
+            f.write(f"u{i} {td}/u{i}.wav\n")
+    reader = WaveReader(f"{td}/wav.scp")
+    for center in (True, False):
+        for frame_len, hop in ((512, 256), (400, 160), (512, 128)):
+            args = argparse.Namespace(center=center, frame_hop=hop, frame_len=frame_len)
+            n_fft = 512
+            for i, n in enumerate(lens):
+                if not center and n < n_fft:
+                    continue
+                want = o.forward_stft(np.zeros(n, np.float32), frame_len=frame_len, frame_hop=hop, center=center,
+                                      window="hann", round_power_of_two=True, transpose=False).shape[1]
+                assert _num_frames(reader, f"u{i}", args, n_fft) == want, (center, frame_len, hop, n)
+    K, F = 3, 257
+    frames = [63, 20, 49]
+    np.random.seed(777)
+    seq = [np.random.uniform(size=[K, F, t]) for t in frames]           # the one-process run
+    for owner in range(3):                                              # a rank that owns one utterance
+        np.random.seed(777)
+        for j, t in enumerate(frames):
+            if j == owner:
+                assert np.array_equal(np.random.uniform(size=[K, F, t]), seq[j])
+            else:
+                np.random.uniform(size=K * F * t)
