@@ -34,6 +34,8 @@ def main():
         # (seed 11, case 29 of the first version: 5 channels, 5 frames, cond(Rn) up to 8e8)
         n_min = (C + 4) * hop + (0 if center else 512)
         lens = [int(rng.integers(max(600, n_min), 30000)) for _ in range(n_utts)]
+        if os.environ.get("STRESS_ONLY") and case != int(os.environ["STRESS_ONLY"]):
+            continue  # (the draws above keep the sequence: one case of a sweep can be re-run alone)
         ctx = _ffi.Context(0)
         ctx.stft_plan(512, hop, 512, center)
         kw = dict(frame_len=512, frame_hop=hop, center=center, window="hann")
@@ -62,7 +64,7 @@ def main():
             w = w.cpu().numpy()
             assert w.shape == r.shape, (w.shape, r.shape)
             e = float(np.sqrt(np.mean((w - r) ** 2)) / max(np.sqrt(np.mean(r ** 2)), 1e-12))
-            if e > 2e-3 and kind == "pmwf-0" and C > 1:
+            if e > 1e-3 and kind == "pmwf-0" and C > 1:
                 # pmwf_ref = -1 takes the argmax of per-channel output SNRs that can agree to
                 # 1e-6 (libs/beamformer.py:645-653): a near tie legitimately resolves either way
                 for ref in range(C):
@@ -70,7 +72,7 @@ def main():
                     ea = float(np.sqrt(np.mean((w - alt) ** 2)) / max(np.sqrt(np.mean(alt ** 2)), 1e-12))
                     if ea < e:
                         e, note = ea, f"   (utt {i}: reference-channel near tie, matches pmwf_ref={ref})"
-            if e > 2e-3:
+            if e > 1e-3:
                 # is the case itself ill-conditioned?  the oracle on an input perturbed at the
                 # float32 rounding level
                 pr = np.random.default_rng(1)
@@ -79,15 +81,15 @@ def main():
                 sens = float(np.sqrt(np.mean((alt - r) ** 2)) / max(np.sqrt(np.mean(r ** 2)), 1e-12))
                 note += f"   (utt {i}: the oracle moves by {sens:.1e} under a 1e-7 input perturbation)"
                 if sens > 0.1 * e:
-                    e = min(e, 1.9e-3)  # not a statement about the device
+                    e = min(e, 0.99e-3)  # not a statement about the device
             errs.append(e)
         worst = max(worst, max(errs))
-        flag = "" if max(errs) < 2e-3 and not any(st) else "   <-- CHECK"
+        flag = "" if max(errs) < 1e-3 and not any(st) else "   <-- CHECK"
         print(f"case {case:3d} C={C} hop={hop} center={int(center)} {kind:6s} lens={lens} "
               f"status={st} max rel rms {max(errs):.2e}{flag}{note}")
         ctx.close()
     print(f"worst relative rms over {n_cases} cases: {worst:.3e}")
-    return 0 if worst < 2e-3 else 1
+    return 0 if worst < 1e-3 else 1
 
 
 if __name__ == "__main__":
