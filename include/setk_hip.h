@@ -83,6 +83,20 @@ extern "C" {
 #define SETK_FLAG_NO_GAUGE 0x8   /* leave eigenvector phase as computed       */
 #define SETK_FLAG_OUT_PCM16 0x10 /* enhance_batch writes int16 PCM, not f32   */
 #define SETK_FLAG_NO_RENORM 0x20 /* apply_weights_batch: inverse_stft(norm=None) */
+/* Reference failure semantics (setk_weights, setk_enhance_batch; CLI --strict-reference true).
+ * The reference solves Rn x = b with numpy.linalg.solve (LAPACK ?gesv: LU with partial pivoting
+ * in the matrix's own precision, complex64) and raises LinAlgError("Singular matrix") only on an
+ * EXACT zero pivot (libs/beamformer.py:536 MVDR, :568 MPDR on Ry, :646 PMWF; the CLI logs and
+ * skips the utterance, apply_adaptive_beamformer.py:170-172); its GEV never raises (hegvd's
+ * refusal is caught and scipy.linalg.eig takes over, libs/beamformer.py:54-59).  With this flag
+ * the same decision is taken on the device: a complex64 LU with partial pivoting (cabs1 pivot
+ * search, no fused multiply-adds) of the matrix the reference would hand to solve, per bin, and
+ * SETK_NUM_SINGULAR where a pivot column is exactly zero -- a duplicated / silent / power-of-two
+ * scaled channel, an all-zero noise covariance; GEV goes through even on an all-zero Rn (as the
+ * pencil (Rs, I)).  Without the flag (the default) such input is regularised (floored / loaded
+ * Cholesky) and only an all-zero or non-finite covariance is refused.  The weights of the bins
+ * that pass are the same in both modes. */
+#define SETK_FLAG_STRICT_REFERENCE 0x40
 
 typedef struct setk_context* setk_handle_t;
 

@@ -208,14 +208,37 @@ def fix_gauge_evd(vec):
 def fix_gauge_gev(vec, Rn):
     """Declared gauge for the pencil (Rs, Rn): with Rn = L L^H (L lower),
     y = L^H v has a real non-negative component 0.  y0 = conj(L00)*v0 + ...
-    only column 0 of L^H row 0 -> y0 = sum_k conj(L[k,0]) v[k]."""
+    only column 0 of L^H row 0 -> y0 = sum_k conj(L[k,0]) v[k].
+
+    A bin whose Rn is not positive definite to float64 has no such L.  The reference does
+    NOT raise there (hegvd's refusal is caught and scipy.linalg.eig answers,
+    libs/beamformer.py:54-59; verified on its own recordings with the unmodified modules:
+    tests/golden/ref_skipset.json) and neither may the gauge: such a bin gets the plain
+    rule (component 0 of v real, non-negative) -- its vector is QZ's answer to a singular
+    pencil, i.e. noise, and no comparison is made there (gev_fallback_bins)."""
     out = np.empty_like(vec)
     for f in range(vec.shape[0]):
-        L = np.linalg.cholesky(Rn[f])
-        y0 = np.vdot(L[:, 0], vec[f])  # (L^H v)_0
+        try:
+            L = np.linalg.cholesky(Rn[f])
+            y0 = np.vdot(L[:, 0], vec[f])  # (L^H v)_0
+        except np.linalg.LinAlgError:
+            y0 = vec[f, 0]
         mag = abs(y0)
         out[f] = vec[f] * (np.conj(y0) / mag if mag > 0 else 1)
     return out
+
+
+def gev_fallback_bins(Rs, Rn):
+    """Bins where scipy.linalg.eigh(Rs[f], Rn[f]) refuses (Rn not positive definite for
+    LAPACK's potrf) and the reference's scipy.linalg.eig fallback answers
+    (libs/beamformer.py:52-59): their vectors are rounding artefacts."""
+    bad = []
+    for f in range(Rs.shape[0]):
+        try:
+            scipy.linalg.eigh(Rs[f], Rn[f])
+        except np.linalg.LinAlgError:
+            bad.append(f)
+    return np.asarray(bad, dtype=int)
 
 
 def solve_pevd(Rs, Rn=None, gauge=False):
@@ -663,6 +686,44 @@ def synth_utterance(index, num_channels, num_samples, return_parts=False):
             np.float32)
     return mix
 
+
+
+SKIPSET_KINDS = {
+    # name -> enhance_utterance keywords (the beamformers of apply_adaptive_beamformer.py)
+    "mvdr": dict(kind="mvdr"), "gevd": dict(kind="gevd"), "mpdr": dict(kind="mpdr"),
+    "mpdr-whiten": dict(kind="mpdr-whiten"), "pmwf-0": dict(kind="pmwf-0"),
+    "pmwf-0-eig": dict(kind="pmwf-0", rank1_appro="eig"),
+    "pmwf-0-gev": dict(kind="pmwf-0", rank1_appro="gev"),
+}
+
+
+def skipset_cases():
+    """Inputs on which the reference's numpy.linalg.solve does / does not raise
+    (tests/golden/ref_skipset.json holds what the UNMODIFIED reference did with each:
+    oracle/make_golden.py gen_skipset).  name -> (samps C x N, mask T x F).  Structurally
+    singular: the elimination cancels exactly (duplicated, silent, power-of-two scaled
+    channel; all-zero noise covariance; silence).  Singular to rounding only: a channel that
+    is 0.3 x another or the sum of two others, a noise mask with fewer frames than channels."""
+    mix, sp, nz = synth_utterance(3, 4, 32000, return_parts=True)
+    mask = irm_mask(sp, nz)
+    out = {}
+    out["plain"] = (mix, mask)
+    out["ones-mask"] = (mix, np.ones_like(mask))
+    out["mask-above-one"] = (mix, np.ones_like(mask) * 1.5)
+    d = mix.copy(); d[1] = d[0]
+    out["dup-channel"] = (d, mask)
+    d = mix.copy(); d[3] = 0
+    out["zero-channel"] = (d, mask)
+    d = mix.copy(); d[2] = 2 * d[0]
+    out["channel-x2"] = (d, mask)
+    d = mix.copy(); d[2] = np.float32(0.3) * d[0]
+    out["channel-x0.3"] = (d, mask)
+    d = mix.copy(); d[2] = d[0] + d[1]
+    out["sum-channel"] = (d, mask)
+    m = np.ones_like(mask); m[:3] = 0
+    out["noise-in-3-frames"] = (mix, m)
+    out["silence"] = (np.zeros_like(mix), mask)
+    return out
 
 
 def synth_scene(index, num_channels, num_samples, return_parts=False):

@@ -33,6 +33,7 @@ BF_MVDR, BF_GEVD, BF_PMWF, BF_MPDR, BF_MPDR_WHITEN = 0, 1, 2, 3, 4
 RANK1_NONE, RANK1_EIG, RANK1_GEV = 0, 1, 2
 FLAG_BAN, FLAG_CLAMP_MASK, FLAG_POST_MASK, FLAG_NO_GAUGE, FLAG_OUT_PCM16 = 1, 2, 4, 8, 16
 FLAG_NO_RENORM = 32
+FLAG_STRICT_REFERENCE = 64  # numpy.linalg.solve's exact-zero-pivot refusals (setk_hip.h)
 CGMM_UPDATE_ALPHA = 1
 
 

@@ -19,6 +19,15 @@ struct PairSplit {
     static constexpr int NO = (C * (C - 1) / 2 + 1) / 2;   // off-diagonal pairs per half (max)
 };
 
+// x_i conj(x_j) with the SAME expression for its real part as the diagonal's |x_i|^2 below:
+// for equal operands (a duplicated channel) the off-diagonal sum is then bit for bit the
+// diagonal one, and SETK_FLAG_STRICT_REFERENCE's elimination (solve.hip, lu_refusal_kernel)
+// cancels exactly where the reference's does.  Same two instructions per part as the
+// contracted a.x b.x + a.y b.y.
+SETK_DEV cf cmulc_cov(cf a, cf b) {
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y)));
+}
+
 template <int C, int H>
 SETK_DEV void accumulate_half(const cf (&x)[C], float ws, float wn, float* ds, float* dn, cf* os,
                               cf* on) {
@@ -34,7 +43,7 @@ SETK_DEV void accumulate_half(const cf (&x)[C], float ws, float wn, float* ds, f
 #pragma unroll
         for (int j = i + 1; j < C; ++j) {
             if ((k & 1) == H) {
-                const cf p = cmulc(x[i], x[j]);
+                const cf p = cmulc_cov(x[i], x[j]);
                 os[k / 2].x = fmaf(ws, p.x, os[k / 2].x);
                 on[k / 2].x = fmaf(wn, p.x, on[k / 2].x);
                 os[k / 2].y = fmaf(ws, p.y, os[k / 2].y);

@@ -335,7 +335,7 @@ SD void fix_gauge(cd (&v)[C]) {
 // at eps_f32 * max diag(M) (the noise level of the float32-accumulated input);
 // only an all-zero / non-finite / negative-diagonal matrix reports 1.
 template <int C>
-SD int chol_lds(const cd (&col)[C], cd* L, double* piv, int j) {
+SD int chol_lds(const cd (&col)[C], cd* L, double* piv, int j, bool zero_is_identity = false) {
     // col[i] = M[i][j] (lane j owns column j of the Hermitian M), so the row
     // element M[j][k] is conj(col[k])
     double diag = 0.0;
@@ -345,6 +345,16 @@ SD int chol_lds(const cd (&col)[C], cd* L, double* piv, int j) {
     double scale = diag;
 #pragma unroll
     for (int s = 1; s < Grp<C>::W; s <<= 1) scale = fmax(scale, __shfl_xor(scale, s, Grp<C>::W));
+    if (zero_is_identity && scale == 0.0) {
+        // SETK_FLAG_STRICT_REFERENCE, GEV: the reference goes through on an all-zero Rn
+        // (hegvd refuses, scipy.linalg.eig takes over: libs/beamformer.py:54-59); the pencil
+        // (Rs, I) stands in for what QZ makes of (Rs, 0)
+#pragma unroll
+        for (int k = 0; k < C; ++k)
+            if (j >= k && j < C) L[k * C + j] = make_double2(j == k ? 1.0 : 0.0, 0.0);
+        __syncthreads();
+        return 0;
+    }
     const int bad0 = !(scale > 0.0);
     int bad = bad0;
     const double floor_piv = kEpsF32 * scale;
@@ -570,7 +580,8 @@ __global__ __launch_bounds__(64, (C > 8) ? 1 : SETK_SOLVE_WAVES) void solve_kern
         {
             cd rn[C];
             load_col(1, rn);
-            st_sing |= chol_lds<C>(rn, L, piv, j);
+            st_sing |= chol_lds<C>(rn, L, piv, j,
+                                   kind == SETK_BF_GEVD && (a.flags & SETK_FLAG_STRICT_REFERENCE) != 0);
         }
         cd rs[C];
         load_col(0, rs);
@@ -764,6 +775,137 @@ __global__ __launch_bounds__(64, (C > 8) ? 1 : SETK_SOLVE_WAVES) void solve_kern
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// SETK_FLAG_STRICT_REFERENCE: where would numpy.linalg.solve have raised?
+//
+// The reference hands the noise (MVDR libs/beamformer.py:536, PMWF :646) or observation
+// (MPDR :568) covariance to numpy.linalg.solve: LAPACK ?gesv, i.e. an LU with partial
+// pivoting in the matrix's own precision (complex64: the covariances are complex64 einsums),
+// which reports "singular" only when the pivot search finds an EXACTLY zero column
+// (?getf2: `if A(jp, j) != 0` else info = j); numpy turns that into LinAlgError for the whole
+// stack and the CLI skips the utterance (apply_adaptive_beamformer.py:170-172).  On rounded
+// data that happens for structurally singular input -- a duplicated, silent or power-of-two
+// scaled channel, an all-zero covariance -- where the elimination cancels exactly; a
+// covariance that is merely rank deficient to rounding (few mask frames, a channel that is
+// 0.3 x another, a real 16-channel recording of three sources) goes through on noise-level
+// pivots, in the reference and here.
+//
+// One thread per (utterance, bin): the same elimination in float32 without fused
+// multiply-adds (right-looking, rows swapped, pivot = first maximum of |re| + |im| as
+// icamax), SETK_NUM_SINGULAR when a pivot column is exactly zero.  The weights are not
+// touched: they stay the float64 Cholesky's.  Which bin cancels exactly is rounding luck
+// (LAPACK builds differ in their operation order as well); what is reproduced, and tested
+// against the unmodified reference (tests/golden/ref_skipset.json), is the decision per
+// utterance.
+// ---------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(64) void lu_refusal_kernel(SolveArgs a, int pitch, int which) {
+    const int C = a.num_channels, F = a.num_bins;
+    const int NP = npairs(C);
+    const long n_prob = (long)a.n_utts * F;
+    const long prob = (long)blockIdx.x * 64 + threadIdx.x;
+    if (prob >= n_prob) return;
+    const int u = (int)(prob / F), f = (int)(prob % F);
+    float ar[kMaxChannels16][kMaxChannels16], ai[kMaxChannels16][kMaxChannels16];
+    const bool fused = a.partials != nullptr;
+    const size_t slab = (size_t)(4 * NP + 2) * pitch;
+    const float* base = a.covar + (size_t)u * a.planes * pitch + f;
+    const float* P = nullptr;
+    int nparts = 0;
+    float scale = 0.f;
+    if (fused) {
+        const UttDesc ud = a.utts[u];
+        P = a.partials + (size_t)ud.part0 * slab + f;
+        nparts = ud.nparts;
+        float den = 0.f;
+        if (which < 2) {
+            for (int p = 0; p < nparts; ++p) den += P[p * slab + (size_t)(4 * NP + which) * pitch];
+        } else {
+            den = (float)ud.num_frames;
+        }
+        scale = a.num_scale / fmaxf(den, 1e-6f);
+    }
+    for (int i = 0; i < C; ++i)
+        for (int k = i; k < C; ++k) {
+            const int e = pair_index(i, k, C);
+            float re, im;
+            if (!fused) {
+                re = base[(size_t)((2 * which + 0) * NP + e) * pitch];
+                im = base[(size_t)((2 * which + 1) * NP + e) * pitch];
+            } else {
+                // the sums of load_col (solve_kernel), same order, same float32 expressions
+                float sr = 0.f, si = 0.f;
+                for (int p = 0; p < nparts; ++p) {
+                    if (which < 2) {
+                        sr += P[p * slab + (size_t)((2 * which + 0) * NP + e) * pitch];
+                        si += P[p * slab + (size_t)((2 * which + 1) * NP + e) * pitch];
+                    } else {
+                        sr += P[p * slab + (size_t)(0 * NP + e) * pitch] + P[p * slab + (size_t)(2 * NP + e) * pitch];
+                        si += P[p * slab + (size_t)(1 * NP + e) * pitch] + P[p * slab + (size_t)(3 * NP + e) * pitch];
+                    }
+                }
+                re = sr * scale;
+                im = si * scale;
+            }
+            // An imaginary part below the rounding level of its real part is the residue of the
+            // multiply-adds that built the sum (a.y b.x - a.x b.y of EQUAL operands is the rounding
+            // error of one product, not zero).  The reference's einsum carries the same residue
+            // in both triangles of its (not exactly Hermitian) matrix, where it cancels when a
+            // row is eliminated with an equal one; here only the upper triangle exists and the
+            // mirrored residue would have the opposite sign.  Dropping it keeps the rows of a
+            // duplicated (or 2^k-scaled) channel equal, as the reference's are.
+            if (i == k || fabsf(im) <= 8.f * 1.1920929e-07f * fabsf(re)) im = 0.f;
+            ar[i][k] = re;
+            ai[i][k] = im;
+            ar[k][i] = re;
+            ai[k][i] = -im;
+        }
+    bool singular = false;
+    for (int k = 0; k < C && !singular; ++k) {
+        int p = k;
+        float best = fabsf(ar[k][k]) + fabsf(ai[k][k]);
+        for (int i = k + 1; i < C; ++i) {
+            const float v = fabsf(ar[i][k]) + fabsf(ai[i][k]);
+            if (v > best) {
+                best = v;
+                p = i;
+            }
+        }
+        if (best == 0.f) {
+            singular = true;
+            break;
+        }
+        if (p != k)
+            for (int m = 0; m < C; ++m) {
+                const float tr = ar[k][m], ti = ai[k][m];
+                ar[k][m] = ar[p][m];
+                ai[k][m] = ai[p][m];
+                ar[p][m] = tr;
+                ai[p][m] = ti;
+            }
+        const float pr = ar[k][k], pi = ai[k][k];
+        const float d = pr * pr + pi * pi;
+        for (int i = k + 1; i < C; ++i) {
+            // l = a_ik / pivot as a conj(p) / |p|^2: a row that EQUALS the pivot row (or is a power
+            // of two times it) gets l = 1 (2^k) exactly and cancels exactly, in every bin -- the
+            // structural cases do not hang on rounding luck as they do with LAPACK's
+            // multiply-by-reciprocal, which finds them in some bins of the 257 only
+            const float lr = (ar[i][k] * pr + ai[i][k] * pi) / d;
+            const float li = (ai[i][k] * pr - ar[i][k] * pi) / d;
+            for (int m = k + 1; m < C; ++m) {
+                ar[i][m] = ar[i][m] - (lr * ar[k][m] - li * ai[k][m]);
+                ai[i][m] = ai[i][m] - (lr * ai[k][m] + li * ar[k][m]);
+            }
+        }
+    }
+    if (singular) {
+        if (a.bin_status) atomicMax(a.bin_status + prob, SETK_NUM_SINGULAR);
+        if (a.status) atomicMax(a.status + u, SETK_NUM_SINGULAR);
+    }
+}
+#pragma clang fp contract(fast)
+
 hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
     const long n_prob = (long)a.n_utts * a.num_bins;
     const int pw = a.num_channels > 8 ? 4 : (a.num_channels > 4 ? 8 : 16);  // problems per wavefront (64 / Grp<C>::W)
@@ -814,7 +956,18 @@ hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
     }
 #undef SETK_CASE
 #undef SETK_LAUNCH
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if ((a.flags & SETK_FLAG_STRICT_REFERENCE) &&
+        (a.kind == SETK_BF_MVDR || a.kind == SETK_BF_PMWF || a.kind == SETK_BF_MPDR ||
+         a.kind == SETK_BF_MPDR_WHITEN)) {
+        // the matrix the reference's numpy.linalg.solve factors: Rn (MVDR, PMWF), Ry (MPDR)
+        const int which = (a.kind == SETK_BF_MVDR || a.kind == SETK_BF_PMWF) ? 1 : 2;
+        hipLaunchKernelGGL(lu_refusal_kernel, dim3((unsigned)((n_prob + 63) / 64)), dim3(64), 0, s, a,
+                           pitch, which);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 // ---------------------------------------------------------------------------

@@ -173,7 +173,10 @@ class BatchEnhancer(object):
     def __init__(self, beamformer="mvdr", frame_len=512, frame_hop=256, center=True,
                  round_power_of_two=True, window="hann", ban=False, pmwf_ref=-1, rank1_appro="",
                  post_mask=False, vad_proportion=1, pcm16=False, device=None, ctx=None,
-                 max_batch_samples=1 << 28):
+                 max_batch_samples=1 << 28, strict_reference=False):
+        """strict_reference: refuse (status SETK_NUM_SINGULAR -> the CLI's LinAlgError branch)
+        exactly where the reference's numpy.linalg.solve meets an exactly zero pivot
+        (SETK_FLAG_STRICT_REFERENCE, include/setk_hip.h); default: regularise and go through."""
         if beamformer not in BEAMFORMER_KINDS:
             raise ValueError(f"unknown beamformer {beamformer}")
         # no GPU / no library: setk_create fails here, loudly (there is no CPU fallback).
@@ -193,6 +196,8 @@ class BatchEnhancer(object):
             flags |= _ffi.FLAG_POST_MASK
         if pcm16:
             flags |= _ffi.FLAG_OUT_PCM16
+        if strict_reference:
+            flags |= _ffi.FLAG_STRICT_REFERENCE
         self.base_flags = flags
         self.opts_kw = dict(kind=kind, pmwf_beta=beta, pmwf_ref=int(pmwf_ref),
                             rank1=RANK1[rank1_appro])
@@ -312,7 +317,7 @@ class BatchEnhancer(object):
                 ctx.covar(spec, torch.ones_like(ms), C, T, F, Ry)
             w = torch.empty((F, C), dtype=torch.complex64, device=dev)
             status = np.zeros(F, dtype=np.int32)
-            flags = self.base_flags & _ffi.FLAG_BAN
+            flags = self.base_flags & (_ffi.FLAG_BAN | _ffi.FLAG_STRICT_REFERENCE)
             ctx.weights(_ffi.BfOpts(flags=flags, **self.opts_kw), Rs, Rn, Ry, F, C, w, status)
             if status.any():
                 results[i] = (None, int(status.max()))

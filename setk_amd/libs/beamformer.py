@@ -25,6 +25,8 @@ diffuse-field coherence) -- a few kilobytes of float64 host arithmetic per
 direction, kept on the host in the reference's own formulas; applying them to an
 utterance is the device beamformer (setk_beamform / setk_apply_weights_batch).
 """
+import os
+
 import numpy as np
 
 from .. import _ffi
@@ -267,9 +269,19 @@ class CircularSDBeamformer(CircularDSBeamformer):
 
 
 class SupervisedBeamformer(Beamformer):
-    """Base class of the TF-mask based beamformers (reference :237-283)."""
+    """Base class of the TF-mask based beamformers (reference :237-283).
+
+    strict_reference (class or instance attribute, default from SETK_STRICT_REFERENCE=1, else
+    False): raise LinAlgError("Singular matrix") exactly where the reference's
+    numpy.linalg.solve does (SETK_FLAG_STRICT_REFERENCE, include/setk_hip.h); by default a
+    covariance that is singular but not all-zero is regularised and solved."""
     _kind = None
     _wide = False  # reference dtype of the weights (complex128 for GEV)
+    strict_reference = os.environ.get("SETK_STRICT_REFERENCE", "0") not in ("", "0", "false")
+
+    def _mode_flags(self, ban):
+        return (_ffi.FLAG_BAN if ban else 0) | \
+            (_ffi.FLAG_STRICT_REFERENCE if self.strict_reference else 0)
 
     def __init__(self, num_bins):
         super(SupervisedBeamformer, self).__init__()
@@ -285,7 +297,7 @@ class SupervisedBeamformer(Beamformer):
         return compute_covar(obs, target_mask)
 
     def _opts(self, ban=False):
-        return _ffi.BfOpts(kind=self._kind, flags=_ffi.FLAG_BAN if ban else 0, pmwf_beta=0.0,
+        return _ffi.BfOpts(kind=self._kind, flags=self._mode_flags(ban), pmwf_beta=0.0,
                            pmwf_ref=-1, rank1=0)
 
     def _device_weight(self, Rs, Rn, Ry=None, ban=False):
@@ -341,7 +353,7 @@ class PmwfBeamformer(SupervisedBeamformer):
     def _opts(self, ban=False):
         rank1 = {"eig": _ffi.RANK1_EIG, "gev": _ffi.RANK1_GEV}.get(self.rank1_appro,
                                                                    _ffi.RANK1_NONE)
-        return _ffi.BfOpts(kind=self._kind, flags=_ffi.FLAG_BAN if ban else 0,
+        return _ffi.BfOpts(kind=self._kind, flags=self._mode_flags(ban),
                            pmwf_beta=float(self.beta), pmwf_ref=int(self.ref_channel),
                            rank1=rank1)
 

@@ -61,6 +61,12 @@ _OPTIONS = (
                                     help="If >= 64, using online beamformer instead")),
     (("--online.channels",), dict(default=4, type=int, dest="channels",
                                   help="Number of channels available")),
+    (("--strict-reference",), dict(default=False, type=strtobool,
+                                   help="[setk_amd] skip an utterance exactly where the reference's "
+                                        "numpy.linalg.solve raises LinAlgError (an exactly zero LU pivot in "
+                                        "complex64: duplicated / silent channel, all-zero noise covariance); "
+                                        "default: such covariances are regularised and the utterance is "
+                                        "enhanced (INTEGRATION.md)")),
     (("--batch-utts",), dict(default=32, type=int,
                              help="[setk_amd] utterances enhanced per GPU batch")),
     (("--device",), dict(default=-1, type=int,
@@ -295,7 +301,8 @@ def run_offline(args, shard):
                            round_power_of_two=bool(args.round_power_of_two), window=args.window,
                            ban=bool(args.ban), pmwf_ref=args.pmwf_ref,
                            rank1_appro=args.rank1_appro, post_mask=bool(args.mask),
-                           vad_proportion=args.vad_proportion, pcm16=True, device=device)
+                           vad_proportion=args.vad_proportion, pcm16=True, device=device,
+                           strict_reference=bool(getattr(args, "strict_reference", False)))
     # before any thread pool or pinned slab exists: they inherit the placement
     from setk_amd import numa
     placement = numa.bind(engine.ctx, getattr(args, "numa", "auto"))

@@ -45,3 +45,23 @@ def pcm16_rel_rms(pcm, ref_float):
 
 def rel_rms(a, ref):
     return rms(a, ref) / max(rms(ref), 1e-30)
+
+
+def rel_rms_outside_bins(wav, ref, bad_bins, guard=3, n_fft=512, hop=256):
+    """Two waveforms compared bin by bin in the STFT domain, leaving out `bad_bins` (+- guard:
+    the Hann window spreads a bin over its neighbours) and after fitting ONE real scale (the
+    max-abs renorm of a wave depends on every bin, the left-out ones included).  For real
+    recordings whose GEV pencil is singular in a few bins: there the reference's answer is
+    scipy.linalg.eig's (libs/beamformer.py:54-59), i.e. rounding noise of arbitrary size, and the
+    rest of the spectrum is still a well-posed comparison."""
+    from oracle import np_oracle as o
+    A = o.librosa_stft(np.asarray(wav, dtype=np.float64), n_fft, hop, center=True)
+    B = o.librosa_stft(np.asarray(ref, dtype=np.float64), n_fft, hop, center=True)
+    keep = np.ones(A.shape[0], dtype=bool)
+    for b in np.asarray(bad_bins, dtype=int):
+        keep[max(0, b - guard):b + guard + 1] = False
+    if not keep.any():
+        return None, 0
+    A, B = A[keep], B[keep]
+    scale = float(np.real(np.vdot(A, B)) / max(np.real(np.vdot(A, A)), 1e-300))
+    return rms(A * scale, B) / max(rms(B), 1e-30), int(keep.sum())

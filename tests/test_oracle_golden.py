@@ -5,6 +5,8 @@ Pins the CPU oracle (oracle/np_oracle.py) against
        (oracle/make_golden.py -> tests/golden/*.npz),
   (iii) the live reference, when /root/reference is present.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -386,3 +388,65 @@ def test_wide_real_recording_through_the_reference_clis():
     assert wav.shape == ref.shape
     # measured: every sample of the file equal (a quiet recording: one LSB is 3e-3 of its RMS)
     assert np.mean(float_to_pcm(wav) != g["pmwf0"]) < 1e-3
+
+
+# ---- the reference's skip set on singular noise covariances ------------------------------
+def _skipset_inputs():
+    cases = dict(o.skipset_cases())
+    cases.update(mg.skipset_real_recordings())
+    return cases
+
+
+def _oracle_outcome(samps, mask, spec, gauge):
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            wav = o.enhance_utterance(samps, mask, gauge=gauge, **spec)
+        except np.linalg.LinAlgError:
+            return "LinAlgError"
+    return "ok" if np.isfinite(wav).all() else "ok-nonfinite"
+
+
+def test_oracle_skip_set_equals_the_reference():
+    """Which (input, beamformer) pairs raise LinAlgError -- the utterances
+    apply_adaptive_beamformer.py:170-172 skips.  tests/golden/ref_skipset.json is what the
+    UNMODIFIED reference classes did (oracle/make_golden.py gen_skipset); the oracle must
+    raise on exactly those, with and without the gauge (round 4's oracle raised from its own
+    gauge Cholesky on `noisy` / the 16-channel recording under GEV, where the reference's
+    scipy.linalg.eig fallback goes through: the reference skips NONE of its real
+    recordings)."""
+    import json
+    table = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_skipset.json")))["table"]
+    cases = _skipset_inputs()
+    assert set(cases) == set(table)
+    raised = 0
+    for name, (samps, mask) in cases.items():
+        for kname, spec in o.SKIPSET_KINDS.items():
+            want = table[name][kname]
+            for gauge in ((False, True) if samps.shape[0] <= 5 else (True,)):
+                got = _oracle_outcome(samps, mask, spec, gauge)
+                # a NaN result and a clean one are both "the reference writes a file"
+                assert (got == "LinAlgError") == (want == "LinAlgError"), (name, kname, gauge, got, want)
+            raised += want == "LinAlgError"
+    assert raised >= 20
+    for name in table:
+        if name.startswith("real-"):
+            assert all(v == "ok" for v in table[name].values()), name
+        assert table[name]["gevd"] != "LinAlgError"  # the GEV path never raises (:54-59)
+
+
+@pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+def test_skip_set_table_equals_the_live_reference():
+    import json
+    import warnings
+    table = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_skipset.json")))["table"]
+    libs = rh.load()
+    cases = _skipset_inputs()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name in ("plain", "dup-channel", "channel-x2", "channel-x0.3", "ones-mask", "silence",
+                     "real-noisy-5ch", "real-ssl-first-8ch"):
+            samps, mask = cases[name]
+            for kname, spec in o.SKIPSET_KINDS.items():
+                assert mg.ref_skipset_outcome(libs, samps, mask, spec) == table[name][kname], (name, kname)
