@@ -85,7 +85,20 @@ def parse():
                          "streaming kernels IN THIS RUN by re-running three timed steps under "
                          "`rocprofv3 --pmc` (separate passes, counters only; 0 = skip)")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
-    return ap.parse_args()
+    ap.add_argument("--pcm-child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--int16-ingest", type=int, default=1,
+                    help="N=1 only: the same shard fed as 16-bit PCM (SETK_FLAG_IN_PCM16: 2 C N audio bytes "
+                         "per pass), reported apart in `int16_ingest` with its own roofline block (0 = skip)")
+    ap.add_argument("--aux", type=int, default=0,
+                    help="N=1 only: the auxiliary legs -- `sustained`, `uncached_call`, `power`, "
+                         "`roofline.issue_rates`, `cpu_baseline.all_cores` (default off: the line stays "
+                         "short enough for the driver's record to keep stage_ms, roofline.pass1/pass2 and "
+                         "cpu_baseline whole)")
+    args = ap.parse_args()
+    if not args.aux:
+        args.sustain_sec = 0.0
+        args.cpu_allcore_per_proc = 0
+    return args
 
 
 def free_port():
@@ -181,6 +194,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.pcm_child:
+        # profiled child of pcm_traffic(): the int16 step's launches are all it is for
+        print(json.dumps(int16_ingest_leg(args, ctx, _ffi, torch, opts, audio, masks, waves, C, N, T, L, U, nd,
+                                          None)), flush=True)
+        return
     for _ in range(args.warmup):
         step()
     st = ctx.enhance_batch(opts, C, aptr, ns, mptr, None, wptr, want_status=True)
@@ -238,7 +256,7 @@ def main():
     #      tables alternate between two sets of buffers (so the descriptor block is rebuilt
     #      and uploaded every call) and the per-utterance status words are read back
     fresh = None
-    if rank == 0:
+    if rank == 0 and args.aux:
         audio_b = [t.clone() for t in audio]
         masks_b = [t.clone() for t in masks]
         waves_b = [torch.empty(L, dtype=torch.float32, device=dev) for _ in range(U)]
@@ -267,6 +285,20 @@ def main():
         wave0 = {"waves": [waves[i].cpu().numpy() for i in range(nd)],
                  "clones_bit_identical": all(bool(torch.equal(waves[i], waves[i % nd])) for i in range(nd, U)),
                  "clones": U - nd}
+    # (a'') the shard as 16-bit PCM (its own roofline block; the float32 headline is untouched)
+    int16_leg = None
+    if rank == 0 and world == 1 and args.int16_ingest:
+        int16_leg = int16_ingest_leg(args, ctx, _ffi, torch, opts, audio, masks, waves, C, N, T, L, U, nd,
+                                     {"stft_covar": round(stage_ms[0], 4), "beamform_istft": round(stage_ms[2], 4)})
+        if args.pmc:
+            tr = pcm_traffic(args)
+            int16_leg["roofline"]["pmc"] = {k: (None if not isinstance(v, dict) else {
+                "hbm_read_bytes": v.get("hbm_read_bytes"), "hbm_write_bytes": v.get("hbm_write_bytes"),
+                "valu_insts": v.get("valu_insts"), "profiled_kernel_ms": v.get("profiled_kernel_ms")})
+                for k, v in tr.items() if k in ("pass1", "pass2", "ingest")} if "error" not in tr else tr
+            p1 = tr.get("pass1") if isinstance(tr, dict) else None
+            if isinstance(p1, dict) and p1.get("hbm_read_bytes") is not None:
+                int16_leg["roofline"]["traffic"] = round(p1["hbm_read_bytes"] + (p1.get("hbm_write_bytes") or 0.0))
     # (b) strong-scaling anchor: the whole configs[2] batch on this one GPU
     full_batch = None
     if world == 1 and args.full_batch > U:
@@ -278,7 +310,7 @@ def main():
         k1_ms, k2_ms = stage_ms[0], stage_ms[2]
         achieved = b_k1 / (k1_ms * 1e-3) / 1e9
         pmc = pmc_leg(args) if (world == 1 and args.pmc) else None
-        rates = issue_rates_leg() if (world == 1 and args.pmc) else None
+        rates = issue_rates_leg() if (world == 1 and args.pmc and args.aux) else None
         roof = build_roofline(C, b_k1, b_k2, k1_ms, k2_ms, pmc, rates, solve_ms=stage_ms[1])
         if rates is not None:
             roof["issue_rates"] = rates
@@ -316,9 +348,11 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             # (ahead of the auxiliary legs: the driver's record keeps the head of the line)
             out["cpu_baseline"] = cpu_baseline(args, C, N, rank * U, wave0)
+        if int16_leg is not None:
+            out["int16_ingest"] = int16_leg
         if sustained is not None:
             out["sustained"] = sustained
-        if world == 1 and args.sustain_sec > 0 and args.pmc:
+        if world == 1 and args.sustain_sec > 0 and args.pmc and args.aux:
             out["power"] = power_leg(step, torch, min(3.0, max(1.0, args.sustain_sec)))
         if fresh is not None:
             out["uncached_call"] = fresh
@@ -432,7 +466,7 @@ def power_leg(step, torch, seconds=2.0):
             "how": "rocm-smi --showpower --showclocks polled while the step repeats"}
 
 
-def pmc_leg(args, child=None, kernels=None):
+def pmc_leg(args, child=None, kernels=None, pcm=False):
     """Counters of THIS run's workload (or of `child`, a command line, for the kernels
     `kernels` = {key: [name fragments]}): three timed steps of the same configuration
     re-run as a child under `rocprofv3 --pmc`, one pass per counter group (counters
@@ -473,7 +507,9 @@ def pmc_leg(args, child=None, kernels=None):
                 for row in csv.DictReader(open(fn)):
                     for key, knames in kernels.items():
                         kname = next((k for k in knames if k + "<" in row["Kernel_Name"]), None)
-                        if kname and ", true>" not in row["Kernel_Name"]:
+                        # the streaming kernels' last template argument: 16-bit PCM input
+                        is_pcm = ", true>(" in row["Kernel_Name"] or row["Kernel_Name"].rstrip().endswith(", true>")
+                        if kname and (key not in ("pass1", "pass2") or is_pcm == pcm):
                             acc.setdefault(key, {})["__kernel__"] = kname
                             d = acc[key].setdefault(row["Counter_Name"], [])
                             d.append((float(row["Counter_Value"]),
@@ -725,6 +761,123 @@ def cgmm_roofline(args, C, T, U, rates):
                                           "why": "three 256-thread workgroups per CU: 46.5 KB of LDS each, 168 VGPRs"}}
     ent["bound"] = "valu_issue"
     return ent
+
+
+def int16_ingest_leg(args, ctx, _ffi, torch, opts, audio, masks, waves, C, N, T, L, U, nd, f32_stage_ms):
+    """The timed configuration with its audio as 16-bit PCM, as a wave file stores it (SURVEY
+    8f-3 "int16 ingest on device", 8d "report that variant separately with 2 C N").  Resident
+    in HBM: the interleaved frames [N][C] of every utterance.  One step = de-interleave into
+    planar int16 (setk_pcm16_deinterleave_batch: 4 C N bytes; the float32 conversion it
+    replaces moved 6 C N) + the four stages with SETK_FLAG_IN_PCM16 (both streaming kernels
+    read 2 bytes per sample; read_wav's / 32768 is folded into their window tables).
+    `enhance_only`: the planar samples already resident (what a caller who stores int16
+    [C][N] pays).  The parity check is exact: the outputs equal the float32 path's on
+    pcm / 32768 bit for bit."""
+    dev = audio[0].device
+    F = 257
+    stride = ctx.pcm16_channel_stride(N)
+    frames, f32q = [], []
+    for i in range(nd):
+        q = torch.clamp(torch.round(audio[i].T * 32767.0), -32768, 32767).to(torch.int16).contiguous()  # [N][C]
+        frames.append(q)
+        f32q.append((q.T.to(torch.float32) / 32768.0).contiguous())
+    frames += [frames[i % nd].clone() for i in range(nd, U)]
+    planar = [torch.empty((C, stride), dtype=torch.int16, device=dev) for _ in range(U)]
+    fptr = [t.data_ptr() for t in frames]
+    pptr = [t.data_ptr() for t in planar]
+    mptr = [t.data_ptr() for t in masks]
+    wptr = [t.data_ptr() for t in waves]
+    ns = [N] * U
+    po = _ffi.BfOpts(kind=opts.kind, flags=opts.flags | _ffi.FLAG_IN_PCM16, pmwf_beta=opts.pmwf_beta,
+                     pmwf_ref=opts.pmwf_ref, rank1=opts.rank1)
+
+    def step(ingest=True):
+        if ingest:
+            ctx.pcm16_deinterleave_batch(C, fptr, ns, pptr)
+        ctx.enhance_batch(po, C, pptr, ns, mptr, None, wptr, want_status=False)
+
+    def timed(fn, warm, k):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / k
+
+    warm, k = (1, 3) if args.pcm_child else (max(10, args.warmup // 2), max(20, args.steps // 2))
+    step()
+    st = ctx.enhance_batch(po, C, pptr, ns, mptr, None, wptr, want_status=True)
+    ms_full = timed(step, warm, k)
+    ctx.set_profiling(True)
+    ms_enh = timed(lambda: step(False), warm, k)
+    ctx.set_profiling(False)
+    stage = ctx.last_stage_ms()
+    if args.pcm_child:
+        return {"pcm_child": True, "ms_per_step": round(ms_full, 4), "stage_ms": [round(x, 4) for x in stage]}
+    # ingest kernel alone
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(20):
+        ctx.pcm16_deinterleave_batch(C, fptr, ns, pptr)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms_ingest = ev0.elapsed_time(ev1) / 20
+    # exact parity against the float32 path on the dequantised samples (distinct utterances)
+    step()
+    torch.cuda.synchronize()
+    got = [waves[i].clone() for i in range(nd)]
+    fw = [torch.empty(L, dtype=torch.float32, device=dev) for _ in range(nd)]
+    ctx.enhance_batch(opts, C, [t.data_ptr() for t in f32q], [N] * nd, mptr[:nd], None,
+                      [t.data_ptr() for t in fw], want_status=True)
+    torch.cuda.synchronize()
+    identical = all(bool(torch.equal(a, b)) for a, b in zip(got, fw))
+    b_k1 = U * (2.0 * C * N + 4.0 * T * F)
+    b_k2 = U * (2.0 * C * N + 4.0 * L)
+    b_all = U * (2.0 * C * N + 4.0 * T * F + 4.0 * L)
+    out = {
+        "what": f"{U} x {C}-ch x {N / SR:g} s, audio resident as the wave files' interleaved 16-bit frames; "
+                "step = de-interleave (planar int16, no float32 copy) + the four stages reading int16",
+        "status": "ok" if st is not None and not any(st) else str(st),
+        "ms_per_step": round(ms_full, 4),
+        "value": round(U * (N / SR) / (ms_full * 1e-3), 1),
+        "enhance_only_ms": round(ms_enh, 4),
+        "ingest_ms": round(ms_ingest, 4),
+        "ingest_gbs": round(U * 4.0 * C * N / (ms_ingest * 1e-3) / 1e9, 1),
+        "stage_ms": {"stft_covar": round(stage[0], 4), "reduce_solve": round(stage[1], 4),
+                     "beamform_istft": round(stage[2], 4), "renorm": round(stage[3], 4)},
+        "float32_stage_ms": f32_stage_ms,
+        "bit_identical_to_float32_path_on_pcm_over_32768": identical,
+        "roofline": {
+            "kernel": "stft_covar_kernel<C,false,PCM>", "bound": "hbm",
+            "algorithmic_bytes": "U x (2 C N + 4 T F): int16 audio, float32 mask",
+            "achieved": round(b_k1 / (stage[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(b_k1 / (stage[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "pass2": {"kernel": "beamform_istft_mc_kernel<C,PCM>",
+                      "achieved": round(b_k2 / (stage[2] * 1e-3) / 1e9, 1),
+                      "frac": round(b_k2 / (stage[2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "pipeline_achieved": round(b_all / (ms_enh * 1e-3) / 1e9, 1),
+            "note": "the kernels are VALU-issue bound (section 5 of DESIGN.md): halving the audio bytes "
+                    "halves this fraction's numerator while the time stays; what the variant buys is HBM "
+                    "traffic (power) and the ingest pass",
+        },
+    }
+    return out
+
+
+def pcm_traffic(args):
+    """HBM traffic of the int16 step's kernels: a child of this script under rocprofv3 --pmc
+    (counters only), as pmc_leg does for the float32 step."""
+    child = [sys.executable, os.path.abspath(__file__), "--pcm-child", "1", "--gpus", "1",
+             "--steps", "3", "--warmup", "1", "--utts", str(args.utts), "--channels", str(args.channels),
+             "--seconds", str(args.seconds), "--beamformer", args.beamformer, "--distinct", str(args.distinct)]
+    try:
+        return pmc_leg(args, child=child, pcm=True, kernels={
+            "pass1": ["stft_covar_kernel"], "pass2": ["beamform_istft_mc_kernel"],
+            "ingest": ["pcm16_deinterleave_batch_kernel"]})
+    except Exception as e:  # the leg is auxiliary: report, do not fail the bench
+        return {"error": repr(e)}
 
 
 def time_full_batch(args, ctx, opts, torch, audio, masks, C, N, L):

@@ -97,6 +97,14 @@ extern "C" {
  * Cholesky) and only an all-zero or non-finite covariance is refused.  The weights of the bins
  * that pass are the same in both modes. */
 #define SETK_FLAG_STRICT_REFERENCE 0x40
+/* setk_enhance_batch(_taps): audio[u] is 16-bit PCM, planar int16 [C][setk_pcm16_channel_stride(
+ * num_samples[u])] as setk_pcm16_deinterleave_batch lays it out, not float32 [C][N].  Both
+ * streaming kernels then read 2 bytes per sample and scale by 2^-15 inside their transforms
+ * (folded into the window tables: a power of two, so the results are bit for bit those of the
+ * float32 call on pcm / 32768, i.e. on read_wav's dtype="float32" samples, libs/utils.py:80-90).
+ * Needs hop = n_fft / 2 (the CLI default 512 / 256); otherwise SETK_ERR_UNSUPPORTED -- convert
+ * with setk_pcm16_to_float_batch. */
+#define SETK_FLAG_IN_PCM16 0x80
 
 typedef struct setk_context* setk_handle_t;
 
@@ -230,6 +238,17 @@ int setk_pcm16_to_float(setk_handle_t h, const int16_t* pcm, int num_channels,
 int setk_pcm16_to_float_batch(setk_handle_t h, int n_utts, int num_channels,
                               const int16_t* const* pcm, const int* num_samples,
                               float* const* audio, double* power0, void* stream);
+
+/* 16-bit PCM ingest WITHOUT a float32 copy: interleaved frames pcm[u][n][c] (a wave file's
+ * data chunk) -> planar int16 out[u][c][stride], stride = setk_pcm16_channel_stride(num_samples[u])
+ * (the samples between channels: num_samples rounded up to a multiple of 8, the padding
+ * zeroed), the layout SETK_FLAG_IN_PCM16 reads.  4 C N bytes of traffic where the float32
+ * conversion moves 6 C N, and half the bytes in both streaming passes afterwards.  power0 as
+ * setk_pcm16_to_float_batch.  Device pointers, host tables, asynchronous on `stream`. */
+int setk_pcm16_channel_stride(int num_samples);
+int setk_pcm16_deinterleave_batch(setk_handle_t h, int n_utts, int num_channels,
+                                  const int16_t* const* pcm, const int* num_samples,
+                                  int16_t* const* out, double* power0, void* stream);
 
 /* The way back for a multi-channel result (apply_wpe.py:58-61 -> write_wav,
  * libs/utils.py:45-62 -> soundfile.write, float -> PCM_16): float32 rows audio[C][N] ->
@@ -375,7 +394,11 @@ int setk_wpe_batch_fnt(setk_handle_t h, int n_utts, const float* const* spec, in
  *   2. batched per-bin weight solve
  *   3. rFFT recompute + w^H x + irFFT + overlap-add
  *   4. max-abs renorm (to max|input|) and emit float32 (or PCM16)
- * audio[u]   device float32 [C][num_samples[u]]
+ * audio[u]   device float32 [C][num_samples[u]]; with SETK_FLAG_IN_PCM16 device int16
+ *            [C][setk_pcm16_channel_stride(num_samples[u])] (cast to const float*).
+ *            Float samples of any magnitude are accepted: the matrix-core transforms of
+ *            stage 3 bring an utterance whose max |x| exceeds 1 into their fp16 operand range
+ *            by a power of two taken from stage 1's max |x| (exact, undone on the way out)
  * mask_s[u]  device float32 [T_u][F]
  * mask_n     NULL, or per-utterance interferer masks (--itf-mask)
  * wave[u]    device float32 (or int16) [hop*(T_u-1)] when center, see

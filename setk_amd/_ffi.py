@@ -34,6 +34,7 @@ RANK1_NONE, RANK1_EIG, RANK1_GEV = 0, 1, 2
 FLAG_BAN, FLAG_CLAMP_MASK, FLAG_POST_MASK, FLAG_NO_GAUGE, FLAG_OUT_PCM16 = 1, 2, 4, 8, 16
 FLAG_NO_RENORM = 32
 FLAG_STRICT_REFERENCE = 64  # numpy.linalg.solve's exact-zero-pivot refusals (setk_hip.h)
+FLAG_IN_PCM16 = 128  # enhance_batch: audio[u] is planar int16 [C][pcm16_channel_stride(N)]
 CGMM_UPDATE_ALPHA = 1
 
 
@@ -98,7 +99,7 @@ def exported_symbols():
         "setk_host_register", "setk_host_unregister", "setk_memcpy_h2d_async",
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_stft_batch", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
-        "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_float_to_pcm16", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks", "setk_cgmm_masks_k",
+        "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_pcm16_channel_stride", "setk_pcm16_deinterleave_batch", "setk_float_to_pcm16", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks", "setk_cgmm_masks_k",
         "setk_cgmm_masks_batch", "setk_cgmm_estimate_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
         "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_wpe_batch", "setk_wpe_batch_fnt", "setk_set_profiling",
@@ -164,6 +165,9 @@ def load_library():
     lib.setk_ban.argtypes = [H, fp, fp, c_int, c_int, fp, c_void_p]
     lib.setk_pcm16_to_float.argtypes = [H, c_void_p, c_int, c_int, fp, c_void_p]
     lib.setk_float_to_pcm16.argtypes = [H, fp, c_int, c_int, c_void_p, c_void_p]
+    lib.setk_pcm16_channel_stride.argtypes = [c_int]
+    lib.setk_pcm16_deinterleave_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int),
+                                                  POINTER(c_void_p), c_void_p, c_void_p]
     lib.setk_pcm16_to_float_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int),
                                               POINTER(c_void_p), c_void_p, c_void_p]
     lib.setk_rank1.argtypes = [H, fp, fp, c_int, c_int, fp, fp, c_void_p]
@@ -441,6 +445,21 @@ class Context:
         NS = (c_int * n)(*[int(v) for v in num_samples])
         self.check(
             self._lib.setk_pcm16_to_float_batch(
+                self._h, n, int(C), P, NS, O, _ptr(power0),
+                current_stream_ptr() if stream is None else stream))
+
+    def pcm16_channel_stride(self, num_samples):
+        return int(self._lib.setk_pcm16_channel_stride(int(num_samples)))
+
+    def pcm16_deinterleave_batch(self, C, pcm_ptrs, num_samples, out_ptrs, power0=None, stream=None):
+        """Interleaved int16 frames -> planar int16 [C][pcm16_channel_stride(N)] (device
+        addresses), ONE launch: the input layout of FLAG_IN_PCM16."""
+        n = len(pcm_ptrs)
+        P = (c_void_p * n)(*pcm_ptrs)
+        O = (c_void_p * n)(*out_ptrs)
+        NS = (c_int * n)(*[int(v) for v in num_samples])
+        self.check(
+            self._lib.setk_pcm16_deinterleave_batch(
                 self._h, n, int(C), P, NS, O, _ptr(power0),
                 current_stream_ptr() if stream is None else stream))
 

@@ -43,6 +43,7 @@ struct setk_context {
     float2* d_tw512 = nullptr;  // [129]
     // matrix-core transforms of the fused path (n_fft = 512; mcdft.h)
     unsigned* d_mc_tab = nullptr;  // [mc::kTabWords][64] operand tiles (once per handle)
+    float* d_window_pcm = nullptr; // d_window x 2^-15: pass 1 on 16-bit PCM (SETK_FLAG_IN_PCM16)
     float* d_mc_win = nullptr;     // [8][64] analysis window rows x mc_scale
     float* d_mc_syn = nullptr;     // [8][64] synthesis window rows / 512 / sum(window^2) (hop = n_fft / 2)
     float* d_mc_edge = nullptr;    // [8][64] corrections of the single-contribution blocks
@@ -355,6 +356,7 @@ int setk_destroy(setk_handle_t h) {
     if (h->d_tw512) (void)hipFree(h->d_tw512);
     if (h->d_mc_tab) (void)hipFree(h->d_mc_tab);
     if (h->d_mc_win) (void)hipFree(h->d_mc_win);
+    if (h->d_window_pcm) (void)hipFree(h->d_window_pcm);
     if (h->d_mc_syn) (void)hipFree(h->d_mc_syn);
     if (h->d_mc_edge) (void)hipFree(h->d_mc_edge);
     if (h->d_twn) (void)hipFree(h->d_twn);
@@ -574,6 +576,15 @@ int setk_stft_plan(setk_handle_t h, int frame_len, int frame_hop, int n_fft, int
     if (!h->d_tw256) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tw256), 256 * sizeof(float2)));
     if (!h->d_tw512) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tw512), 129 * sizeof(float2)));
     HIP_TRY(h, hipMemcpy(h->d_window, w.data(), n_fft * sizeof(float), hipMemcpyHostToDevice));
+    {
+        // the same window with read_wav's 1 / 32768 folded in (exact: a power of two)
+        std::vector<float> wp(n_fft);
+        for (int i = 0; i < n_fft; ++i) wp[i] = w[i] * 3.0517578125e-05f;
+        if (h->d_window_pcm) (void)hipFree(h->d_window_pcm);
+        h->d_window_pcm = nullptr;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_window_pcm), n_fft * sizeof(float)));
+        HIP_TRY(h, hipMemcpy(h->d_window_pcm, wp.data(), n_fft * sizeof(float), hipMemcpyHostToDevice));
+    }
     HIP_TRY(h, hipMemcpy(h->d_winsq, w2.data(), n_fft * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_tw256, t256.data(), 256 * sizeof(float2), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_tw512, t512.data(), 129 * sizeof(float2), hipMemcpyHostToDevice));
@@ -1204,6 +1215,33 @@ int setk_pcm16_to_float_batch(setk_handle_t h, int n_utts, int num_channels,
     if (rc) return rc;
     if (power0) HIP_TRY(h, hipMemsetAsync(power0, 0, (size_t)n_utts * sizeof(double), s));
     HIP_TRY(h, launch_pcm16_to_float_batch(d_tbl, n_utts, num_channels, max_n, power0, s));
+    return SETK_OK;
+}
+
+int setk_pcm16_channel_stride(int num_samples) { return num_samples <= 0 ? 0 : ((num_samples + 7) & ~7); }
+
+int setk_pcm16_deinterleave_batch(setk_handle_t h, int n_utts, int num_channels,
+                                  const int16_t* const* pcm, const int* num_samples,
+                                  int16_t* const* out, double* power0, void* stream) {
+    if (!h || n_utts <= 0 || num_channels <= 0 || !pcm || !num_samples || !out)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h, s);
+    std::vector<char> tbl(pcm_item_bytes() * n_utts);
+    int max_n = 0;
+    for (int u = 0; u < n_utts; ++u) {
+        if (!pcm[u] || !out[u] || num_samples[u] <= 0)
+            return fail(h, SETK_ERR_INVALID, "null utterance pointer");
+        pcm_item_fill_planar(tbl.data(), u, pcm[u], out[u], num_samples[u],
+                             setk_pcm16_channel_stride(num_samples[u]));
+        max_n = std::max(max_n, num_samples[u]);
+    }
+    void* d_tbl;
+    int rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
+    if (rc) return rc;
+    if (power0) HIP_TRY(h, hipMemsetAsync(power0, 0, (size_t)n_utts * sizeof(double), s));
+    HIP_TRY(h, launch_pcm16_deinterleave_batch(d_tbl, n_utts, num_channels, max_n, power0, s));
     return SETK_OK;
 }
 
@@ -1901,6 +1939,7 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     HIP_TRY(h, hipSetDevice(h->device));
     arena_reset(h, s);
     const bool pcm16 = (opts->flags & SETK_FLAG_OUT_PCM16) != 0;
+    const bool in_pcm = (opts->flags & SETK_FLAG_IN_PCM16) != 0;
     const int NP = npairs(C);
     const StftGeom g = geom_of(h);
 
@@ -1921,6 +1960,10 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     // pass 2 on the matrix cores: hop = n_fft / 2 only (wave-resident overlap-add, pass2_mc.hip)
     const bool mc2 = h->mc_enabled && 2 * g.hop == kNfft && g.keep == 1 &&
                      !(getenv("SETK_MC_PASS2") && atoi(getenv("SETK_MC_PASS2")) == 0);
+    if (in_pcm && !mc2)
+        return fail(h, SETK_ERR_UNSUPPORTED,
+                    "16-bit PCM input (SETK_FLAG_IN_PCM16) needs hop = n_fft / 2 and the matrix-core "
+                    "pass 2; convert with setk_pcm16_to_float_batch");
     const int quant2 = mc2 ? 8 : kSuperTile;
     const int target2 = mc2 ? choose_target(all_frames, h->mc_p2_items > 0 ? h->mc_p2_items : h->mc_cus * pass2_mc_wgs_per_cu(C), quant2, 64)
                             : choose_target(all_frames, h->p2_items, kSuperTile, kSuperTile * 4);
@@ -1931,6 +1974,10 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
         if (!audio[u] || !mask_s[u] || !wave[u] || (mask_n && !mask_n[u]))
             return fail(h, SETK_ERR_INVALID, "null utterance pointer");
         ud.audio = audio[u];
+        ud.audio_fmt = in_pcm ? kAudioPcm16 : kAudioF32;
+        ud.ch_stride = in_pcm ? setk_pcm16_channel_stride(num_samples[u]) : num_samples[u];
+        if (in_pcm && (reinterpret_cast<uintptr_t>(audio[u]) & 3))
+            return fail(h, SETK_ERR_INVALID, "16-bit PCM input must be 4-byte aligned");
         ud.mask_s = mask_s[u];
         ud.mask_n = mask_n ? mask_n[u] : nullptr;
         ud.num_samples = num_samples[u];
@@ -2037,12 +2084,13 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     p1.mc_win = h->d_mc_win;
     // pass 1 on the matrix cores is opt-in (SETK_MC_PASS1=1): parity-green, but its transform
     // waves are the long pole of the tile pipeline (0.95 ms against 0.88)
-    const bool mc1 = h->mc_enabled && pass1_mc_supported(C, g.hop) && getenv("SETK_MC_PASS1") &&
+    const bool mc1 = !in_pcm && h->mc_enabled && pass1_mc_supported(C, g.hop) && getenv("SETK_MC_PASS1") &&
                      atoi(getenv("SETK_MC_PASS1")) != 0;
+    if (in_pcm) p1.window = h->d_window_pcm;
     if (mc1)
         HIP_TRY(h, launch_pass1_mc(C, p1, (int)items1.size(), s));
     else
-        HIP_TRY(h, launch_pass1(C, false, p1, (int)items1.size(), s));
+        HIP_TRY(h, launch_pass1(C, false, p1, (int)items1.size(), s, in_pcm));
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[1], s));
     FinalizeArgs fa;
     memset(&fa, 0, sizeof(fa));
@@ -2126,6 +2174,7 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     p2.tw256 = h->d_tw256;
     p2.tw512 = h->d_tw512;
     p2.outmax_bits = d_omax;
+    p2.norm_bits = d_norm;
     p2.g = g;
     p2.flags = opts->flags;
     p2.mc_tab = h->d_mc_tab;
@@ -2133,7 +2182,7 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
     p2.mc_syn = h->d_mc_syn;
     p2.mc_edge = h->d_mc_edge;
     if (mc2)
-        HIP_TRY(h, launch_pass2_mc(C, p2, (int)items2.size(), s));
+        HIP_TRY(h, launch_pass2_mc(C, p2, (int)items2.size(), s, in_pcm));
     else
         HIP_TRY(h, launch_pass2(C, false, p2, (int)items2.size(), s));
     if (prof) HIP_TRY(h, hipEventRecord(h->ev[3], s));

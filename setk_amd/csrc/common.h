@@ -35,8 +35,15 @@ __host__ __device__ constexpr int pair_index(int i, int j, int c) {
     return i * c - i * (i - 1) / 2 + (j - i);
 }
 
+// sample formats of UttDesc::audio
+constexpr int kAudioF32 = 0;    // float32 [C][ch_stride]   (the reference's C x N, read_wav's int16 / 32768)
+constexpr int kAudioPcm16 = 1;  // int16   [C][ch_stride]   planar 16-bit PCM as stored in the wave file
+                                // (setk_pcm16_deinterleave_batch); the kernels scale by 2^-15, exactly
+                                // libs/utils.py:80-90's dtype="float32" read.  ch_stride is even: a
+                                // pair of samples (x[2n], x[2n+1]) is ONE aligned dword
+
 struct UttDesc {
-    const float* audio;   // [C][num_samples]
+    const float* audio;   // float32 [C][num_samples], or (audio_fmt) int16 [C][ch_stride]
     const float* mask_s;  // [T][F]
     const float* mask_n;  // [T][F] or null
     float* wave_f32;      // pass-2 float output [out_len]
@@ -46,6 +53,8 @@ struct UttDesc {
     int out_len;
     int part0;   // first partial slab of this utterance
     int nparts;  // number of partial slabs
+    int audio_fmt;  // kAudioF32 | kAudioPcm16
+    int ch_stride;  // kAudioPcm16: samples between channels (even, >= num_samples)
     int pad_;
 };
 
@@ -67,7 +76,7 @@ struct Pass1Args {
     const UttDesc* utts;
     const WorkItem* items;
     float* partials;        // [nparts_total][nplanes][kBinsPad]
-    const float* window;    // [512] analysis window (padded, centred)
+    const float* window;    // [512] analysis window (padded, centred); PCM16 launches: x 2^-15
     const float2* tw256;    // [16][16]  exp(-2 pi i la q / 256) at [q*16+la]
     const float2* tw512;    // [129]     exp(-2 pi i k / 512)
     unsigned* norm_bits;    // [n_utts] max |audio| as float bits (atomicMax)
@@ -121,6 +130,7 @@ struct Pass2Args {
     const float2* tw256;
     const float2* tw512;
     unsigned* outmax_bits;   // [n_utts]
+    const unsigned* norm_bits;  // [n_utts] max |audio| (pass 1): pass2_mc's input range (may be null)
     StftGeom g;
     int flags;
     // matrix-core transforms (pass2_mc.hip / mcdft.h)
@@ -139,10 +149,10 @@ struct ScaleArgs {
 };
 
 // launchers (implemented in the kernel TUs)
-hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s);
+hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s, bool pcm16 = false);
 hipError_t launch_pass1_mc(int C, const Pass1Args& a, int n_items, hipStream_t s);
 bool pass1_mc_supported(int C, int hop);
-hipError_t launch_pass2_mc(int C, const Pass2Args& a, int n_items, hipStream_t s);
+hipError_t launch_pass2_mc(int C, const Pass2Args& a, int n_items, hipStream_t s, bool pcm16 = false);
 int pass2_mc_wgs_per_cu(int C);
 // STFT of whole utterances into the bin-major [F][C][Tp] layout of cgmm_bin.hip
 // (items: 64-frame blocks; UttDesc::wave_out = the utterance's output)
@@ -218,6 +228,9 @@ size_t pcm_item_bytes();
 void pcm_item_fill(void* dst, int i, const int16_t* pcm, float* out, int n);
 hipError_t launch_pcm16_to_float_batch(const void* d_items, int n_utts, int C, int max_n,
                                        double* power0, hipStream_t s);
+void pcm_item_fill_planar(void* dst, int i, const int16_t* pcm, int16_t* out, int n, int stride);
+hipError_t launch_pcm16_deinterleave_batch(const void* d_items, int n_utts, int C, int max_n,
+                                           double* power0, hipStream_t s);
 hipError_t launch_beamform_spec(const float* w_fc, const float* spec, int C, int T, int F,
                                 float* out, hipStream_t s);
 

@@ -302,6 +302,38 @@ SETK_DEV void load_raw(cf (&v)[16], FloatPtr x, int n_samp, int s, int la, bool 
     }
 }
 
+// 16-bit PCM (planar int16, UttDesc::audio_fmt == kAudioPcm16): the pair (x[s+2n], x[s+2n+1]) is
+// ONE dword, kept packed while in flight (16 registers per frame where the float form holds
+// 32) and unpacked by two SDWA conversions (v_cvt_f32_i32 sext word_0 / word_1) when the
+// transform starts.  The 2^-15 of read_wav (libs/utils.py:80-90: int16 / 32768 as float32) is
+// folded into the window table -- a power of two, so every product is bit for bit that of the
+// float path on the dequantised samples.
+typedef const SETK_GLOBAL short* gcshort_p;
+typedef const SETK_GLOBAL int* gcint_p;
+SETK_DEV void load_raw_pcm(int (&v)[16], gcshort_p x, int n_samp, int s, int la, bool valid) {
+    if (!valid) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = 0;
+        return;
+    }
+    // (x is 4-byte aligned and s even by construction: channel strides are even, hop and pad too)
+    const bool interior = (s >= 0) && (s + kFrame <= n_samp) && ((((uintptr_t)(x + s)) & 3) == 0);
+    if (interior) {
+        gcint_p p = (gcint_p)(x + s);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = p[la + 16 * j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int n = la + 16 * j;
+            const int lo = x[reflect_index(s + 2 * n, n_samp)];
+            const int hi = x[reflect_index(s + 2 * n + 1, n_samp)];
+            v[j] = (lo & 0xffff) | (hi << 16);
+        }
+    }
+}
+SETK_DEV cf unpack_pcm(int v) { return make_float2((float)(short)(v & 0xffff), (float)(v >> 16)); }
+
 // lane la <- value of lane (16 - la) & 15 of the same quad-row (a DPP row):
 // row_mirror (la -> 15 - la) followed by row_ror:1
 SETK_DEV float qr_partner(float x) {

@@ -580,6 +580,100 @@ hipError_t launch_pcm16_to_float_batch(const void* d_items, int n_utts, int C, i
 }
 
 // ---------------------------------------------------------------------------
+// 16-bit PCM ingest without a float32 twin: the wave file's interleaved frames pcm[n][c] ->
+// planar int16 out[c][stride] (stride even, >= n: UttDesc::ch_stride), which the fused
+// kernels read directly (SETK_FLAG_IN_PCM16: 2 bytes per sample in both streaming passes
+// instead of 4, 4 C N bytes moved here instead of 6 C N).  read_wav's int16 / 32768
+// (libs/utils.py:80-90) happens inside the transforms, folded into their window tables.
+// A thread takes FR = 4 frames: CT dwords in, one 8-byte store per channel.  power0 as above
+// (the CLI's log line), from the dequantised samples of channel 0.
+// ---------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256) void pcm16_deinterleave_batch_kernel(const PcmItem* __restrict__ items,
+                                                                       int C, double* power0) {
+    const PcmItem it = items[blockIdx.y];
+    int16_t* out = reinterpret_cast<int16_t*>(it.out);
+    const int stride = it.pad_;
+    const float k = 1.0f / 32768.0f;
+    float acc = 0.f;
+    constexpr int CV = CT > 0 ? CT : 1;
+    constexpr int FR = 4;
+    const bool fast = CT > 0 && (reinterpret_cast<uintptr_t>(it.pcm) & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(out) & 7) == 0 && (stride % FR) == 0;
+    const int groups = fast ? it.n / FR : 0;
+    if (fast) {
+        for (int p = blockIdx.x * 256 + threadIdx.x; p < groups; p += gridDim.x * 256) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(it.pcm + (size_t)FR * p * CV);
+            uint32_t w[FR * CV / 2];
+#pragma unroll
+            for (int i = 0; i < FR * CV / 2; ++i) w[i] = src[i];
+            auto at = [&](int fr, int c) -> uint32_t {  // sample c of frame fr as 16 bits
+                const int e = fr * CV + c;
+                return (e & 1) ? (w[e / 2] >> 16) : (w[e / 2] & 0xffffu);
+            };
+#pragma unroll
+            for (int c = 0; c < CV; ++c) {
+                uint2 o;
+                o.x = at(0, c) | (at(1, c) << 16);
+                o.y = at(2, c) | (at(3, c) << 16);
+                *reinterpret_cast<uint2*>(out + (size_t)c * stride + FR * p) = o;
+                if (c == 0) {
+#pragma unroll
+                    for (int fr = 0; fr < FR; ++fr) {
+                        const float v = (float)(int16_t)at(fr, 0) * k;
+                        acc = fmaf(v, v, acc);
+                    }
+                }
+            }
+        }
+    }
+    // the frames the fast path leaves (n % 4), or everything
+    for (int n = FR * groups + blockIdx.x * 256 + threadIdx.x; n < it.n; n += gridDim.x * 256) {
+        const int16_t* src = it.pcm + (size_t)n * C;
+        for (int c = 0; c < C; ++c) {
+            out[(size_t)c * stride + n] = src[c];
+            if (c == 0) {
+                const float v = (float)src[0] * k;
+                acc = fmaf(v, v, acc);
+            }
+        }
+    }
+    // the padding up to the stride reads as silence (never addressed by the transforms, which
+    // reflect at num_samples; zeroed so that a dump of the buffer is deterministic)
+    for (int n = it.n + blockIdx.x * 256 + threadIdx.x; n < stride; n += gridDim.x * 256)
+        for (int c = 0; c < C; ++c) out[(size_t)c * stride + n] = 0;
+    if (power0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if ((threadIdx.x & 63) == 0) atomicAdd(power0 + blockIdx.y, (double)acc);
+    }
+}
+
+void pcm_item_fill_planar(void* dst, int i, const int16_t* pcm, int16_t* out, int n, int stride) {
+    PcmItem* it = static_cast<PcmItem*>(dst) + i;
+    it->pcm = pcm;
+    it->out = reinterpret_cast<float*>(out);
+    it->n = n;
+    it->pad_ = stride;
+}
+
+hipError_t launch_pcm16_deinterleave_batch(const void* d_items, int n_utts, int C, int max_n,
+                                           double* power0, hipStream_t s) {
+    int bx = (max_n + 256 * 8 - 1) / (256 * 8);
+    bx = bx < 1 ? 1 : bx;
+    const PcmItem* items = static_cast<const PcmItem*>(d_items);
+    const dim3 grid(bx, n_utts), block(256);
+    switch (C) {
+        case 2: hipLaunchKernelGGL(pcm16_deinterleave_batch_kernel<2>, grid, block, 0, s, items, C, power0); break;
+        case 4: hipLaunchKernelGGL(pcm16_deinterleave_batch_kernel<4>, grid, block, 0, s, items, C, power0); break;
+        case 6: hipLaunchKernelGGL(pcm16_deinterleave_batch_kernel<6>, grid, block, 0, s, items, C, power0); break;
+        case 8: hipLaunchKernelGGL(pcm16_deinterleave_batch_kernel<8>, grid, block, 0, s, items, C, power0); break;
+        default: hipLaunchKernelGGL(pcm16_deinterleave_batch_kernel<0>, grid, block, 0, s, items, C, power0);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Helpers of the fixed-weight path (apply_fixed_beamformer.py:38-48):
 // max |audio| per utterance (SpectrogramReader.maxabs, the renorm target) and
 // the reference's F x M weight sets -> the planar [C][264] layout of pass 2.

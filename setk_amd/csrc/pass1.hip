@@ -27,11 +27,12 @@
 #include "fft512.h"
 #include "covar_fold.h"
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 namespace setk {
 
-template <int C, bool DUMP>
+template <int C, bool DUMP, bool PCM = false>
 __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
     constexpr int NT = 1024;
     constexpr int TB = pass1_tile_frames(C);
@@ -85,12 +86,13 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
         const int my_tt = my_i / C, my_c = my_i - my_tt * C;
         const bool producer = my_set < NS;
         gcfloat_p my_audio = gptr(ud.audio) + (size_t)my_c * n_samp;
+        gcshort_p my_pcm = (gcshort_p)gptr(ud.audio) + (size_t)my_c * ud.ch_stride;
         const cf* win_row = win_l + la * LaneTab<ROW>::lstride;
         const cf* tw_row = tw_l + la * LaneTab<ROW>::lstride;
         const cf* tw5_row = tw5_l + la * LaneTab<ROW>::lstride5;
         const bool ny_lane = !DUMP && producer && my_c == 0 && la == 0;
 
-        cf raw[16];
+        typename std::conditional<PCM, int, cf>::type raw[16];  // PCM: packed pairs of samples
         float raw_ms = 0.f, raw_mn = 0.f;
         bool raw_ok = false, raw_last = false;
         auto fetch = [&](int tb_tile) {
@@ -98,10 +100,12 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
             raw_ok = t < wi.t1;
             raw_last = t == T - 1;
 #ifdef SETK_NO_GLOAD
-            load_raw(raw, my_audio, n_samp, t * a.g.hop - a.g.pad, la, raw_ok && n_samp < 0);
+            const bool raw_go = raw_ok && n_samp < 0;
 #else
-            load_raw(raw, my_audio, n_samp, t * a.g.hop - a.g.pad, la, raw_ok);
+            const bool raw_go = raw_ok;
 #endif
+            if constexpr (PCM) load_raw_pcm(raw, my_pcm, n_samp, t * a.g.hop - a.g.pad, la, raw_go);
+            else load_raw(raw, my_audio, n_samp, t * a.g.hop - a.g.pad, la, raw_go);
             if (ny_lane) {
                 raw_ms = 0.f;
                 raw_mn = 0.f;
@@ -118,13 +122,16 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
             cf* slot = xt0 + (b * NF + my_i) * SL;
             cf v[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) mx = max3_abs(mx, raw[j].x, raw[j].y);
-            if (!half_max || raw_last) {
-#pragma unroll
-                for (int j = 8; j < 16; ++j) mx = max3_abs(mx, raw[j].x, raw[j].y);
+            for (int j = 0; j < 16; ++j) {
+                if constexpr (PCM) v[j] = unpack_pcm(raw[j]);  // (integers as floats; the window carries 2^-15)
+                else v[j] = raw[j];
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = raw[j];
+            for (int j = 0; j < 8; ++j) mx = max3_abs(mx, v[j].x, v[j].y);
+            if (!half_max || raw_last) {
+#pragma unroll
+                for (int j = 8; j < 16; ++j) mx = max3_abs(mx, v[j].x, v[j].y);
+            }
             apply_window<ROW>(v, win_row);
             if (ny_lane) {
                 const float s = clamp ? fminf(raw_ms, 1.f) : raw_ms;
@@ -256,9 +263,14 @@ __global__ __launch_bounds__(1024, 4) void stft_covar_kernel(Pass1Args a) {
             // samples after the last frame's span are never loaded above
             const int covered = (T - 1) * a.g.hop - a.g.pad + kNfft;
             for (int c = 0; c < C; ++c)
-                for (int i = covered + tid; i < n_samp; i += NT)
-                    mx = fmaxf(mx, fabsf(gptr(ud.audio)[(size_t)c * n_samp + i]));
+                for (int i = covered + tid; i < n_samp; i += NT) {
+                    if constexpr (PCM)
+                        mx = fmaxf(mx, fabsf((float)((gcshort_p)gptr(ud.audio))[(size_t)c * ud.ch_stride + i]));
+                    else
+                        mx = fmaxf(mx, fabsf(gptr(ud.audio)[(size_t)c * n_samp + i]));
+                }
         }
+        if constexpr (PCM) mx *= 3.0517578125e-05f;  // 2^-15: max |int16| -> max |x| (exact)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         if ((tid & 63) == 0) red[tid >> 6] = mx;
@@ -378,12 +390,12 @@ hipError_t launch_stft_binmajor(int C, const Pass1Args& a, int n_items, hipStrea
     return hipGetLastError();
 }
 
-template <int C, bool DUMP>
+template <int C, bool DUMP, bool PCM = false>
 static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s) {
     constexpr int NF = pass1_tile_frames(C) * C;
     const size_t lds = (size_t)2 * NF * slot_entries(17) * sizeof(cf) + table_entries(17) * sizeof(cf) +
                        (64 + 32 + 16) * sizeof(float);
-    auto k = stft_covar_kernel<C, DUMP>;
+    auto k = stft_covar_kernel<C, DUMP, PCM>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -391,10 +403,12 @@ static hipError_t launch_pass1_t(const Pass1Args& a, int n_items, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s) {
+hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipStream_t s, bool pcm16) {
+    if (pcm16 && dump) return hipErrorInvalidValue;  // (the spectrogram dump takes float32 samples)
 #define SETK_CASE(c)                                                \
     case c:                                                         \
         if (dump) return launch_pass1_t<c, true>(a, n_items, s);     \
+        if (pcm16) return launch_pass1_t<c, false, true>(a, n_items, s); \
         return launch_pass1_t<c, false>(a, n_items, s);
     switch (C) {
         SETK_CASE(1)

@@ -118,7 +118,9 @@ SETK_DEV float wave_max_nonneg(float x) {
 // one of an utterance, emitted only when center = False) take the per-lane corrections mc_edge.
 // A workgroup shares the weight table and the once-per-frame operand tiles; its waves split the
 // item's frame range and each recomputes one frame ahead of its sub-range for the carry.
-template <int C>
+// PCM: UttDesc::audio is planar 16-bit PCM (kAudioPcm16) -- sign-extending 2-byte loads, one
+// conversion per sample, and 2^-15 (read_wav's int16 / 32768) folded into the window rows.
+template <int C, bool PCM = false>
 __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamform_istft_mc_kernel(Pass2Args a) {
     constexpr int NT = kP2McThreads;
     constexpr int NW = kP2McWaves;
@@ -150,6 +152,23 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
     const bool post_mask = (a.flags & 0x4) != 0;
     const bool clamp = (a.flags & 0x2) != 0;
 
+    // The fp16 operand splits of the forward transform hold window x sample x 2^10 and want
+    // |sample| <= 1 (65504 is the end of fp16).  The utterance's max |x| is known (pass 1 reduced
+    // it into norm_bits before this kernel started): samples above 1 -- float wave files, int16
+    // ranges handed over as floats (WaveReader(normalize=False)), C-API callers -- are brought
+    // into range by the power of two 2^-e in the window rows and taken out again by 2^e in the
+    // synthesis rows.  e = 0 (nothing changes, bit for bit) whenever max |x| <= 1.  The
+    // beamformer is linear, every other stage of this kernel is scale free (the inverse
+    // transform normalises each frame's spectrum by its own power of two).  16-bit PCM arrives
+    // as integers: 2^-15 on the way in, nothing on the way out.
+    float in_sc = PCM ? 3.0517578125e-05f : 1.f, out_sc = 1.f;
+    if (a.norm_bits) {
+        const unsigned nb = a.norm_bits[wi.utt];  // max |x| (natural units) as float bits
+        int e = (int)((nb >> 23) & 0xff) - 126;   // max |x| < 2^e
+        e = (__builtin_bit_cast(float, nb) <= 1.f) ? 0 : (e > 100 ? 100 : e);
+        in_sc *= __builtin_bit_cast(float, (unsigned)(127 - e) << 23);
+        out_sc = __builtin_bit_cast(float, (unsigned)(127 + e) << 23);
+    }
     {
         const cf* wsrc = reinterpret_cast<const cf*>(a.weight) + (size_t)wi.utt * C * kBinsPad;
         for (int i = tid; i < C * F; i += NT) {
@@ -162,14 +181,19 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
 #if SETK_P2MC_KLDS
     mc::stage_tiles(tiles + 12 * 64, a.mc_tab, mc::kW_MC_H, 8, tid, NT);
 #if SETK_P2MC_WLDS
-    mc::stage_tiles(tiles + 20 * 64, reinterpret_cast<const unsigned*>(a.mc_win), 0, 2, tid, NT);
+    for (int i = tid; i < 128; i += NT) {
+        const int l = i & 63, t4 = i >> 6;
+        const mc::f4 w = {a.mc_win[(4 * t4 + 0) * 64 + l] * in_sc, a.mc_win[(4 * t4 + 1) * 64 + l] * in_sc,
+                          a.mc_win[(4 * t4 + 2) * 64 + l] * in_sc, a.mc_win[(4 * t4 + 3) * 64 + l] * in_sc};
+        tiles[20 * 64 + i] = __builtin_bit_cast(mc::u4, w);
+    }
     mc::stage_tiles(tiles + 22 * 64, a.mc_tab, mc::kW_TR, 3, tid, NT);
 #endif
 #endif
     for (int i = tid; i < 128; i += NT) {
         const int l = i & 63, hf = i >> 6;
-        synr[i] = (mc::f4){a.mc_syn[(4 * hf + 0) * 64 + l], a.mc_syn[(4 * hf + 1) * 64 + l],
-                           a.mc_syn[(4 * hf + 2) * 64 + l], a.mc_syn[(4 * hf + 3) * 64 + l]};
+        synr[i] = (mc::f4){a.mc_syn[(4 * hf + 0) * 64 + l] * out_sc, a.mc_syn[(4 * hf + 1) * 64 + l] * out_sc,
+                           a.mc_syn[(4 * hf + 2) * 64 + l] * out_sc, a.mc_syn[(4 * hf + 3) * 64 + l] * out_sc};
     }
 #if SETK_P2MC_KLDS && SETK_P2MC_WLDS
     struct { float tr[4], ti[4]; } K;  // (the inverse's conjugate twiddles: re-read there)
@@ -188,7 +212,7 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
 #if !(SETK_P2MC_KLDS && SETK_P2MC_WLDS)
     float win[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) win[e] = gptr(a.mc_win)[e * 64 + lane];
+    for (int e = 0; e < 8; ++e) win[e] = gptr(a.mc_win)[e * 64 + lane] * in_sc;
 #endif
     float* yoddw = yodd_s + wave * 16;
     const int lane_bin = mc::bin_of(c16, g, 0);
@@ -217,12 +241,19 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
     // EDGE: some sample of the group lies outside the signal (numpy "reflect" padding) -- the
     // first and the last group of an utterance; frames past the last one repeat it (computed
     // to keep the group uniform, never emitted).
+    // channel c of the utterance: float32 [C][N] or int16 [C][ch_stride] (the conversion is the
+    // implicit one of `float = short`: global_load_sshort + v_cvt_f32_i32)
+    auto chan = [&](int c) {
+        if constexpr (PCM) return (gcshort_p)gptr(ud.audio) + (size_t)c * ud.ch_stride;
+        else return gptr(ud.audio) + (size_t)c * n_samp;
+    };
     auto load_full = [&](float (&v)[8], int t, int c, auto edge) __attribute__((always_inline)) {
 #ifdef SETK_P2MC_ABL_L2  // ablation: every wave reads the same 1 MB (L2 resident) -- wrong results
         gcfloat_p x = gptr(a.utts[0].audio) + (size_t)c * n_samp;
+        (void)chan;
         const int s0 = (min(t, T - 1) & 127) * hop + 4096, o = 64 * g + c16;
 #else
-        gcfloat_p x = gptr(ud.audio) + (size_t)c * n_samp;
+        const auto x = chan(c);
         const int s0 = min(t, T - 1) * hop - a.g.pad, o = 64 * g + c16;
 #endif
         if (!decltype(edge)::value) {
@@ -240,13 +271,14 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
         }
     };
     auto load_half = [&](float (&v)[8], int t, int c, auto edge) __attribute__((always_inline)) {
-        gcfloat_p x = gptr(ud.audio) + (size_t)c * n_samp;
 #ifdef SETK_P2MC_ABL_REHALF  // ablation: re-read the half just loaded (cache hit) -- wrong results
+        const auto x = chan(c);
         const int s0 = min(t, T - 1) * hop - a.g.pad, o = 64 * g + c16;
 #elif defined(SETK_P2MC_ABL_L2)
-        x = gptr(a.utts[0].audio) + (size_t)c * n_samp;
+        gcfloat_p x = gptr(a.utts[0].audio) + (size_t)c * n_samp;
         const int s0 = (min(t, T - 1) & 127) * hop + 4096 + 256, o = 64 * g + c16;
 #else
+        const auto x = chan(c);
         const int s0 = min(t, T - 1) * hop - a.g.pad + 256, o = 64 * g + c16;
 #endif
         if (!decltype(edge)::value) {
@@ -482,10 +514,10 @@ int pass2_mc_wgs_per_cu(int C) {
     return by_waves < by_lds ? (by_waves > 0 ? by_waves : 1) : (by_lds > 0 ? by_lds : 1);
 }
 
-template <int C>
+template <int C, bool PCM = false>
 static hipError_t launch_pass2_mc_t(const Pass2Args& a, int n_items, hipStream_t s) {
     const size_t lds = pass2_mc_lds_bytes(C);
-    auto k = beamform_istft_mc_kernel<C>;
+    auto k = beamform_istft_mc_kernel<C, PCM>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -493,17 +525,20 @@ static hipError_t launch_pass2_mc_t(const Pass2Args& a, int n_items, hipStream_t
     return hipGetLastError();
 }
 
-hipError_t launch_pass2_mc(int C, const Pass2Args& a, int n_items, hipStream_t s) {
+hipError_t launch_pass2_mc(int C, const Pass2Args& a, int n_items, hipStream_t s, bool pcm16) {
+#define SETK_CASE(c) \
+    case c: return pcm16 ? launch_pass2_mc_t<c, true>(a, n_items, s) : launch_pass2_mc_t<c>(a, n_items, s);
     switch (C) {
-        case 1: return launch_pass2_mc_t<1>(a, n_items, s);
-        case 2: return launch_pass2_mc_t<2>(a, n_items, s);
-        case 3: return launch_pass2_mc_t<3>(a, n_items, s);
-        case 4: return launch_pass2_mc_t<4>(a, n_items, s);
-        case 5: return launch_pass2_mc_t<5>(a, n_items, s);
-        case 6: return launch_pass2_mc_t<6>(a, n_items, s);
-        case 7: return launch_pass2_mc_t<7>(a, n_items, s);
-        case 8: return launch_pass2_mc_t<8>(a, n_items, s);
+        SETK_CASE(1)
+        SETK_CASE(2)
+        SETK_CASE(3)
+        SETK_CASE(4)
+        SETK_CASE(5)
+        SETK_CASE(6)
+        SETK_CASE(7)
+        SETK_CASE(8)
     }
+#undef SETK_CASE
     return hipErrorInvalidValue;
 }
 

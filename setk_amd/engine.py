@@ -7,6 +7,8 @@ This is the compute body of apply_adaptive_beamformer.py:130-178 for many
 utterances at once -- per-utterance work is microseconds on an MI355X, so the
 engineering unit is the batch, not the utterance.
 """
+import os
+
 import numpy as np
 
 from . import _ffi
@@ -202,6 +204,11 @@ class BatchEnhancer(object):
         self.opts_kw = dict(kind=kind, pmwf_beta=beta, pmwf_ref=int(pmwf_ref),
                             rank1=RANK1[rank1_appro])
         self.pcm16 = pcm16
+        # wave files' 16-bit samples go into the fused kernels as stored (de-interleaved, never
+        # widened to float32) when the geometry is the matrix-core pass 2's: hop = n_fft / 2
+        self.pcm_direct_ok = n_fft == 512 and 2 * frame_hop == n_fft and \
+            os.environ.get("SETK_PCM16_DIRECT", "1") != "0" and \
+            os.environ.get("SETK_MC_PASS2", "1") != "0" and os.environ.get("SETK_LEGACY_FFT", "0") == "0"
         self.vad_proportion = vad_proportion
         self.max_batch_samples = max_batch_samples
 
@@ -348,9 +355,20 @@ class BatchEnhancer(object):
         torch, ctx, dev = self.torch, self.ctx, self.dev
         audio, masks, itfs, waves, ns = [], [], [], [], []
         flags = self.base_flags | (0 if has_itf else _ffi.FLAG_CLAMP_MASK)
+        # 16-bit PCM all the way into the kernels (SETK_FLAG_IN_PCM16): no float32 copy exists
+        direct = self.pcm_direct_ok and all(isinstance(utts[i][0], Pcm16Frames) for i in batch) \
+            and not (0.5 < self.vad_proportion < 1)
+        if direct:
+            flags |= _ffi.FLAG_IN_PCM16
+        staged = []  # (interleaved frames on the device, N, planar destination)
         for i in batch:
             samps, mask, itf = utts[i]
-            if isinstance(samps, Pcm16Frames):
+            if isinstance(samps, Pcm16Frames) and direct:
+                pcm = torch.from_numpy(samps.frames).to(dev)
+                N = samps.frames.shape[0]
+                a = torch.empty((C, ctx.pcm16_channel_stride(N)), dtype=torch.int16, device=dev)
+                staged.append((pcm, N, a))
+            elif isinstance(samps, Pcm16Frames):
                 # the wav's 2-byte frames go up as they are; scaling and the
                 # transpose to C x N happen on the device
                 pcm = torch.from_numpy(samps.frames).to(dev)
@@ -384,6 +402,9 @@ class BatchEnhancer(object):
             waves.append(torch.empty(L, dtype=torch.int16 if self.pcm16 else torch.float32,
                                      device=dev))
             ns.append(N)
+        if staged:
+            ctx.pcm16_deinterleave_batch(C, [p.data_ptr() for p, _, _ in staged], [n for _, n, _ in staged],
+                                         [a.data_ptr() for _, _, a in staged])
         opts = _ffi.BfOpts(flags=flags, **self.opts_kw)
         status = ctx.enhance_batch(opts, C, [t.data_ptr() for t in audio], ns,
                                    [t.data_ptr() for t in masks],

@@ -467,10 +467,14 @@ class StreamPipeline(object):
             if j.itf is not None:
                 j.off_itf = off
                 off = _align(off + j.itf.nbytes)
+        # the device twin of a 16-bit payload: planar int16 [C][stride] (the fused kernels read
+        # it directly, SETK_FLAG_IN_PCM16) -- or float32 [C][N] when the batch mixes sample
+        # formats or the geometry is not the matrix-core pass 2's
+        direct = self.engine.pcm_direct_ok and all(j.pcm16 for j in batch)
         for j in batch:
             j.off_f32 = f32
             if j.pcm16:
-                f32 = _align(f32 + 4 * j.C * j.N)
+                f32 = _align(f32 + (2 * j.C * ((j.N + 7) & ~7) if direct else 4 * j.C * j.N))
             j.off_out = out
             out = _align(out + 2 * j.L)
         n = len(batch)
@@ -566,14 +570,16 @@ class StreamPipeline(object):
         ctx.stream_wait_event(self.s_compute, slot.e_in)
         stream = self.s_compute
         pcm = [j for j in jobs if j.pcm16]
+        direct = eng.pcm_direct_ok and len(pcm) == len(jobs)
         if pcm:
-            # int16 frames -> float32 C x N; sum(x0^2) of the k-th converted
-            # utterance lands at off_power + 8 k of the out-slab (log line only)
+            # int16 frames -> planar int16 C x stride (or float32 C x N); sum(x0^2) of the k-th
+            # converted utterance lands at off_power + 8 k of the out-slab (log line only)
             for k, j in enumerate(pcm):
                 j.pw_idx = k
-            ctx.pcm16_to_float_batch(C, [base_in + j.off_audio for j in pcm],
-                                     [j.N for j in pcm], [base_f32 + j.off_f32 for j in pcm],
-                                     power0=base_out + off_power, stream=stream)
+            ingest = ctx.pcm16_deinterleave_batch if direct else ctx.pcm16_to_float_batch
+            ingest(C, [base_in + j.off_audio for j in pcm],
+                   [j.N for j in pcm], [base_f32 + j.off_f32 for j in pcm],
+                   power0=base_out + off_power, stream=stream)
         tt.append(time.perf_counter())
         aptr = [(base_f32 + j.off_f32) if j.pcm16 else (base_in + j.off_audio) for j in jobs]
         mptr = [base_in + j.off_mask for j in jobs]
@@ -582,7 +588,8 @@ class StreamPipeline(object):
         kind = eng.opts_kw["kind"]
         if has_itf and kind == _ffi.BF_MPDR:
             iptr = None  # plain MPDR never reads the interferer mask
-        flags = eng.base_flags | _ffi.FLAG_OUT_PCM16 | (0 if has_itf else _ffi.FLAG_CLAMP_MASK)
+        flags = eng.base_flags | _ffi.FLAG_OUT_PCM16 | (0 if has_itf else _ffi.FLAG_CLAMP_MASK) | \
+            (_ffi.FLAG_IN_PCM16 if direct else 0)
         opts = _ffi.BfOpts(flags=flags, **eng.opts_kw)
         # status of job i at off_status + 4 * i (positions within `jobs`)
         ctx.enhance_batch(opts, C, aptr, [j.N for j in jobs], mptr, iptr, wptr,

@@ -473,3 +473,137 @@ def test_strict_reference_leaves_the_weights_alone():
             assert np.array_equal(y0[0], y1[0]) and np.array_equal(y0[2], y1[2])
     finally:
         c.close()
+
+
+def _enhance_pcm16(ctx, opts, frames_list, masks):
+    """frames_list: int16 [N][C] arrays (a wave file's frames).  De-interleaved on the device
+    (setk_pcm16_deinterleave_batch) and enhanced with SETK_FLAG_IN_PCM16: no float32 copy."""
+    from setk_amd import _ffi
+    dev = torch.device("cuda:0")
+    C = frames_list[0].shape[1]
+    src = [torch.from_numpy(np.ascontiguousarray(f)).to(dev) for f in frames_list]
+    ns = [f.shape[0] for f in frames_list]
+    planar = [torch.full((C, ctx.pcm16_channel_stride(n)), 12345, dtype=torch.int16, device=dev) for n in ns]
+    power = torch.zeros(len(ns), dtype=torch.float64, device=dev)
+    ctx.pcm16_deinterleave_batch(C, [t.data_ptr() for t in src], ns, [t.data_ptr() for t in planar],
+                                 power0=power.data_ptr())
+    m = [torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev) for x in masks]
+    outs = [torch.empty(ctx.istft_num_samples(ctx.num_frames(n)), dtype=torch.float32, device=dev) for n in ns]
+    opts.flags |= _ffi.FLAG_IN_PCM16
+    st = ctx.enhance_batch(opts, C, [t.data_ptr() for t in planar], ns, [t.data_ptr() for t in m], None,
+                           [t.data_ptr() for t in outs])
+    torch.cuda.synchronize()
+    return [t.cpu().numpy() for t in outs], st, [t.cpu().numpy() for t in planar], power.cpu().numpy()
+
+
+@pytest.mark.parametrize("kind", ["mvdr", "gevd", "pmwf-0", "mpdr-whiten"])
+@pytest.mark.parametrize("C,lens", [(8, [20000, 9001, 33333]), (4, [16000, 5003]), (5, [7001]), (1, [6000]),
+                                    (2, [12345, 4097, 8190]), (6, [10007])])
+def test_pcm16_input_is_the_float_path_bit_for_bit(ctx, kind, C, lens):
+    """SETK_FLAG_IN_PCM16 (SURVEY 8f-3 'int16 ingest on device'): both streaming kernels read
+    the wave file's 16-bit samples (planar int16, 2 bytes per sample) and scale by 2^-15 inside
+    their transforms.  Reference: read_wav's dtype='float32' read, int16 / 32768
+    (libs/utils.py:80-90).  Because the scale is a power of two folded into the window tables,
+    the waveform equals the float32 call on pcm / 32768 BIT FOR BIT -- and so holds the same
+    1e-3 bar against the oracle on the dequantised samples.  Ragged batches, odd lengths (the
+    channel stride is padded to a multiple of 8), every channel count class."""
+    from setk_amd import _ffi
+    if C == 1 and kind not in ("mvdr", "pmwf-0"):
+        pytest.skip("single channel: covered by mvdr/pmwf")
+    frames, floats, masks = [], [], []
+    for i, n in enumerate(lens):
+        mix, sp, nz = o.synth_utterance(700 + 10 * C + i, C, n, return_parts=True)
+        pcm = np.clip(np.rint(mix.T * 32767.0 * 4.0), -32768, 32767).astype(np.int16)  # [N][C], near full scale
+        frames.append(pcm)
+        floats.append(np.ascontiguousarray(pcm.T.astype(np.float32) / 32768.0))
+        masks.append(o.irm_mask(sp, nz))
+    ys, st, planar, power = _enhance_pcm16(ctx, _ffi.BfOpts(flags=_ffi.FLAG_CLAMP_MASK, **KINDS[kind]), frames, masks)
+    yf, stf = run_batch(ctx, _ffi.BfOpts(flags=_ffi.FLAG_CLAMP_MASK, **KINDS[kind]), floats, masks)
+    assert st == [0] * len(lens) and stf == st
+    for i, n in enumerate(lens):
+        # the planar copy: the file's samples, channel major, the padding zeroed
+        assert np.array_equal(planar[i][:, :n], frames[i].T) and not planar[i][:, n:].any()
+        assert abs(power[i] - float(np.sum(floats[i][0].astype(np.float64) ** 2))) <= 1e-4 * max(power[i], 1e-9)
+        assert np.array_equal(ys[i], yf[i]), (kind, C, n, rms(ys[i], yf[i]) / rms(yf[i]))
+    ref = o.enhance_utterance(floats[0], masks[0], kind=kind, gauge=True)
+    assert rms(ys[0], ref) / rms(ref) < 1e-3
+
+
+def test_pcm16_input_flags_edges_and_taps(ctx):
+    """The same identity with BAN + post-mask, an interferer mask, PCM16 output, a batch that
+    is cut into several frame ranges per utterance (partial slabs, carries across ranges), and
+    the taps: covariances, weights and max |x| equal those of the float call."""
+    from setk_amd import _ffi
+    dev = torch.device("cuda:0")
+    C, lens = 8, [160000, 40000]
+    frames, floats, masks, itf = [], [], [], []
+    for i, n in enumerate(lens):
+        mix, sp, nz = o.synth_utterance(760 + i, C, n, return_parts=True)
+        pcm = np.rint(mix.T * 32767.0 * 2.0).astype(np.int16)
+        frames.append(pcm)
+        floats.append(np.ascontiguousarray(pcm.T.astype(np.float32) / 32768.0))
+        m = o.irm_mask(sp, nz)
+        masks.append(m)
+        itf.append((1 - m) ** 2)
+    for flags, use_itf in ((_ffi.FLAG_CLAMP_MASK | _ffi.FLAG_BAN | _ffi.FLAG_POST_MASK, False), (0, True)):
+        src = [torch.from_numpy(f).to(dev) for f in frames]
+        planar = [torch.empty((C, ctx.pcm16_channel_stride(n)), dtype=torch.int16, device=dev) for n in lens]
+        ctx.pcm16_deinterleave_batch(C, [t.data_ptr() for t in src], lens, [t.data_ptr() for t in planar])
+        fl = [torch.from_numpy(f).to(dev) for f in floats]
+        m = [torch.from_numpy(x).to(dev) for x in masks]
+        it = [torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev) for x in itf] if use_itf else None
+        res = {}
+        for name, aud, extra in (("pcm", planar, _ffi.FLAG_IN_PCM16), ("f32", fl, 0)):
+            outs = [torch.empty(ctx.istft_num_samples(ctx.num_frames(n)), dtype=torch.int16, device=dev) for n in lens]
+            taps = dict(Rs=torch.empty((2, 257, C, C), dtype=torch.complex64, device=dev),
+                        Rn=torch.empty((2, 257, C, C), dtype=torch.complex64, device=dev),
+                        weight=torch.empty((2, 257, C), dtype=torch.complex64, device=dev),
+                        maxabs=torch.empty(2, dtype=torch.float32, device=dev))
+            st = ctx.enhance_batch(_ffi.BfOpts(flags=flags | extra | _ffi.FLAG_OUT_PCM16, **KINDS["mvdr"]), C,
+                                   [t.data_ptr() for t in aud], lens, [t.data_ptr() for t in m],
+                                   None if it is None else [t.data_ptr() for t in it],
+                                   [t.data_ptr() for t in outs], taps=taps)
+            torch.cuda.synchronize()
+            assert st == [0, 0]
+            res[name] = [t.cpu().numpy() for t in outs] + [v.cpu().numpy() for v in taps.values()]
+        for a, b in zip(res["pcm"], res["f32"]):
+            assert np.array_equal(a, b)
+        assert res["pcm"][-1][0] == np.abs(floats[0]).max()
+
+
+def test_pcm16_input_needs_the_half_overlap_geometry():
+    from setk_amd import _ffi
+    c = _ffi.Context(0)
+    c.stft_plan(512, 128, 512, True)
+    try:
+        dev = torch.device("cuda:0")
+        a = torch.zeros((2, 8000), dtype=torch.int16, device=dev)
+        m = torch.full((c.num_frames(8000), 257), 0.5, dtype=torch.float32, device=dev)
+        out = torch.empty(c.istft_num_samples(c.num_frames(8000)), dtype=torch.float32, device=dev)
+        with pytest.raises(Exception) as e:
+            c.enhance_batch(_ffi.BfOpts(flags=_ffi.FLAG_IN_PCM16, kind=0), 2, [a.data_ptr()], [8000],
+                            [m.data_ptr()], None, [out.data_ptr()])
+        assert "hop" in str(e.value)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("scale", [32768.0, 3.0, 1e4, 2.0 ** 40])
+@pytest.mark.parametrize("kind", ["mvdr", "gevd"])
+def test_float_samples_beyond_unit_range(ctx, kind, scale):
+    """The reference's STFT / iSTFT is scale free (libs/utils.py:96-173): float wave files,
+    WaveReader(normalize=False)'s int16-range floats or any C-API caller may hand in |x| >> 1.
+    The matrix-core transforms of pass 2 split window x sample x 2^10 into fp16 operands (65504
+    ends that range); they take the utterance's max |x| from pass 1 and scale by a power of two
+    (round 4 assumed |x| <= 1 and produced inf / NaN beyond ~64).  The beamformer is linear and
+    the renorm targets max |x|: the output scales with the input."""
+    from setk_amd import _ffi
+    mix, sp, nz = o.synth_utterance(41, 4, 24000, return_parts=True)
+    mask = o.irm_mask(sp, nz)
+    opts = lambda: _ffi.BfOpts(flags=_ffi.FLAG_CLAMP_MASK, **KINDS[kind])  # noqa: E731
+    (y1,), st1 = run_batch(ctx, opts(), [mix], [mask])
+    (ys,), sts = run_batch(ctx, opts(), [(mix * np.float32(scale))], [mask])
+    assert st1 == [0] and sts == [0] and np.isfinite(ys).all()
+    assert rms(ys / scale, y1) / rms(y1) < 2e-5
+    ref = o.enhance_utterance(mix * np.float32(scale), mask, kind=kind, gauge=True)
+    assert rms(ys, ref) / rms(ref) < 1e-3
