@@ -509,7 +509,9 @@ def pmc_leg(args, child=None, kernels=None, pcm=False):
                         kname = next((k for k in knames if k + "<" in row["Kernel_Name"]), None)
                         # the streaming kernels' last template argument: 16-bit PCM input
                         is_pcm = ", true>(" in row["Kernel_Name"] or row["Kernel_Name"].rstrip().endswith(", true>")
-                        if kname and (key not in ("pass1", "pass2") or is_pcm == pcm):
+                        # (stft_covar_kernel<C, true, false> is the spectrogram dump of setk_stft)
+                        if kname and ", true, false>" not in row["Kernel_Name"] and \
+                                (key not in ("pass1", "pass2") or is_pcm == pcm):
                             acc.setdefault(key, {})["__kernel__"] = kname
                             d = acc[key].setdefault(row["Counter_Name"], [])
                             d.append((float(row["Counter_Value"]),
@@ -828,11 +830,11 @@ def int16_ingest_leg(args, ctx, _ffi, torch, opts, audio, masks, waves, C, N, T,
     step()
     torch.cuda.synchronize()
     got = [waves[i].clone() for i in range(nd)]
-    fw = [torch.empty(L, dtype=torch.float32, device=dev) for _ in range(nd)]
-    ctx.enhance_batch(opts, C, [t.data_ptr() for t in f32q], [N] * nd, mptr[:nd], None,
-                      [t.data_ptr() for t in fw], want_status=True)
+    # (the same batch of U utterances: the work list -- hence the order in which an utterance's
+    #  partial covariance slabs are summed -- depends on the batch)
+    ctx.enhance_batch(opts, C, [f32q[i % nd].data_ptr() for i in range(U)], ns, mptr, None, wptr, want_status=True)
     torch.cuda.synchronize()
-    identical = all(bool(torch.equal(a, b)) for a, b in zip(got, fw))
+    identical = all(bool(torch.equal(got[i], waves[i])) for i in range(nd))
     b_k1 = U * (2.0 * C * N + 4.0 * T * F)
     b_k2 = U * (2.0 * C * N + 4.0 * L)
     b_all = U * (2.0 * C * N + 4.0 * T * F + 4.0 * L)

@@ -434,6 +434,27 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
                             const float* const* mask_n, void* const* wave,
                             int* status, const setk_batch_taps* taps, void* stream);
 
+/* ---- multi-GPU: the work-queue barrier on RCCL ------------------------------
+ * The path shards by utterance with no data exchange (the reference: split_scp.pl + run.pl
+ * JOB=1:nj, scripts/run_adapt_beamformer.sh:69-92).  One process per GPU needs a start / finish
+ * barrier and the sums of its "Processed N utterances" counters: an all-reduce of a few
+ * doubles over xGMI.  librccl is dlopen'ed on first use.  Rendezvous: rank 0 calls
+ * setk_comm_unique_id, the caller carries the SETK_COMM_ID_BYTES to every rank (setk_amd/
+ * dist.py: a TCP socket on MASTER_ADDR:MASTER_PORT), every rank calls setk_comm_create
+ * (collective).  values: host array, reduced in place over all ranks (n <= 64).
+ * SETK_ERR_UNSUPPORTED: librccl is not available (setk_comm_last_error has the reason). */
+#define SETK_COMM_ID_BYTES 128
+#define SETK_COMM_SUM 0
+#define SETK_COMM_MAX 1
+typedef struct setk_comm* setk_comm_t;
+int setk_comm_unique_id(char out[SETK_COMM_ID_BYTES]);
+int setk_comm_create(setk_comm_t* out, int device_ordinal, const char id[SETK_COMM_ID_BYTES],
+                     int rank, int world);
+int setk_comm_allreduce_f64(setk_comm_t c, double* values, int n, int op);
+int setk_comm_barrier(setk_comm_t c);
+int setk_comm_destroy(setk_comm_t c);
+const char* setk_comm_last_error(void);
+
 /* Stage timings (ms, hipEvent on `stream`) of the most recent
  * setk_enhance_batch when profiling was enabled with setk_set_profiling(h,1):
  * out[0] = the fused STFT+covariance kernel alone, out[1] = partial reduction +

@@ -103,7 +103,9 @@ def exported_symbols():
         "setk_cgmm_masks_batch", "setk_cgmm_estimate_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
         "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_wpe_batch", "setk_wpe_batch_fnt", "setk_set_profiling",
-        "setk_last_stage_ms"
+        "setk_last_stage_ms",
+        "setk_comm_unique_id", "setk_comm_create", "setk_comm_allreduce_f64", "setk_comm_barrier",
+        "setk_comm_destroy", "setk_comm_last_error"
     ]
 
 

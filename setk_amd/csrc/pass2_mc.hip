@@ -66,6 +66,16 @@ SETK_DEV void load_raw_mc2(float (&v)[8], FloatPtr x, int n_samp, int s, int lan
 #ifndef SETK_P2MC_WLDS
 #define SETK_P2MC_WLDS 1
 #endif
+// streaming (nontemporal) hint on the loads whose data is not read again (see load_full)
+#ifndef SETK_P2MC_NT
+#define SETK_P2MC_NT 1
+#endif
+// samples requested TWO transforms ahead of their use (groups of two frames only): while frame
+// (t0, c) is transformed the whole frame (t0, c + 1) is in flight, and the second half of
+// (t0 + 1, c) landed during the previous transform -- 12 registers in flight instead of 8
+#ifndef SETK_P2MC_PF2
+#define SETK_P2MC_PF2 0
+#endif
 struct False { static constexpr bool value = false; };
 struct True { static constexpr bool value = true; };
 constexpr int kP2McThreads = SETK_P2MC_THREADS;
@@ -259,8 +269,17 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
         if (!decltype(edge)::value) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+#if SETK_P2MC_NT
+                // both halves of a group's first frame are read for the last time here (the first
+                // one is the re-read of what the previous group fetched as ITS last half): a
+                // streaming hint keeps them from pushing the halves that WILL be read again --
+                // load_half's -- out of the XCD's L2
+                v[e] = __builtin_nontemporal_load(&x[s0 + o + 16 * e]);
+                v[4 + e] = __builtin_nontemporal_load(&x[s0 + o + 256 + 16 * e]);
+#else
                 v[e] = x[s0 + o + 16 * e];
                 v[4 + e] = x[s0 + o + 256 + 16 * e];
+#endif
             }
         } else {
 #pragma unroll
@@ -289,6 +308,21 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
             for (int e = 0; e < 4; ++e) v[4 + e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
         }
     };
+#if SETK_P2MC_PF2
+    static_assert(SETK_P2MC_GROUP == 2, "the two-ahead prefetch is written for groups of two frames");
+    float nxth[4];  // second half of frame t0 + 1 of the NEXT channel
+    auto load_half4 = [&](float (&v)[4], int t, int c, auto edge) __attribute__((always_inline)) {
+        const auto x = chan(c);
+        const int s0 = min(t, T - 1) * hop - a.g.pad + 256, o = 64 * g + c16;
+        if (!decltype(edge)::value) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = x[s0 + o + 16 * e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
+        }
+    };
+#endif
     mc::f4 yr[R], yi[R];
     // the R transforms of every channel of one group; `nxt` arrives holding frame (t0, channel 0)
     // and leaves holding frame (t0 + R, channel 0)
@@ -309,12 +343,26 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
             float x[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = nxt[e];
+#if SETK_P2MC_PF2
+            float xh[4];  // this channel's second half of frame t0 + 1 (requested one channel ago)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xh[e] = nxth[e];
+#endif
 #pragma unroll
             for (int k = 0; k < R; ++k) {
+#if SETK_P2MC_PF2
+                // two transforms ahead: during (t0, c) the whole frame (t0, c + 1), during
+                // (t0 + 1, c) the second half of (t0 + 1, c + 1)
+                if (c + 1 < C) {
+                    if (k == 0) load_full(nxt, t0, c + 1, edge);
+                    else load_half4(nxth, t0 + 1, c + 1, edge);
+                }
+#else
                 // what comes next travels while this transform runs: the second half of the
                 // next frame of the group, or the first frame of the next channel / group
                 if (k + 1 < R) load_half(nxt, t0 + k + 1, c, edge);
                 else if (c + 1 < C) load_full(nxt, t0, c + 1, edge);
+#endif
                 mc::f4 zr, zi, a16;
 #if SETK_P2MC_KLDS && SETK_P2MC_WLDS
                 {
@@ -344,7 +392,11 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         x[e] = x[4 + e];
+#if SETK_P2MC_PF2
+                        x[4 + e] = xh[e];
+#else
                         x[4 + e] = nxt[4 + e];
+#endif
                     }
                 }
                 // one transform at a time: interleaved by the scheduler, the R unrolled
@@ -357,19 +409,26 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
         const int lo = t0 * hop - a.g.pad, hi = (t0 + R - 1) * hop - a.g.pad + kNfft;
         return lo < 0 || hi > n_samp || t0 + R > T;
     };
-    if (tw < tb) {
-        if (span_is_edge(tw)) load_full(nxt, tw, 0, True());
-        else load_full(nxt, tw, 0, False());
-    }
+    auto request_group = [&](int t0) __attribute__((always_inline)) {
+        if (span_is_edge(t0)) {
+            load_full(nxt, t0, 0, True());
+#if SETK_P2MC_PF2
+            load_half4(nxth, t0 + 1, 0, True());
+#endif
+        } else {
+            load_full(nxt, t0, 0, False());
+#if SETK_P2MC_PF2
+            load_half4(nxth, t0 + 1, 0, False());
+#endif
+        }
+    };
+    if (tw < tb) request_group(tw);
 #pragma unroll 1
     for (int t0 = tw; t0 < tb; t0 += R) {
         const int nf = min(R, tb - t0);
         if (span_is_edge(t0)) group(t0, True());
         else group(t0, False());
-        if (t0 + R < tb) {  // first frame of the next group (issued here: its span decides the path)
-            if (span_is_edge(t0 + R)) load_full(nxt, t0 + R, 0, True());
-            else load_full(nxt, t0 + R, 0, False());
-        }
+        if (t0 + R < tb) request_group(t0 + R);  // (issued here: its span decides the path)
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             if (k >= nf) break;

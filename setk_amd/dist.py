@@ -2,15 +2,110 @@
 Utterance sharding over the GPUs of one node.
 
 The reference parallelises this path with ``split_scp.pl`` + ``run.pl JOB=1:nj``
-(scripts/run_adapt_beamformer.sh:69-92): contiguous scp shards, one process
-each, no communication.  Here: one process per GPU (torchrun), utterances are
-independent units dealt to ranks by duration (longest first, each to the least
-loaded rank) and
-RCCL (torch.distributed backend "nccl") carries only the start/finish barrier
-and the three counters of the final "Processed N utterances" line.  There is no
-data-path collective because the path has no exchange step.
+(scripts/run_adapt_beamformer.sh:69-92): contiguous scp shards, one process each, no
+communication.  Here: one process per GPU (any launcher that exports RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT, e.g. ``python -m torch.distributed.run``); utterances
+are independent units dealt to ranks by duration (longest first, each to the least loaded rank),
+and the ranks exchange only the start / finish barrier and the counters of the final "Processed N
+utterances" line.  There is no data-path collective because the path has no exchange step.
+
+Backends of those few bytes (``Shard(backend=...)`` or SETK_DIST_BACKEND):
+
+  rccl   (default on a GPU node) RCCL over xGMI through the library's own C entry points
+         (setk_comm_*, csrc/comm.hip): no ``import torch`` in any rank -- 1 - 2 s of start-up
+         per rank saved.  Rendezvous: rank 0's ncclUniqueId travels over a TCP socket on
+         MASTER_ADDR:MASTER_PORT.
+  tcp    the same exchange over that socket alone (rank 0 gathers and answers): for hosts
+         without a GPU per rank -- the CPU tests of the multi-rank command line -- and as the
+         fallback when librccl cannot be loaded.
+  nccl / gloo   torch.distributed, as in rounds 1 - 4; taken only when asked for, or when the
+         loaded library predates setk_comm_*.
 """
 import os
+import socket
+import struct
+import time
+
+
+def _recv_exact(sock, n):
+    buf = b""
+    while len(buf) < n:
+        part = sock.recv(n - len(buf))
+        if not part:
+            raise ConnectionError("peer closed the rendezvous socket")
+        buf += part
+    return buf
+
+
+class _Star(object):
+    """Rank 0 listens on MASTER_ADDR:MASTER_PORT, ranks 1..W-1 connect (with retries while the
+    listener comes up) and stay connected: a W-way exchange is one round trip through rank 0.
+    Carries the RCCL rendezvous (128 bytes) and, as backend "tcp", the barrier and the sums."""
+
+    def __init__(self, rank, world, addr, port, timeout=300.0):
+        self.rank, self.world = rank, world
+        self.peers = []
+        self.sock = None
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            got = {}
+            while len(got) < world - 1:
+                c, _ = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.settimeout(timeout)
+                r = struct.unpack("<i", _recv_exact(c, 4))[0]
+                got[r] = c
+            srv.close()
+            self.peers = [got[r] for r in range(1, world)]
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    s = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.settimeout(timeout)
+            s.sendall(struct.pack("<i", rank))
+            self.sock = s
+
+    def broadcast(self, payload, nbytes):
+        """rank 0's `payload` (bytes) to everybody."""
+        if self.rank == 0:
+            for c in self.peers:
+                c.sendall(payload)
+            return payload
+        return _recv_exact(self.sock, nbytes)
+
+    def allreduce(self, values, op="sum"):
+        n = len(values)
+        fmt = "<%dd" % n
+        if self.rank == 0:
+            acc = [float(v) for v in values]
+            for c in self.peers:
+                other = struct.unpack(fmt, _recv_exact(c, 8 * n))
+                acc = [max(a, b) if op == "max" else a + b for a, b in zip(acc, other)]
+            out = struct.pack(fmt, *acc)
+            for c in self.peers:
+                c.sendall(out)
+            return acc
+        self.sock.sendall(struct.pack(fmt, *[float(v) for v in values]))
+        return list(struct.unpack(fmt, _recv_exact(self.sock, 8 * n)))
+
+    def close(self):
+        for c in self.peers + ([self.sock] if self.sock else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers, self.sock = [], None
 
 
 class Shard:
@@ -20,31 +115,102 @@ class Shard:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self._dist = None
+        self._dist = None    # torch.distributed (legacy backends)
+        self._star = None    # the TCP star (rendezvous, backend "tcp")
+        self._comm = None    # setk_comm_t (backend "rccl")
+        self._lib = None
+        self.backend = None
         self.assigned_weight = 0.0
-        if self.world > 1:
-            import torch
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if "MASTER_PORT" not in os.environ:
-                # the ranks can only agree on a port through their launcher
-                raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: start the ranks with "
-                                   "`python -m torch.distributed.run --master-addr 127.0.0.1 "
-                                   "--master-port <free port> ...` (or export MASTER_PORT)")
-            if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
-            if not dist.is_initialized():
-                kw = {}
-                if backend == "nccl":
-                    torch.cuda.set_device(self.local_rank)
-                    kw["device_id"] = torch.device("cuda", self.local_rank)
-                dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
-            self._dist = dist
-            self.backend = backend
+        if self.world <= 1:
+            return
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            # the ranks can only agree on a port through their launcher
+            raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: start the ranks with "
+                               "`python -m torch.distributed.run --master-addr 127.0.0.1 "
+                               "--master-port <free port> ...` (or export MASTER_PORT)")
+        backend = backend or os.environ.get("SETK_DIST_BACKEND") or "rccl"
+        if backend in ("rccl", "tcp"):
+            # connected at the first collective: a command line decides whether it runs
+            # torch-free (which fixes how the library is loaded) after it has seen its inputs
+            self._want = backend
+            return
+        self._init_torch(backend)
+
+    _want = None
+
+    def _ensure(self):
+        if self._want is None:
+            return
+        backend, self._want = self._want, None
+        # (the launcher's own store listens on MASTER_PORT: the star takes the next port)
+        addr, port = os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1 + \
+            int(os.environ.get("SETK_DIST_PORT_OFFSET", "0"))
+        self._star = _Star(self.rank, self.world, addr, port)
+        if backend == "rccl" and not self._init_rccl():
+            backend = "tcp"
+        self.backend = backend
+
+    def _init_rccl(self):
+        """RCCL through the C ABI.  Every rank learns whether ALL of them can (library with
+        setk_comm_*, librccl loadable, a GPU): one cannot fall back alone."""
+        import ctypes
+        from . import _ffi
+        lib, ok, uid = None, 1.0, b"\0" * 128
+        try:
+            lib = _ffi.load_library()
+            if not hasattr(lib, "setk_comm_create") or not os.path.exists("/dev/kfd"):
+                ok = 0.0  # (a library from before round 5, or no GPU driver on this host)
+            elif self.rank == 0:
+                buf = ctypes.create_string_buffer(128)
+                if lib.setk_comm_unique_id(buf) != 0:
+                    ok = 0.0
+                uid = buf.raw
+        except Exception:  # noqa: BLE001  (no library / no GPU: the star alone carries the job)
+            ok = 0.0
+        if sum(self._star.allreduce([ok])) < self.world:
+            return False
+        uid = self._star.broadcast(uid, 128)
+        comm = ctypes.c_void_p()
+        lib.setk_comm_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_char_p,
+                                         ctypes.c_int, ctypes.c_int]
+        lib.setk_comm_allreduce_f64.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                                ctypes.c_int, ctypes.c_int]
+        lib.setk_comm_barrier.argtypes = [ctypes.c_void_p]
+        lib.setk_comm_destroy.argtypes = [ctypes.c_void_p]
+        lib.setk_comm_last_error.restype = ctypes.c_char_p
+        rc = lib.setk_comm_create(ctypes.byref(comm), self.local_rank, uid, self.rank, self.world)
+        good = 1.0 if rc == 0 else 0.0
+        if sum(self._star.allreduce([good])) < self.world:
+            if rc == 0:
+                lib.setk_comm_destroy(comm)
+            return False
+        self._lib, self._comm = lib, comm
+        return True
+
+    def _init_torch(self, backend):
+        import torch
+        import torch.distributed as dist
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if not dist.is_initialized():
+            kw = {}
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                kw["device_id"] = torch.device("cuda", self.local_rank)
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+        self._dist = dist
+        self.backend = backend
 
     @property
     def device(self):
         return self.local_rank
+
+    @property
+    def torch_free_ok(self):
+        """A command line may run without torch: alone, or with the library's own collectives
+        (the torch.distributed backends bring torch in themselves)."""
+        return self.world <= 1 or self._dist is None
 
     def assign(self, keys, weights=None):
         """Keys owned by this rank.  With weights (e.g. durations) the keys are
@@ -68,21 +234,52 @@ class Shard:
         self.assigned_weight = sum(wsum[k] for k in mine)
         return mine
 
+    def _allreduce(self, values, op="sum"):
+        self._ensure()
+        values = [float(v) for v in values]
+        if self._comm is not None:
+            import ctypes
+            out = []
+            for i in range(0, len(values), 64):
+                chunk = values[i:i + 64]
+                arr = (ctypes.c_double * len(chunk))(*chunk)
+                rc = self._lib.setk_comm_allreduce_f64(self._comm, arr, len(chunk), 1 if op == "max" else 0)
+                if rc != 0:
+                    raise RuntimeError("setk_comm_allreduce_f64: " +
+                                       (self._lib.setk_comm_last_error() or b"?").decode())
+                out.extend(arr)
+            return out
+        if self._star is not None:
+            return self._star.allreduce(values, op)
+        import torch
+        dev = torch.device("cuda", self.local_rank) if self.backend == "nccl" else "cpu"
+        t = torch.tensor(values, dtype=torch.float64, device=dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX if op == "max" else self._dist.ReduceOp.SUM)
+        return t.cpu().tolist()
+
     def barrier(self):
-        if self._dist is not None:
-            self._dist.barrier()
+        if self.world > 1:
+            self._allreduce([1.0])
 
     def sum_counts(self, values):
         """Element-wise sum of a short list of python numbers over all ranks."""
-        if self._dist is None:
+        if self.world <= 1:
             return list(values)
-        import torch
-        dev = torch.device("cuda", self.local_rank) if self.backend == "nccl" else "cpu"
-        t = torch.tensor(list(values), dtype=torch.float64, device=dev)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
-        return t.cpu().tolist()
+        return self._allreduce(values, "sum")
+
+    def max_values(self, values):
+        """Element-wise maximum over all ranks (wall clocks)."""
+        if self.world <= 1:
+            return list(values)
+        return self._allreduce(values, "max")
 
     def close(self):
+        if self._comm is not None:
+            self._lib.setk_comm_destroy(self._comm)
+            self._comm = None
+        if self._star is not None:
+            self._star.close()
+            self._star = None
         if self._dist is not None and self._dist.is_initialized():
             self._dist.destroy_process_group()
             self._dist = None

@@ -913,3 +913,358 @@ class BatchDereverb(object):
         host = waves.cpu().numpy()
         return [None if _ffi.wpe_failed(status[u]).any() else host[o:o + C * L].reshape(C, L)
                 for u, (o, L) in enumerate(views)]
+
+
+class _Twin(object):
+    """A grow-only page-locked host buffer with a device twin (one memcpy up or down per batch)."""
+
+    def __init__(self, ctx):
+        self.ctx, self.cap, self.h, self.d, self.view = ctx, 0, 0, 0, None
+
+    def reserve(self, nbytes, stream):
+        if nbytes > self.cap:
+            self.ctx.stream_synchronize(stream)
+            self.close()
+            self.cap = int(nbytes * 1.25) + 256
+            self.h, self.view = self.ctx.host_alloc(self.cap)
+            self.d = self.ctx.device_alloc(self.cap)
+
+    def close(self):
+        if self.h:
+            self.view = None
+            self.ctx.host_free(self.h)
+            self.ctx.device_free(self.d)
+        self.cap, self.h, self.d = 0, 0, 0
+
+
+class BatchDirectionalFeatures(object):
+    """Directional features from TF masks for a batch of utterances, resident on the device.
+
+    Replaces the per-utterance body of funcwj/setk scripts/sptk/compute_df_on_mask.py:40-54
+    (SpectrogramReader -> compute_covar -> solve_pevd -> directional_feats, libs/spatial.py:
+    184-208): the samples of a batch go up in one slab, ONE setk_stft_batch launch writes every
+    spectrogram, and per utterance setk_covar -> setk_pevd -> setk_directional_feats run on
+    device pointers -- the spectrogram (31 MB at 8 ch x 30 s), the covariance and the steer
+    vector never visit the host; one slab of T x F features and the per-bin status words comes
+    down per batch.  run() takes [(samps C x N float32 | Pcm16Frames, mask T x F or F x T)] and
+    returns [(features T x F float32 | None, status)]: status != 0 is numpy's LinAlgError case
+    (np.linalg.eigh on a non-finite covariance).  Other transform sizes and more than 8 channels
+    go through the stand-alone operators of setk_amd.libs (numpy in, numpy out)."""
+
+    def __init__(self, df_pair, frame_len=512, frame_hop=256, center=True, round_power_of_two=True,
+                 window="hann", device=None, max_batch_samples=1 << 28):
+        pairs = [(int(i), int(j)) for i, j in df_pair]
+        if not pairs:
+            raise ValueError("no microphone pair given")
+        self.pairs = pairs
+        self.ctx = _ffi.default_context(device)
+        n_fft = nextpow2(frame_len) if round_power_of_two else frame_len
+        self.stft = dict(frame_len=frame_len, frame_hop=frame_hop, n_fft=n_fft, center=center,
+                         window=stft_window(window, frame_len))
+        self.window_name = window
+        self.round_power_of_two = round_power_of_two
+        self.num_bins = n_fft // 2 + 1
+        self.max_batch_samples = max_batch_samples
+        self._slabs = None
+        self._masks = None
+        self._scratch, self._scratch_cap = 0, 0
+
+    def close(self):
+        b, self._slabs = self._slabs, None
+        if b:
+            b.close()
+        if self._masks is not None:
+            self._masks.close()
+            self._masks = None
+        if self._scratch:
+            self.ctx.device_free(self._scratch)
+            self._scratch, self._scratch_cap = 0, 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def condition_mask(self, mask, T):
+        """compute_df_on_mask.py:44-47: F x T masks are turned, values above one clipped."""
+        F = self.num_bins
+        m = np.asarray(mask)
+        if m.ndim != 2:
+            raise ValueError(f"mask must be 2-D, got {m.shape}")
+        if m.shape[0] == F and m.shape != (T, F):
+            m = m.T
+        if m.shape != (T, F):
+            raise ValueError(f"mask {np.asarray(mask).shape} does not fit {T} frames x {F} bins")
+        return np.minimum(m, 1).astype(np.float32, copy=False)
+
+    def run(self, utts):
+        s = self.stft
+        self.ctx.stft_plan(s["frame_len"], s["frame_hop"], s["n_fft"], s["center"], s["window"])
+        out = [None] * len(utts)
+        by_channels = {}
+        for i, (samps, _) in enumerate(utts):
+            by_channels.setdefault(_channels_and_size(samps)[0], []).append(i)
+        for C, idx in by_channels.items():
+            if any(max(p) >= C or min(p) < 0 for p in self.pairs):
+                raise ValueError(f"microphone pair out of range for {C} channels: {self.pairs}")
+            if s["n_fft"] != 512 or C > 8:
+                for i in idx:
+                    out[i] = self._one_by_operators(*utts[i])
+                continue
+            batch, load = [], 0
+            for i in idx:
+                n = _channels_and_size(utts[i][0])[1]
+                if batch and load + n > self.max_batch_samples:
+                    self._run_resident(utts, batch, C, out)
+                    batch, load = [], 0
+                batch.append(i)
+                load += n
+            if batch:
+                self._run_resident(utts, batch, C, out)
+        return out
+
+    def _run_resident(self, utts, batch, C, out):
+        ctx, F = self.ctx, self.num_bins
+        if self._slabs is None:
+            self._slabs = _Slabs(ctx)
+            self._masks = _Twin(ctx)
+        b, mk = self._slabs, self._masks
+        al = lambda v: (v + 255) & ~255  # noqa: E731
+        # out-slab per utterance: [features T x F float32 | status int32[F]]
+        aptr, ns, off_out, n_out = b.stage_audio(
+            [utts[i][0] for i in batch], C, lambda N: al(4 * ctx.num_frames(N) * F) + 4 * F)
+        frames = [ctx.num_frames(N) for N in ns]
+        masks = [self.condition_mask(utts[i][1], T) for i, T in zip(batch, frames)]
+        moff, need_m = [], 0
+        for T in frames:
+            moff.append(need_m)
+            need_m = al(need_m + 4 * T * F)
+        mk.reserve(need_m, b.stream)
+        for m, o in zip(masks, moff):
+            mk.view[o:o + m.size * 4] = np.frombuffer(np.ascontiguousarray(m), dtype=np.uint8)
+        ctx.memcpy_h2d_async(mk.d, mk.h, need_m, b.stream)
+        # device scratch: spectrogram [C][T][F], covariance [F][C][C], steer vector [F][C] per utterance
+        need, spec, cov, sv = 0, [], [], []
+        for T in frames:
+            spec.append(need)
+            need = al(need + 8 * C * T * F)
+            cov.append(need)
+            need = al(need + 8 * F * C * C)
+            sv.append(need)
+            need = al(need + 8 * F * C)
+        if need > self._scratch_cap:
+            ctx.stream_synchronize(b.stream)
+            if self._scratch:
+                ctx.device_free(self._scratch)
+            self._scratch_cap = int(need * 1.25)
+            self._scratch = ctx.device_alloc(self._scratch_cap)
+        base = self._scratch
+        ctx.stft_batch(C, aptr, ns, [base + o for o in spec], stream=b.stream)
+        for k, T in enumerate(frames):
+            o_df = b.d_out + off_out[k]
+            o_st = o_df + al(4 * T * F)
+            ctx.covar(base + spec[k], mk.d + moff[k], C, T, F, base + cov[k], stream=b.stream)
+            ctx.pevd(base + cov[k], None, F, C, 0, base + sv[k], o_st, stream=b.stream)
+            ctx.directional_feats(base + spec[k], base + sv[k], self.pairs, C, T, F, o_df, stream=b.stream)
+        host = b.fetch(n_out)
+        for k, (i, T) in enumerate(zip(batch, frames)):
+            o_df = off_out[k]
+            o_st = o_df + al(4 * T * F)
+            status = np.frombuffer(host[o_st:o_st + 4 * F], dtype=np.int32)
+            code = int(status.max()) if F else 0
+            df = None
+            if code == 0:
+                df = np.frombuffer(host[o_df:o_df + 4 * T * F], dtype=np.float32).reshape(T, F).copy()
+            out[i] = (df, code)
+
+    def _one_by_operators(self, samps, mask):
+        """n_fft != 512 or more than 8 channels: the mirrored operators, one utterance at a time."""
+        from .libs.beamformer import compute_covar, solve_pevd
+        from .libs.spatial import directional_feats
+        from .libs.utils import forward_stft
+        if isinstance(samps, Pcm16Frames):
+            samps = samps.to_float()
+        samps = np.ascontiguousarray(samps, dtype=np.float32)
+        if samps.ndim == 1:
+            samps = samps[None]
+        s = self.stft
+        obs = np.stack([forward_stft(ch, frame_len=s["frame_len"], frame_hop=s["frame_hop"],
+                                     round_power_of_two=self.round_power_of_two, center=s["center"],
+                                     window=self.window_name, transpose=False) for ch in samps])
+        m = self.condition_mask(mask, obs.shape[2])
+        try:
+            sv = solve_pevd(compute_covar(obs, m))
+        except np.linalg.LinAlgError:
+            return None, _ffi.NUM_NONFINITE
+        return directional_feats(obs, sv.T, df_pair=self.pairs), 0
+
+
+class BatchWpd(object):
+    """Factorised WPD (joint dereverberation and denoising) for a batch, resident on the device.
+
+    Replaces the per-utterance body of funcwj/setk scripts/sptk/apply_wpd.py:31-57 around
+    libs/wpe.py:113-177 (facted_wpd): per outer iteration one WPE step with the variances of the
+    previous enhanced signal, a K = 2 CGMM on the dereverberated channels, the power-weighted
+    and the mask-weighted covariance, the MVDR weights and the beamformer.  Where the numpy
+    mirror (setk_amd.libs.wpe.facted_wpd) carries every intermediate through host arrays, here
+    the samples of a batch go up once, setk_stft_batch writes the spectrograms, and every stage
+    works on device pointers of one scratch block: setk_wpe -> setk_cgmm_masks -> setk_covar x 2
+    -> setk_weights -> setk_beamform, then setk_istft with the renorm to max |samples|
+    (SpectrogramReader.maxabs) and the float -> PCM_16 conversion; one slab comes down per batch:
+    [wave | status words | speech mask].  run() takes C x N float32 arrays or Pcm16Frames of one
+    channel count and returns [(wave, mask T x F float32) | None]; None is the reference's
+    LinAlgError (singular tap correlation or power-weighted covariance).  The transform sizes the
+    fused STFT does not serve (n_fft != 512, more than 8 channels) go through the numpy mirror."""
+
+    def __init__(self, taps=10, delay=3, context=1, wpd_iters=3, cgmm_iters=20, update_alpha=False,
+                 frame_len=512, frame_hop=256, center=True, round_power_of_two=True, window="hann",
+                 device=None, pcm16=False):
+        self.ctx = _ffi.default_context(device)
+        self.taps, self.delay, self.context = int(taps), int(delay), int(context)
+        self.wpd_iters, self.cgmm_iters = int(wpd_iters), int(cgmm_iters)
+        self.update_alpha = bool(update_alpha)
+        self.pcm16 = bool(pcm16)
+        n_fft = nextpow2(frame_len) if round_power_of_two else frame_len
+        self.stft = dict(frame_len=frame_len, frame_hop=frame_hop, n_fft=n_fft, center=center,
+                         window=stft_window(window, frame_len))
+        self.window_name, self.round_power_of_two = window, round_power_of_two
+        self.num_bins = n_fft // 2 + 1
+        self.rank_deficient_bins = 0
+        self._slabs = None
+        self._scratch, self._scratch_cap = 0, 0
+
+    def close(self):
+        b, self._slabs = self._slabs, None
+        if b:
+            b.close()
+        if self._scratch:
+            self.ctx.device_free(self._scratch)
+            self._scratch, self._scratch_cap = 0, 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, utts):
+        if not len(utts):
+            return []
+        s = self.stft
+        self.ctx.stft_plan(s["frame_len"], s["frame_hop"], s["n_fft"], s["center"], s["window"])
+        C = _channels_and_size(utts[0])[0]
+        if any(_channels_and_size(u)[0] != C for u in utts):
+            raise ValueError("BatchWpd.run needs the same channel count in every utterance")
+        if s["n_fft"] == 512 and C <= 8:
+            return self._run_resident(utts, C)
+        return [self._one_by_mirror(u) for u in utts]
+
+    @staticmethod
+    def _peak(samps):
+        if isinstance(samps, Pcm16Frames):
+            return float(np.abs(samps.frames.astype(np.int32)).max()) / 32768.0 if samps.frames.size else 0.0
+        return float(np.max(np.abs(samps))) if np.size(samps) else 0.0
+
+    def _run_resident(self, utts, C):
+        ctx, F, K = self.ctx, self.num_bins, self.wpd_iters
+        if self._slabs is None:
+            self._slabs = _Slabs(ctx)
+        b = self._slabs
+        al = lambda v: (v + 255) & ~255  # noqa: E731
+        esz = 2 if self.pcm16 else 4
+        n_status = 2 * K * F  # per outer iteration: WPE's tap correlation, the MVDR solve
+
+        def out_bytes(N):
+            T = ctx.num_frames(N)
+            return al(esz * ctx.istft_num_samples(T)) + al(4 * n_status) + al(4 * T * F) + 256
+
+        aptr, ns, off_out, n_out = b.stage_audio(utts, C, out_bytes)
+        frames = [ctx.num_frames(N) for N in ns]
+        lens = [ctx.istft_num_samples(T) for T in frames]
+        # scratch per utterance: spectrogram, dereverberated channels, 1 / lambda, posteriors,
+        # two covariances, weights, enhanced spectrum, float wave (PCM16 output)
+        lay, need = [], 0
+
+        def take(nbytes):
+            nonlocal need
+            o = need
+            need = al(need + nbytes)
+            return o
+
+        for T, L in zip(frames, lens):
+            lay.append(dict(spec=take(8 * C * T * F), der=take(8 * C * T * F), inv=take(4 * T * F),
+                            gamma=take(8 * T * F), Rd=take(8 * F * C * C), Rs=take(8 * F * C * C),
+                            w=take(8 * F * C), enh=take(8 * T * F), wav=take(4 * L), norm=take(256)))
+        if need > self._scratch_cap:
+            ctx.stream_synchronize(b.stream)
+            if self._scratch:
+                ctx.device_free(self._scratch)
+            self._scratch_cap = int(need * 1.25)
+            self._scratch = ctx.device_alloc(self._scratch_cap)
+        base, st = self._scratch, b.stream
+        ctx.stft_batch(C, aptr, ns, [base + q["spec"] for q in lay], stream=st)
+        mvdr = _ffi.BfOpts(kind=_ffi.BF_MVDR)
+        peaks = [np.array([self._peak(u)], dtype=np.float32) for u in utts]  # (kept alive until the fetch)
+        for k, (q, T, L) in enumerate(zip(lay, frames, lens)):
+            o_wave = b.d_out + off_out[k]
+            o_stat = o_wave + al(esz * L)
+            o_mask = o_stat + al(4 * n_status)
+            p = lambda name: base + q[name]  # noqa: E731
+            for it in range(K):
+                ctx.wpe(p("spec"), C, T, F, self.taps, self.delay, self.context, 1, p("der"),
+                        lambda_enh=p("enh") if it else None, inv_lambda_out=p("inv"),
+                        status=o_stat + 4 * F * (2 * it), stream=st)
+                ctx.cgmm_masks(p("der"), C, T, F, self.cgmm_iters, None, p("gamma"), o_mask, stream=st,
+                               update_alpha=self.update_alpha)
+                # the mask 1 / lambda gives the power-weighted covariance up to a per-bin scale
+                # that cancels in the MVDR weight
+                ctx.covar(p("der"), p("inv"), C, T, F, p("Rd"), stream=st)
+                ctx.covar(p("der"), o_mask, C, T, F, p("Rs"), stream=st)
+                ctx.weights(mvdr, p("Rs"), p("Rd"), None, F, C, p("w"), o_stat + 4 * F * (2 * it + 1), stream=st)
+                ctx.beamform(p("w"), p("der"), C, T, F, p("enh"), stream=st)
+            ctx.memcpy_h2d_async(p("norm"), peaks[k].ctypes.data, 4, st)
+            if self.pcm16:
+                ctx.istft(p("enh"), 1, T, None, p("norm"), p("wav"), stream=st)
+                ctx.float_to_pcm16(p("wav"), 1, L, o_wave, stream=st)
+            else:
+                ctx.istft(p("enh"), 1, T, None, p("norm"), o_wave, stream=st)
+        host = b.fetch(n_out)
+        out = []
+        for k, (T, L) in enumerate(zip(frames, lens)):
+            o_wave = off_out[k]
+            o_stat = o_wave + al(esz * L)
+            o_mask = o_stat + al(4 * n_status)
+            status = np.frombuffer(host[o_stat:o_stat + 4 * n_status], dtype=np.int32).reshape(K, 2, F)
+            self.rank_deficient_bins += int(np.count_nonzero(status[:, 0] == _ffi.NUM_RANKDEF))
+            if _ffi.wpe_failed(status[:, 0]).any() or status[:, 1].any():
+                out.append(None)
+                continue
+            wave = np.frombuffer(host[o_wave:o_wave + esz * L], dtype=np.int16 if self.pcm16 else np.float32).copy()
+            mask = np.frombuffer(host[o_mask:o_mask + 4 * T * F], dtype=np.float32).reshape(T, F).copy()
+            out.append((wave, mask))
+        return out
+
+    def _one_by_mirror(self, samps):
+        from .libs.utils import forward_stft, inverse_stft
+        from .libs.wpe import facted_wpd
+        from .libs import wavio
+        if isinstance(samps, Pcm16Frames):
+            samps = samps.to_float()
+        samps = np.ascontiguousarray(samps, dtype=np.float32)
+        if samps.ndim == 1:
+            samps = samps[None]
+        s = self.stft
+        kw = dict(frame_len=s["frame_len"], frame_hop=s["frame_hop"], center=s["center"], window=self.window_name)
+        obs = np.stack([forward_stft(ch, round_power_of_two=self.round_power_of_two, transpose=True, **kw)
+                        for ch in samps])  # N x T x F
+        try:
+            tf_mask, enh = facted_wpd(obs, wpd_iters=self.wpd_iters, cgmm_iters=self.cgmm_iters,
+                                      update_alpha=self.update_alpha, context=self.context,
+                                      taps=self.taps, delay=self.delay)
+        except np.linalg.LinAlgError:
+            return None
+        wave = inverse_stft(enh, norm=float(np.max(np.abs(samps))), transpose=True, **kw)
+        if self.pcm16:
+            wave = wavio.float_to_pcm16(wave)
+        return wave, tf_mask[..., 0].astype(np.float32)

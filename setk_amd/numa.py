@@ -66,7 +66,12 @@ def device_node(ctx):
 def _set_mempolicy_preferred(node):
     """set_mempolicy(MPOL_PREFERRED, {node}) for the calling thread (inherited by threads it
     starts); False if the syscall is not available (seccomp'd containers)."""
-    MPOL_PREFERRED, SYS_set_mempolicy = 1, 238  # x86_64
+    import platform
+    # the syscall number is per architecture (238 is migrate_pages on aarch64): known tables only
+    SYS_set_mempolicy = {"x86_64": 238, "aarch64": 237}.get(platform.machine())
+    if SYS_set_mempolicy is None:
+        return False
+    MPOL_PREFERRED = 1
     try:
         libc = ctypes.CDLL(None, use_errno=True)
         nbits = max(64, node + 1)

@@ -157,10 +157,10 @@ def _arm_fault_injection(shard, writer):
     """Test hook of the re-queue path (tests/test_host_asan.py): SETK_FAULT_INJECT=
     "<rank>:<n>[:<attempt>]" makes that rank die WITHOUT any clean-up -- as a killed process
     or a lost GPU would -- after its n-th wave file (in attempt <attempt> of
-    `python -m setk_amd.launch`, default 0).  Unset: nothing happens."""
+    `python -m setk_amd.launch`, default 0).  Only with SETK_TESTING=1; unset: nothing happens."""
     spec = os.environ.get("SETK_FAULT_INJECT", "")
-    if not spec:
-        return
+    if not spec or os.environ.get("SETK_TESTING") != "1":
+        return  # (a test hook: inert in a production environment even if the variable leaks in)
     parts = spec.split(":")
     rank, after = int(parts[0]), int(parts[1])
     attempt = int(parts[2]) if len(parts) > 2 else 0
@@ -291,7 +291,7 @@ def run_offline(args, shard):
     device = None if args.device < 0 else args.device
     if device is None and shard.world > 1:
         device = shard.device
-    if _fast_path_ok(args) and shard.world == 1:
+    if _fast_path_ok(args) and shard.torch_free_ok:
         # the streaming pipeline gets its buffers, streams and events from the library: a
         # single-process run never imports torch (0.9 s of a 2 s run on 192 utterances)
         # (more than 8 channels run the unfused engine through torch tensors)
@@ -326,6 +326,11 @@ def run_offline(args, shard):
                 "(first scp read to last wav close)")
     if args.profile:
         import json
+        import sys
+        if shard.world > 1:
+            shard.barrier()  # (connects the ranks if nothing has yet: the record names the backend)
+        summary["dist_backend"] = shard.backend
+        summary["torch_loaded"] = "torch" in sys.modules
         path = args.profile if shard.world == 1 else f"{args.profile}.rank{shard.rank}"
         with open(path, "w") as f:
             json.dump(summary, f, indent=1)

@@ -107,7 +107,7 @@ def run_offline(args, beamformer, utt2doa, shard):
     num_bins = n_fft // 2 + 1
     wav_reader = WaveReader(args.wav_scp, sr=args.sr)
     device = shard.device if shard.world > 1 else None
-    if n_fft == 512 and shard.world == 1:
+    if n_fft == 512 and shard.torch_free_ok:
         # the batch engine brings its own buffers and stream (more than 8 channels: torch)
         _ffi.set_torch_free(wav_reader.first_channels_at_most(8))
     done = 0

@@ -39,7 +39,7 @@ def run(args):
     shard = Shard()
     device = shard.device if shard.world > 1 else None
     n_fft = 2**int(np.ceil(np.log2(args.frame_len))) if args.round_power_of_two else args.frame_len
-    if n_fft == 512 and shard.world == 1:
+    if n_fft == 512 and shard.torch_free_ok:
         # the batch engine brings its own buffers and stream (more than 8 channels: torch)
         _ffi.set_torch_free(weights.shape[-1] <= 8)
     engine = FixedBatchBeamformer(weights, frame_len=args.frame_len, frame_hop=args.frame_hop,

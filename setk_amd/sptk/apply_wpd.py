@@ -2,73 +2,89 @@
 """
 Joint dereverberation & denoising (factorised WPD) on the MI355X.
 
-Drop-in for funcwj/setk ``scripts/sptk/apply_wpd.py`` (same positional arguments,
-options and defaults, :64-113): per utterance the WPE step, the CGMM mask
-estimation and the power-weighted MVDR run on the GPU (setk_amd.libs.wpe), the
-enhanced channel is written as PCM_16 wav, optionally with the speech mask.
+Drop-in for funcwj/setk ``scripts/sptk/apply_wpd.py`` (same positional arguments, options and
+defaults, :64-113; outputs {dst_dir}/{key}.wav PCM_16 and, with --dump-mask, {key}.npy).  The
+reference walks a SpectrogramReader and carries every stage through numpy; this front end
+hands batches of WAVE SAMPLES to ``engine.BatchWpd``: one upload per batch, the spectrogram and
+every intermediate of the outer iterations (WPE step, CGMM posteriors, the two covariances,
+MVDR weights, enhanced spectrum) live in one device scratch block, the inverse STFT, the
+renorm to max |samples| and the PCM_16 conversion run on the device, one slab comes down.
+Utterances are dealt over the ranks of a ``torchrun`` launch by duration.
 """
 import argparse
 
 import numpy as np
 
 from .. import _ffi
-from .._ffi import SetkUnsupported
 from setk_amd.dist import Shard
-from setk_amd.libs.data_handler import SpectrogramReader, WaveWriter
+from setk_amd.engine import BatchWpd, Pcm16Frames
+from setk_amd.libs.data_handler import WaveReader, WaveWriter
 from setk_amd.libs.opts import StftParser, strtobool
-from setk_amd.libs.utils import get_logger, inverse_stft
-from setk_amd.libs.wpe import facted_wpd
+from setk_amd.libs.utils import get_logger
 
 logger = get_logger(__name__)
 
 
 def run(args):
-    stft_kwargs = {
-        "frame_len": args.frame_len,
-        "frame_hop": args.frame_hop,
-        "window": args.window,
-        "center": args.center,
-        "transpose": True  # T x F
-    }
     shard = Shard()
-    if shard.world == 1:
-        _ffi.set_torch_free()  # numpy arrays in and out of the library: nothing here needs torch
-    reader = SpectrogramReader(args.wav_scp, round_power_of_two=args.round_power_of_two,
-                               **stft_kwargs)
-    num_done = 0
+    waves = WaveReader(args.wav_scp)
+    if shard.torch_free_ok:
+        # buffers, streams and copies come from the library (wider tables: torch tensors)
+        _ffi.set_torch_free(waves.first_channels_at_most(8))
+    engine = BatchWpd(taps=args.taps, delay=args.delay, context=args.context,
+                      wpd_iters=args.wpd_iters, cgmm_iters=args.cgmm_iters,
+                      update_alpha=bool(args.update_alpha), frame_len=args.frame_len,
+                      frame_hop=args.frame_hop, center=bool(args.center), window=args.window,
+                      round_power_of_two=bool(args.round_power_of_two), pcm16=True,
+                      device=shard.device if shard.world > 1 else None)
+    mine = shard.assign_by_duration(waves)
+    done = 0
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
-        for key in shard.assign_by_duration(reader):
-            obs = reader[key]
-            logger.info(f"Processing utt {key}...")
-            if obs.ndim != 3:
-                raise RuntimeError(f"Expected 3D array, but got {obs.ndim}")
+
+        def emit(group):
+            """One device batch: utterances of ONE channel count."""
+            nonlocal done
             try:
-                tf_mask, wpd_enh = facted_wpd(obs, wpd_iters=args.wpd_iters,
-                                              cgmm_iters=args.cgmm_iters,
-                                              update_alpha=args.update_alpha,
-                                              context=args.context, taps=args.taps,
-                                              delay=args.delay)
-            except np.linalg.LinAlgError:
-                logger.warning(f"{key}: Failed cause LinAlgError in wpd")
-                continue
-            except SetkUnsupported as e:
-                # a shape beyond the device kernels' limits (channels x taps): skip the
-                # utterance like a numerical failure instead of ending the run
-                logger.warning(f"{key}: skipped, {e}")
-                continue
-            norm = reader.maxabs(key)
-            samps = inverse_stft(wpd_enh, norm=norm, **stft_kwargs)
-            writer.write(key, samps)
-            if args.dump_mask:
-                np.save(f"{args.dst_dir}/{key}", tf_mask[..., 0])
-            num_done += 1
-            if not num_done % 100:
-                logger.info(f"Processed {num_done:d} utterances...")
+                results = engine.run([samps for _, samps in group])
+            except _ffi.SetkUnsupported as e:
+                # a shape beyond the device kernels (channels x taps): skipped like a numerical
+                # failure, the run goes on
+                for key, _ in group:
+                    logger.warning(f"{key}: skipped, {e}")
+                return
+            for (key, _), res in zip(group, results):
+                if res is None:
+                    logger.warning(f"{key}: Failed cause LinAlgError in wpd")
+                    continue
+                wave, mask = res
+                writer.write_pcm16(key, wave)
+                if args.dump_mask:
+                    np.save(f"{args.dst_dir}/{key}", mask.astype(np.float64))
+                done += 1
+                if done % 100 == 0:
+                    logger.info(f"Processed {done:d} utterances...")
+
+        pending = {}  # channel count -> [(key, samples)]
+        for key in mine:
+            logger.info(f"Processing utt {key}...")
+            frames = waves.read_pcm16(key)
+            samps = Pcm16Frames(frames) if frames is not None else np.atleast_2d(waves.read(key))
+            group = pending.setdefault(samps.num_channels if frames is not None else samps.shape[0], [])
+            group.append((key, samps))
+            if len(group) >= args.batch_utts:
+                emit(group)
+                del group[:]
+        for group in pending.values():
+            if group:
+                emit(group)
+    if engine.rank_deficient_bins:
+        logger.warning(f"{engine.rank_deficient_bins:d} frequency bins had a rank-deficient tap correlation "
+                       "(columns at the noise level dropped; numpy.linalg.solve goes through on such input too)")
+    engine.close()
     shard.barrier()
-    if shard.world > 1:
-        num_done = int(round(shard.sum_counts([num_done])[0]))
+    total = int(round(shard.sum_counts([done])[0])) if shard.world > 1 else done
     if shard.rank == 0:
-        logger.info(f"Processed {num_done:d} utterances over {len(reader):d}")
+        logger.info(f"Processed {total:d} utterances over {len(waves):d}")
     shard.close()
 
 
@@ -90,6 +106,8 @@ def build_parser():
     parser.add_argument("--sr", type=int, default=16000, help="Sample rate of the input audio")
     parser.add_argument("--dump-mask", default=False, type=strtobool,
                         help="Dump cgmm mask or not")
+    parser.add_argument("--batch-utts", type=int, default=8,
+                        help="[setk_amd] utterances per GPU batch")
     return parser
 
 

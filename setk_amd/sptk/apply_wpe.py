@@ -31,7 +31,7 @@ def run(args):
     device = shard.device if shard.world > 1 else None
     n_fft = 2**int(np.ceil(np.log2(args.frame_len))) if args.round_power_of_two else args.frame_len
     reader = WaveReader(args.wav_scp)  # 16 kHz tables like the reference (SpectrogramReader)
-    if n_fft == 512 and shard.world == 1:
+    if n_fft == 512 and shard.torch_free_ok:
         # the engine brings its own buffers and stream; more than 8 channels (the unfused STFT
         # path) run through torch and need it imported first
         nch = next((reader.peek_channels(k) for k in reader.index_keys), None)

@@ -75,7 +75,8 @@ def run(args):
         # table dealt over several ranks every rank walks the whole table and DISCARDS the draws
         # of the utterances that are not its own (K x F x T doubles each, T from the wave
         # header), so an 8-GPU run starts every utterance exactly as the one-process run does.
-        random_start = args.num_classes != 2 and not args.init_mask
+        # (per utterance: one whose key is missing from --init-mask still draws)
+        random_start = args.num_classes != 2
         walk = list(reader.index_keys) if (random_start and shard.world > 1) else mine
         own = set(mine)
         num_bins = n_fft // 2 + 1
@@ -89,14 +90,18 @@ def run(args):
                     logger.info(f"Training utterance {key} ... Skip")
                 continue
             if key not in own:
-                np.random.uniform(size=args.num_classes * num_bins * _num_frames(reader, key, args, n_fft))
+                if not (init_reader and key in init_reader):
+                    np.random.uniform(size=args.num_classes * num_bins * _num_frames(reader, key, args, n_fft))
                 continue
             stft = reader[key]
             if stft.ndim == 2:
                 stft = stft[None]
             init_mask = None
             if init_reader and key in init_reader:
-                init_mask = np.transpose(init_reader[key])  # T x F -> F x T
+                init_mask = init_reader[key]
+                # T x F -> F x T; all K masks of a K > 2 model: K x T x F -> K x F x T
+                # (estimate_cgmm_masks.py:50-52 of the reference)
+                init_mask = np.transpose(init_mask) if init_mask.ndim == 2 else np.transpose(init_mask, (0, 2, 1))
                 logger.info("Using external TF-mask to initialize cgmm")
             trainer = CgmmTrainer(stft, args.num_classes, gamma=init_mask,
                                   update_alpha=bool(args.update_alpha))
@@ -132,7 +137,7 @@ def run_batched(args, shard):
     """Fast path: waves in, masks out, STFT + EM for a batch of utterances on the GPU."""
     from setk_amd.libs.data_handler import WaveReader
     reader = WaveReader(args.wav_scp)
-    if shard.world == 1:
+    if shard.torch_free_ok:
         # CgmmEstimator.estimate brings its own buffers and stream: no torch in this process
         # (bins that fit no resident configuration -- more than 8 channels -- go through torch)
         _ffi.set_torch_free(reader.first_channels_at_most(8))

@@ -293,7 +293,7 @@ def test_bench_contract_single_and_two_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     bench = os.path.join(root, "bench.py")
     small = ["--steps", "2", "--warmup", "1", "--utts", "6", "--seconds", "4", "--cpu-sample", "0",
-             "--other-configs", "0", "--sustain-sec", "0.2", "--full-batch", "12"]
+             "--other-configs", "0", "--sustain-sec", "0.2", "--full-batch", "12", "--aux", "1"]
     r = subprocess.run([sys.executable, bench, "--gpus", "1", "--e2e-utts", "6"] + small,
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -319,6 +319,11 @@ def test_bench_contract_single_and_two_ranks():
     assert roof["traffic"] == roof["pass1"]["hbm"]["traffic"]
     # the legs outside the timed steps
     assert one["sustained"]["steps"] >= 50 and one["full_batch"]["utts"] == 12
+    # the same shard as 16-bit PCM: its own block, exact parity with the float32 path
+    i16 = one["int16_ingest"]
+    assert i16["status"] == "ok" and i16["bit_identical_to_float32_path_on_pcm_over_32768"] is True
+    assert i16["roofline"]["bound"] == "hbm" and 0 < i16["roofline"]["frac"] < 1
+    assert "2 C N" in i16["roofline"]["algorithmic_bytes"]
     assert one["uncached_call"]["ms_per_step"] > 0
     e2e = one["end_to_end"]
     assert [r_["written"] for r_ in e2e["runs"]] == [6, 24] and "marginal_ms_per_utt" in e2e
@@ -468,6 +473,22 @@ def test_consumers_fixed_beamformer_and_directional_feats(tmp_path):
         assert np.max(np.abs(df - o.directional_feats(obs, sv.T, df_pair=pairs))) < 1e-4
     with pytest.raises(ValueError):
         S.directional_feats(obs, sv.T[:2], df_pair=pairs)
+    # the batched, device-resident engine behind the CLI: samples + masks in, features out
+    from setk_amd.engine import BatchDirectionalFeatures
+    dfe = BatchDirectionalFeatures(pairs, **kw)
+    res = dfe.run([(Pcm16Frames(g["u0.pcm"]), g["u0.mask"]),
+                   (g["u1.pcm"].T.astype(np.float32) / np.float32(32768), np.ascontiguousarray(g["u1.mask"].T))])
+    for k, (feats_k, code) in zip(("u0", "u1"), res):
+        assert code == 0 and feats_k.dtype == np.float32 and feats_k.shape == g[f"{k}.df"].shape
+        assert np.max(np.abs(feats_k - g[f"{k}.df"])) < 2e-3
+    # a non-finite sample: numpy's eigh raises LinAlgError in the reference; here a status
+    bad = g["u0.pcm"].T.astype(np.float32) / np.float32(32768)
+    bad[1, 1000] = np.nan
+    (none, code), (again, c2) = dfe.run([(bad, g["u0.mask"]), (Pcm16Frames(g["u0.pcm"]), g["u0.mask"])])
+    assert none is None and code != 0 and c2 == 0 and np.array_equal(again, res[0][0])
+    with pytest.raises(ValueError):
+        BatchDirectionalFeatures([(0, 7)], **kw).run([(Pcm16Frames(g["u0.pcm"]), g["u0.mask"])])
+    dfe.close()
 
     # ---- command line level ----
     py = [sys.executable]
@@ -580,3 +601,41 @@ def test_streaming_pipeline_equals_batch_path(tmp_path):
     # --zero-copy: PCM16 wavs and float32 C-ordered masks leave the page cache without a host copy
     assert json.load(open(f"{td}/prof_zc.json"))["stages"]["zero_copy_payloads"] >= 8
     assert prof["stages"]["zero_copy_payloads"] == 0
+
+
+def test_rccl_comm_through_the_c_abi_single_rank():
+    """setk_comm_* (csrc/comm.hip): RCCL reached from the library itself, no torch.distributed.
+    A one-GPU box can only form a communicator of one rank (RCCL refuses two ranks on one
+    device); that still exercises dlopen(librccl), ncclGetUniqueId, ncclCommInitRank, an
+    all-reduce on the device and the teardown.  The multi-rank control flow around it is the CPU
+    test test_shard_without_torch (TCP star) and the 2 / 8-rank command-line tests."""
+    import ctypes
+    from setk_amd import _ffi
+    lib = _ffi.load_library()
+    lib.setk_comm_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_char_p,
+                                     ctypes.c_int, ctypes.c_int]
+    lib.setk_comm_allreduce_f64.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int,
+                                            ctypes.c_int]
+    lib.setk_comm_barrier.argtypes = [ctypes.c_void_p]
+    lib.setk_comm_destroy.argtypes = [ctypes.c_void_p]
+    lib.setk_comm_last_error.restype = ctypes.c_char_p
+    uid = ctypes.create_string_buffer(128)
+    assert lib.setk_comm_unique_id(uid) == 0, lib.setk_comm_last_error()
+    assert any(uid.raw)
+    comm = ctypes.c_void_p()
+    assert lib.setk_comm_create(ctypes.byref(comm), 0, uid.raw, 0, 1) == 0, lib.setk_comm_last_error()
+    vals = (ctypes.c_double * 3)(1.5, -2.0, 7.0)
+    assert lib.setk_comm_allreduce_f64(comm, vals, 3, 0) == 0, lib.setk_comm_last_error()
+    assert list(vals) == [1.5, -2.0, 7.0]
+    assert lib.setk_comm_allreduce_f64(comm, vals, 3, 1) == 0 and list(vals) == [1.5, -2.0, 7.0]
+    assert lib.setk_comm_barrier(comm) == 0
+    assert lib.setk_comm_allreduce_f64(comm, vals, 65, 0) != 0   # more values than the call takes
+    assert lib.setk_comm_destroy(comm) == 0
+    # and through the Shard of the command lines, as a launcher with one rank would set it up
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from setk_amd import _ffi; _ffi.set_torch_free()\n"
+            "from setk_amd.dist import Shard\n"
+            "s = Shard(); s.barrier(); print(s.sum_counts([3, 4]), 'torch' in sys.modules)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "[3, 4] False" in r.stdout, r.stderr[-1500:]

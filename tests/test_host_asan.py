@@ -264,6 +264,9 @@ def test_two_rank_cli_on_the_stand_in(tmp_path):
     per_rank = [json.load(open(f"{td}/prof.json.rank{k}")) for k in range(2)]
     assert sum(p["utts"] for p in per_rank) == 8 and all(p["utts"] >= 2 for p in per_rank)
     assert all(p["mode"] == "pipeline" and p["world"] == 2 for p in per_rank)
+    # no rank imported torch: barrier and counters over the library's own exchange (RCCL on a GPU
+    # node, the TCP star here where no rank has a GPU)
+    assert all(p["dist_backend"] in ("rccl", "tcp") and not p["torch_loaded"] for p in per_rank)
 
 
 def test_eight_rank_cli_on_the_stand_in_balances_ragged_lengths(tmp_path):
@@ -305,6 +308,7 @@ def test_eight_rank_cli_on_the_stand_in_balances_ragged_lengths(tmp_path):
     per_rank = [json.load(open(f"{td}/prof.json.rank{k}")) for k in range(world)]
     assert sum(p["utts"] for p in per_rank) == len(lens)
     assert all(p["mode"] == "pipeline" and p["world"] == world for p in per_rank)
+    assert all(p["dist_backend"] in ("rccl", "tcp") and not p["torch_loaded"] for p in per_rank)
     loads = np.array([p["assigned_samples"] for p in per_rank], dtype=np.float64)
     assert loads.sum() == sum(lens)
     assert np.abs(loads / loads.mean() - 1).max() < 0.02, loads
@@ -323,7 +327,7 @@ def test_launcher_requeues_what_a_dead_rank_left(tmp_path):
     lens = [16000, 64000, 8000, 30011, 16000, 12345, 48000, 9000, 20000, 21000, 22000, 23000]
     _make_table(td, lens)
     env = dict(os.environ, HOSTSTUB_DEVICES="2", SETK_ALLOW_HOSTSTUB="1", OMP_NUM_THREADS="1",
-               SETK_LIB=os.path.join(ROOT, "_abl", "libsetk_hoststub.so"), SETK_FAULT_INJECT="1:2:0",
+               SETK_LIB=os.path.join(ROOT, "_abl", "libsetk_hoststub.so"), SETK_FAULT_INJECT="1:2:0", SETK_TESTING="1",
                PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)

@@ -638,3 +638,54 @@ def test_cgmm_seeded_start_is_independent_of_the_sharding(tmp_path):
                 assert np.array_equal(np.random.uniform(size=[K, F, t]), seq[j])
             else:
                 np.random.uniform(size=K * F * t)
+
+
+_WORKER_TORCH_FREE = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+from setk_amd import _ffi
+from setk_amd.dist import Shard
+_ffi.set_torch_free()                           # what the command lines do before the first Context
+sh = Shard()                                    # default backend: rccl, else the TCP star
+keys = [f"u{{i}}" for i in range(37)]
+dur = [((i * 13) % 7) + 1 for i in range(37)]
+mine = sh.assign(keys, dur)
+sh.barrier()
+tot = sh.sum_counts([len(mine), sum(dur[keys.index(k)] for k in mine)])
+mx = sh.max_values([float(sh.rank), 3.5])
+sh.barrier()
+print(json.dumps(dict(rank=sh.rank, world=sh.world, mine=mine, tot=tot, mx=mx, backend=sh.backend,
+                      torch="torch" in sys.modules)))
+sh.close()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_shard_without_torch(tmp_path, world):
+    """The multi-rank control flow without `import torch` in any rank (round-5 review, item 6):
+    on a GPU node the barrier and the counters go over RCCL through the library's own
+    setk_comm_* entry points (rendezvous of the ncclUniqueId over a TCP socket on MASTER_PORT +
+    1); here, without a GPU per rank, every rank agrees on the TCP star instead.  Same deal of
+    the keys, same sums as the torch.distributed backends above."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER_TORCH_FREE.format(root=ROOT))
+    port = 30400 + (os.getpid() % 500) + 10 * world
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.pop("SETK_DIST_BACKEND", None)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o_, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(__import__("json").loads(o_.strip().splitlines()[-1]))
+    allk = sorted(k for o_ in outs for k in o_["mine"])
+    assert allk == sorted(f"u{i}" for i in range(37))
+    total = sum(((i * 13) % 7) + 1 for i in range(37))
+    for o_ in outs:
+        assert o_["world"] == world and not o_["torch"] and o_["backend"] in ("rccl", "tcp")
+        assert o_["tot"] == [37.0, float(total)] and o_["mx"] == [float(world - 1), 3.5]
+    assert len({o_["backend"] for o_ in outs}) == 1

@@ -83,6 +83,27 @@ def run(utts=16, seconds=10.0):
     res["df_on_mask_4ch"] = {"workload": f"4-ch {seconds:g} s, compute_covar -> solve_pevd -> "
                                          "directional_feats, numpy in / numpy out, one utterance",
                              "ms_per_utt": round(1e3 * dt, 2), "value": round(seconds / dt, 1)}
+    # the CLI's engine since round 5: samples + masks in, feature maps out, spectrograms /
+    # covariances / steer vectors stay on the device (engine.BatchDirectionalFeatures)
+    from setk_amd.engine import BatchDirectionalFeatures
+    dfe = BatchDirectionalFeatures([(0, 1), (0, 2), (1, 3)], frame_len=512, frame_hop=256, center=True)
+    pairs = [(mix, mask)] * 16
+    dfe.run(pairs)
+    dtr = timed(lambda: dfe.run(pairs), 3)
+    res["df_on_mask_4ch_resident"] = {
+        "workload": f"the same from SAMPLES (STFT included) for {len(pairs)} utterances per call: one upload, "
+                    "setk_stft_batch -> setk_covar -> setk_pevd -> setk_directional_feats on device "
+                    "pointers, one download",
+        "ms_per_utt": round(1e3 * dtr / len(pairs), 2), "value": round(len(pairs) * seconds / dtr, 1),
+        "per_utterance_numpy_path_incl_stft_ms": None}
+    # what compute_df_on_mask.py cost per utterance before: the SpectrogramReader's STFT
+    # (numpy out) + the three numpy-in / numpy-out operators
+    def df_old():
+        sp_ = device_stft(mix, 512, 256, True, True, "hann")
+        obs = np.transpose(sp_, (0, 2, 1))
+        sv = B.solve_pevd(B.compute_covar(obs, mask))
+        return S.directional_feats(obs, sv.T, df_pair=[(0, 1), (0, 2), (1, 3)])
+    res["df_on_mask_4ch_resident"]["per_utterance_numpy_path_incl_stft_ms"] = round(1e3 * timed(df_old, 5), 2)
     # ---- unfused engine: n_fft = 400, 12 channels ----
     for label, C, kw in (("mvdr_nfft400_4ch", 4, dict(frame_len=400, frame_hop=160,
                                                       round_power_of_two=False)),
