@@ -270,12 +270,19 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #if SETK_P2MC_NT
+                // (float32 samples only: on the 2-byte loads of the PCM form the hint measured
+                //  0.4 - 2.5 % slower, profiles/round5_pass2_nt_pf2_ab.txt)
                 // both halves of a group's first frame are read for the last time here (the first
                 // one is the re-read of what the previous group fetched as ITS last half): a
                 // streaming hint keeps them from pushing the halves that WILL be read again --
                 // load_half's -- out of the XCD's L2
-                v[e] = __builtin_nontemporal_load(&x[s0 + o + 16 * e]);
-                v[4 + e] = __builtin_nontemporal_load(&x[s0 + o + 256 + 16 * e]);
+                if constexpr (PCM) {
+                    v[e] = x[s0 + o + 16 * e];
+                    v[4 + e] = x[s0 + o + 256 + 16 * e];
+                } else {
+                    v[e] = __builtin_nontemporal_load(&x[s0 + o + 16 * e]);
+                    v[4 + e] = __builtin_nontemporal_load(&x[s0 + o + 256 + 16 * e]);
+                }
 #else
                 v[e] = x[s0 + o + 16 * e];
                 v[4 + e] = x[s0 + o + 256 + 16 * e];

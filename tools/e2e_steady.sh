@@ -67,5 +67,16 @@ print(f"P={P}: full {F:.2f} s ({P*N/F:.0f} utt/s), quarter {Q:.2f} s -> marginal
       f"{marg/P:.0f} per process, {marg*sec:.0f} x real time")
 PY
 done
+# stage clocks of the last full run's process 0 (where the host time goes)
+python - "$D" <<'PY' | tee -a $OUTF
+import json, sys
+try:
+    st = json.load(open(f"{sys.argv[1]}/prof.0.json"))
+    keep = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.get("stages", {}).items()}
+    print("# process 0 of the last run: wall", round(st["wall_s"], 3), "stages", keep)
+except Exception as e:
+    print("# no stage record:", e)
+PY
+grep -h "launch ms" $D/log.0.txt | tail -4 | sed 's/^/# /' | tee -a $OUTF
 grep -h "bound to NUMA" $D/log.0.txt | head -1 | tee -a $OUTF
 rm -rf $D
