@@ -75,6 +75,13 @@ class CgmmTrainer(object):
         else:
             ctx.cgmm_masks_k(self.spec, M, T, F, K, num_iters, self.gamma0, self.init, gamma,
                              update_alpha=self.update_alpha)
+        if not np.isfinite(gamma).all():
+            # the reference's np.linalg.eigh raises on a covariance with NaN / inf
+            # (cluster.py:104-113) -- non-finite samples, or a model that broke down; the device
+            # EM has no status word for it, its posteriors say it
+            bad = int(np.count_nonzero(~np.isfinite(gamma).all(axis=(0, 1))))
+            raise np.linalg.LinAlgError(f"Eigenvalues did not converge ({bad} frequency bins with "
+                                        "non-finite posteriors)")
         self.gamma = np.transpose(gamma, (0, 2, 1)).astype(np.float64)
         return self.gamma
 

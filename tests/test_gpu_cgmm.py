@@ -335,6 +335,18 @@ def test_cgmm_k_classes_match_oracle(K, C, N, iters, ua):
     assert np.mean(np.abs(got - ref)) < 1e-4, np.mean(np.abs(got - ref))
 
 
+def test_cgmm_non_finite_input_raises_like_the_reference():
+    """A NaN in the spectrogram: the reference's np.linalg.eigh raises LinAlgError on the
+    covariance (cluster.py:104-113, uncaught by estimate_cgmm_masks.py: the run ends).  The
+    general device EM has no status word; CgmmTrainer reads it off the posteriors."""
+    from setk_amd.libs.cluster import CgmmTrainer
+    obs = o.multichannel_stft(o.synth_scene(311, 4, 12000), transpose=False, **STFT_KW).copy()
+    obs[1, 40, 7] = np.nan
+    np.random.seed(777)
+    with pytest.raises(np.linalg.LinAlgError):
+        CgmmTrainer(obs, 3).train(3)
+
+
 @pytest.mark.parametrize("C", [9, 12, 16])
 def test_cgmm_wide_arrays_through_the_general_em(C):
     """More than 8 channels (the reference has no cap: cluster.py:396-465): K = 2 with the
