@@ -67,6 +67,12 @@ class CgmmTrainer(object):
         M, F, T = self.shape
         K = self.num_classes
         ctx = _ffi.default_context()
+        if not np.isfinite(self.spec.view(np.float32)).all():
+            # the reference's np.linalg.eigh raises on a covariance with NaN / inf
+            # (cluster.py:104-113; uncaught by estimate_cgmm_masks.py: the run ends).  The device
+            # EM's floors (max(q, eps), max(lambda, eps)) would swallow a NaN into finite
+            # posteriors, so the samples are checked here
+            raise np.linalg.LinAlgError("Eigenvalues did not converge (non-finite spectrogram)")
         gamma = np.empty((K, T, F), dtype=np.float32)
         if K == 2 and M <= 8:
             mask = np.empty((T, F), dtype=np.float32)
