@@ -339,8 +339,13 @@ def run_offline(args, shard):
 
 def _run_pipeline(args, engine, writer, wav_reader, tgt, itf, keys):
     """Streaming path: setk_amd.pipeline.StreamPipeline."""
+    import sys
     import threading
     from setk_amd.pipeline import OpenFiles, StreamPipeline, mask_source, wav_source
+    # ~18 threads share the interpreter lock here, and this (planning) thread never blocks: with
+    # the default 5 ms switch interval a reader that comes back from its copy waits up to 5 ms
+    # to get the lock for the few microseconds of bookkeeping between two payloads
+    sys.setswitchinterval(float(os.environ.get("SETK_SWITCH_INTERVAL", "0.0005")))
     files = OpenFiles()
     lock = threading.Lock()
 

@@ -639,3 +639,42 @@ def test_rccl_comm_through_the_c_abi_single_rank():
             "s = Shard(); s.barrier(); print(s.sum_counts([3, 4]), 'torch' in sys.modules)\n" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "[3, 4] False" in r.stdout, r.stderr[-1500:]
+
+
+def test_cli_strict_reference_skips_what_the_reference_skips(tmp_path):
+    """--strict-reference true: the command line logs 'Raise linalg error' and writes no file for
+    exactly the utterances on which the reference's numpy.linalg.solve raises (a duplicated
+    channel: an exactly singular noise covariance, tests/golden/ref_skipset.json) -- and writes
+    every file by default (the regularised solve), for the same table."""
+    from setk_amd.libs import wavio
+    td = str(tmp_path)
+    cases = o.skipset_cases()
+    os.makedirs(f"{td}/m")
+    with open(f"{td}/wav.scp", "w") as ws, open(f"{td}/mask.scp", "w") as ms:
+        for key in ("plain", "dup-channel", "channel-x0.3", "zero-channel"):
+            samps, mask = cases[key]
+            pcm = wavio.float_to_pcm16(samps.T)
+            if key == "dup-channel":
+                pcm[:, 1] = pcm[:, 0]          # (exact after quantisation too)
+            k = key.replace(".", "_")
+            wavio.write_pcm16(f"{td}/{k}.wav", pcm, 16000)
+            np.save(f"{td}/m/{k}.npy", mask.astype(np.float32))
+            ws.write(f"{k} {td}/{k}.wav\n")
+            ms.write(f"{k} {td}/m/{k}.npy\n")
+    script = os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py")
+
+    def run(dst, *extra):
+        r = subprocess.run([sys.executable, script, "--mask-format", "numpy", *extra,
+                            f"{td}/wav.scp", f"{td}/mask.scp", dst], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return sorted(os.listdir(dst)), r.stderr
+
+    files, err = run(f"{td}/default")
+    assert files == ["channel-x0_3.wav", "dup-channel.wav", "plain.wav", "zero-channel.wav"]
+    assert "Processed 4 utterances out of 4" in err
+    files, err = run(f"{td}/strict", "--strict-reference", "true")
+    assert files == ["channel-x0_3.wav", "plain.wav"], files
+    assert err.count("Raise linalg error") == 2 and "Processed 2 utterances out of 4" in err
+    for gevd_dir in ("gev",):
+        files, err = run(f"{td}/{gevd_dir}", "--strict-reference", "true", "--beamformer", "gevd")
+        assert len(files) == 4 and "Raise linalg error" not in err   # the reference's GEV never raises
