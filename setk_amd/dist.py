@@ -161,7 +161,12 @@ class Shard:
             lib = _ffi.load_library()
             if not hasattr(lib, "setk_comm_create") or not os.path.exists("/dev/kfd"):
                 ok = 0.0  # (a library from before round 5, or no GPU driver on this host)
-            elif self.rank == 0:
+            else:
+                # this rank's GPU must be usable BEFORE the collective ncclCommInitRank: a rank that
+                # fails locally there would leave the others waiting in it.  (The context is the one
+                # the command line creates anyway: `default_context` caches it per device.)
+                _ffi.default_context(self.local_rank)
+            if ok and self.rank == 0:
                 buf = ctypes.create_string_buffer(128)
                 if lib.setk_comm_unique_id(buf) != 0:
                     ok = 0.0
