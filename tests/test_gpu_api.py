@@ -489,6 +489,14 @@ def test_consumers_fixed_beamformer_and_directional_feats(tmp_path):
     with pytest.raises(ValueError):
         BatchDirectionalFeatures([(0, 7)], **kw).run([(Pcm16Frames(g["u0.pcm"]), g["u0.mask"])])
     dfe.close()
+    # another transform size: the stand-alone operators behind the same interface
+    kw1k = dict(frame_len=1024, frame_hop=256, center=True, window="hann")
+    samps1 = g["u1.pcm"].T.astype(np.float32) / np.float32(32768)
+    obs1k = np.stack([o.forward_stft(c, round_power_of_two=True, transpose=False, **kw1k) for c in samps1])
+    m1k = np.random.default_rng(3).uniform(0.1, 0.9, size=(obs1k.shape[2], 513)).astype(np.float32)
+    (f1k, code1k), = BatchDirectionalFeatures(pairs, **kw1k).run([(samps1, m1k)])
+    sv1k = o.solve_pevd(o.compute_covar(obs1k, m1k), gauge=True)
+    assert code1k == 0 and np.max(np.abs(f1k - o.directional_feats(obs1k, sv1k.T, df_pair=pairs))) < 2e-3
 
     # ---- command line level ----
     py = [sys.executable]

@@ -251,3 +251,41 @@ def test_batch_dereverb_resident_matches_oracle(hop, window, pcm):
     outs2 = eng.run([utts[0][0], np.zeros((3, 20000), np.float32)] if not pcm else
                     [utts[0][0], Pcm16Frames(np.zeros((20000, 3), np.int16))])
     assert outs2[1] is None and np.array_equal(outs2[0], outs[0])
+
+
+def test_batch_wpd_resident_engine_matches_oracle():
+    """engine.BatchWpd (what apply_wpd.py runs since round 5): samples -> STFT -> 2 x (WPE step,
+    CGMM, power- and mask-weighted covariances, MVDR, beamformer) -> inverse STFT + renorm, on
+    device pointers of one scratch block; a ragged batch, float32 and 16-bit PCM inputs, against
+    the oracle's facted_wpd (libs/wpe.py:113-177) + inverse_stft (apply_wpd.py:47-49)."""
+    from setk_amd.engine import BatchWpd, Pcm16Frames
+    kw = dict(frame_len=512, frame_hop=256, window="hann", center=True)
+    utts, floats = [], []
+    for u, N in enumerate((24000, 17001)):
+        mix, sp, nz = o.synth_utterance(340 + u, 4, N, return_parts=True)
+        rev = mix.copy()
+        rev[:, 700:] += 0.35 * mix[:, :-700]
+        q = np.round(rev * 32768.0 * 0.8).astype(np.int16)
+        floats.append(q.astype(np.float32) / 32768.0)
+        utts.append(Pcm16Frames(np.ascontiguousarray(q.T)) if u == 0 else floats[-1])
+    eng = BatchWpd(taps=6, delay=2, context=1, wpd_iters=2, cgmm_iters=6, **kw)
+    res = eng.run(utts)
+    assert all(r is not None for r in res)
+    for (wave, mask), samps in zip(res, floats):
+        obs = o.multichannel_stft(samps, transpose=True, round_power_of_two=True, **kw)
+        tf_mask, enh = o.facted_wpd(obs, cgmm_iters=6, wpd_iters=2, taps=6, delay=2, context=1, gauge=True)
+        ref = o.inverse_stft(enh, norm=np.max(np.abs(samps)), transpose=True, **kw)
+        assert wave.dtype == np.float32 and wave.shape == ref.shape
+        assert rms(wave, ref) / rms(ref) < 1e-3, rms(wave, ref) / rms(ref)
+        assert mask.shape == tf_mask[..., 0].shape and np.mean(np.abs(mask - tf_mask[..., 0])) < 1e-3
+    # PCM16 out: the device quantises by libsndfile's rule
+    eng16 = BatchWpd(taps=6, delay=2, context=1, wpd_iters=2, cgmm_iters=6, pcm16=True, **kw)
+    (w16, _), = eng16.run(utts[:1])
+    assert w16.dtype == np.int16 and pcm16_rel_rms(w16, res[0][0]) < 1e-3
+    eng.close()
+    eng16.close()
+    # another transform size: the numpy mirror behind the same interface
+    eng400 = BatchWpd(taps=4, delay=2, context=1, wpd_iters=1, cgmm_iters=4, frame_len=400, frame_hop=160,
+                      round_power_of_two=False)
+    (w400, m400), = eng400.run([floats[1][:, :12000]])
+    assert np.isfinite(w400).all() and m400.shape[1] == 201
