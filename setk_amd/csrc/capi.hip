@@ -1511,8 +1511,10 @@ int setk_directional_feats(setk_handle_t h, const float* spec, const float* stee
                                         F, static_cast<float*>(ob.dev), s));
     rc = copy_back(h, ob, s);
     if (rc) return rc;
-    // `pairs` was uploaded from the caller's host array: drained before returning
-    HIP_TRY(h, hipStreamSynchronize(s));
+    // (`pairs` went through the handle's page-locked buffer: upload() has copied it)  Host
+    // operands are pageable copies queued on the stream: drained before they may be released;
+    // with device operands the call is asynchronous like the other stand-alone operators
+    if (ob.host || !is_device_ptr(spec) || !is_device_ptr(steer_vector)) HIP_TRY(h, hipStreamSynchronize(s));
     return SETK_OK;
 }
 

@@ -937,22 +937,44 @@ class _Twin(object):
         self.cap, self.h, self.d = 0, 0, 0
 
 
+class _DfLane(object):
+    """One of the two in-flight halves of BatchDirectionalFeatures: its own library handle (a handle
+    orders its calls on one stream at a time), slabs, mask twin and device scratch."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.slabs = _Slabs(ctx)
+        self.masks = _Twin(ctx)
+        self.scratch, self.scratch_cap = 0, 0
+        self.pending = None
+
+    def close(self):
+        self.slabs.close()
+        self.masks.close()
+        if self.scratch:
+            self.ctx.device_free(self.scratch)
+            self.scratch, self.scratch_cap = 0, 0
+
+
 class BatchDirectionalFeatures(object):
     """Directional features from TF masks for a batch of utterances, resident on the device.
 
     Replaces the per-utterance body of funcwj/setk scripts/sptk/compute_df_on_mask.py:40-54
     (SpectrogramReader -> compute_covar -> solve_pevd -> directional_feats, libs/spatial.py:
-    184-208): the samples of a batch go up in one slab, ONE setk_stft_batch launch writes every
+    184-208): the samples of a chunk go up in one slab, ONE setk_stft_batch launch writes every
     spectrogram, and per utterance setk_covar -> setk_pevd -> setk_directional_feats run on
     device pointers -- the spectrogram (31 MB at 8 ch x 30 s), the covariance and the steer
     vector never visit the host; one slab of T x F features and the per-bin status words comes
-    down per batch.  run() takes [(samps C x N float32 | Pcm16Frames, mask T x F or F x T)] and
-    returns [(features T x F float32 | None, status)]: status != 0 is numpy's LinAlgError case
-    (np.linalg.eigh on a non-finite covariance).  Other transform sizes and more than 8 channels
-    go through the stand-alone operators of setk_amd.libs (numpy in, numpy out)."""
+    down per chunk.  Two chunks are in flight (two library handles, two streams): the upload and
+    the host-side staging of one overlap the kernels and the download of the other -- the path is
+    bound by the PCIe transfer of samples, masks and feature maps.  run() takes [(samps C x N
+    float32 | Pcm16Frames, mask T x F or F x T)] and returns [(features T x F float32 | None,
+    status)]: status != 0 is numpy's LinAlgError case (np.linalg.eigh on a non-finite
+    covariance).  Other transform sizes and more than 8 channels go through the stand-alone
+    operators of setk_amd.libs (numpy in, numpy out)."""
 
     def __init__(self, df_pair, frame_len=512, frame_hop=256, center=True, round_power_of_two=True,
-                 window="hann", device=None, max_batch_samples=1 << 28):
+                 window="hann", device=None, max_batch_samples=1 << 28, chunk_utts=8):
         pairs = [(int(i), int(j)) for i, j in df_pair]
         if not pairs:
             raise ValueError("no microphone pair given")
@@ -965,20 +987,15 @@ class BatchDirectionalFeatures(object):
         self.round_power_of_two = round_power_of_two
         self.num_bins = n_fft // 2 + 1
         self.max_batch_samples = max_batch_samples
-        self._slabs = None
-        self._masks = None
-        self._scratch, self._scratch_cap = 0, 0
+        self.chunk_utts = max(1, int(chunk_utts))
+        self._lanes = []
 
     def close(self):
-        b, self._slabs = self._slabs, None
-        if b:
-            b.close()
-        if self._masks is not None:
-            self._masks.close()
-            self._masks = None
-        if self._scratch:
-            self.ctx.device_free(self._scratch)
-            self._scratch, self._scratch_cap = 0, 0
+        lanes, self._lanes = self._lanes, []
+        for k, lane in enumerate(lanes):
+            lane.close()
+            if k > 0:
+                lane.ctx.close()  # (lane 0 runs on the process-wide context)
 
     def __del__(self):
         try:
@@ -998,6 +1015,14 @@ class BatchDirectionalFeatures(object):
             raise ValueError(f"mask {np.asarray(mask).shape} does not fit {T} frames x {F} bins")
         return np.minimum(m, 1).astype(np.float32, copy=False)
 
+    def _lane(self, k):
+        s = self.stft
+        while len(self._lanes) <= k:
+            ctx = self.ctx if not self._lanes else _ffi.Context(self.ctx.device)
+            ctx.stft_plan(s["frame_len"], s["frame_hop"], s["n_fft"], s["center"], s["window"])
+            self._lanes.append(_DfLane(ctx))
+        return self._lanes[k]
+
     def run(self, utts):
         s = self.stft
         self.ctx.stft_plan(s["frame_len"], s["frame_hop"], s["n_fft"], s["center"], s["window"])
@@ -1005,6 +1030,7 @@ class BatchDirectionalFeatures(object):
         by_channels = {}
         for i, (samps, _) in enumerate(utts):
             by_channels.setdefault(_channels_and_size(samps)[0], []).append(i)
+        turn = 0
         for C, idx in by_channels.items():
             if any(max(p) >= C or min(p) < 0 for p in self.pairs):
                 raise ValueError(f"microphone pair out of range for {C} channels: {self.pairs}")
@@ -1012,24 +1038,26 @@ class BatchDirectionalFeatures(object):
                 for i in idx:
                     out[i] = self._one_by_operators(*utts[i])
                 continue
-            batch, load = [], 0
-            for i in idx:
-                n = _channels_and_size(utts[i][0])[1]
-                if batch and load + n > self.max_batch_samples:
-                    self._run_resident(utts, batch, C, out)
-                    batch, load = [], 0
-                batch.append(i)
-                load += n
-            if batch:
-                self._run_resident(utts, batch, C, out)
+            chunk, load = [], 0
+            for i in idx + [None]:
+                n = 0 if i is None else _channels_and_size(utts[i][0])[1]
+                if chunk and (i is None or len(chunk) >= self.chunk_utts or load + n > self.max_batch_samples):
+                    lane = self._lane(turn & 1)
+                    self._collect(lane, out)          # the chunk this lane carried two turns ago
+                    self._submit(lane, utts, chunk, C)
+                    turn += 1
+                    chunk, load = [], 0
+                if i is not None:
+                    chunk.append(i)
+                    load += n
+        for lane in self._lanes:
+            self._collect(lane, out)
         return out
 
-    def _run_resident(self, utts, batch, C, out):
-        ctx, F = self.ctx, self.num_bins
-        if self._slabs is None:
-            self._slabs = _Slabs(ctx)
-            self._masks = _Twin(ctx)
-        b, mk = self._slabs, self._masks
+    def _submit(self, lane, utts, batch, C):
+        """Everything of one chunk, enqueued on the lane's stream; nothing waits here."""
+        ctx, F = lane.ctx, self.num_bins
+        b, mk = lane.slabs, lane.masks
         al = lambda v: (v + 255) & ~255  # noqa: E731
         # out-slab per utterance: [features T x F float32 | status int32[F]]
         aptr, ns, off_out, n_out = b.stage_audio(
@@ -1053,13 +1081,13 @@ class BatchDirectionalFeatures(object):
             need = al(need + 8 * F * C * C)
             sv.append(need)
             need = al(need + 8 * F * C)
-        if need > self._scratch_cap:
+        if need > lane.scratch_cap:
             ctx.stream_synchronize(b.stream)
-            if self._scratch:
-                ctx.device_free(self._scratch)
-            self._scratch_cap = int(need * 1.25)
-            self._scratch = ctx.device_alloc(self._scratch_cap)
-        base = self._scratch
+            if lane.scratch:
+                ctx.device_free(lane.scratch)
+            lane.scratch_cap = int(need * 1.25)
+            lane.scratch = ctx.device_alloc(lane.scratch_cap)
+        base = lane.scratch
         ctx.stft_batch(C, aptr, ns, [base + o for o in spec], stream=b.stream)
         for k, T in enumerate(frames):
             o_df = b.d_out + off_out[k]
@@ -1067,7 +1095,18 @@ class BatchDirectionalFeatures(object):
             ctx.covar(base + spec[k], mk.d + moff[k], C, T, F, base + cov[k], stream=b.stream)
             ctx.pevd(base + cov[k], None, F, C, 0, base + sv[k], o_st, stream=b.stream)
             ctx.directional_feats(base + spec[k], base + sv[k], self.pairs, C, T, F, o_df, stream=b.stream)
-        host = b.fetch(n_out)
+        ctx.memcpy_d2h_async(b.h_out, b.d_out, n_out, b.stream)
+        lane.pending = (batch, frames, off_out)
+
+    def _collect(self, lane, out):
+        if lane.pending is None:
+            return
+        batch, frames, off_out = lane.pending
+        lane.pending = None
+        F = self.num_bins
+        al = lambda v: (v + 255) & ~255  # noqa: E731
+        lane.ctx.stream_synchronize(lane.slabs.stream)
+        host = lane.slabs.np_out
         for k, (i, T) in enumerate(zip(batch, frames)):
             o_df = off_out[k]
             o_st = o_df + al(4 * T * F)

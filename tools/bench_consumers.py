@@ -85,15 +85,18 @@ def run(utts=16, seconds=10.0):
                              "ms_per_utt": round(1e3 * dt, 2), "value": round(seconds / dt, 1)}
     # the CLI's engine since round 5: samples + masks in, feature maps out, spectrograms /
     # covariances / steer vectors stay on the device (engine.BatchDirectionalFeatures)
-    from setk_amd.engine import BatchDirectionalFeatures
+    from setk_amd.engine import BatchDirectionalFeatures, Pcm16Frames
+    from setk_amd.libs import wavio
     dfe = BatchDirectionalFeatures([(0, 1), (0, 2), (1, 3)], frame_len=512, frame_hop=256, center=True)
-    pairs = [(mix, mask)] * 16
+    # (16-bit frames, as the command line hands them over: the wave files are PCM16)
+    pairs = [(Pcm16Frames(np.ascontiguousarray(wavio.float_to_pcm16(mix.T))), mask)] * 32
     dfe.run(pairs)
     dtr = timed(lambda: dfe.run(pairs), 3)
     res["df_on_mask_4ch_resident"] = {
-        "workload": f"the same from SAMPLES (STFT included) for {len(pairs)} utterances per call: one upload, "
-                    "setk_stft_batch -> setk_covar -> setk_pevd -> setk_directional_feats on device "
-                    "pointers, one download",
+        "workload": f"the same from SAMPLES (16-bit frames; STFT included) for {len(pairs)} utterances per call, "
+                    "chunks of 8 on two lanes: upload, setk_stft_batch -> setk_covar -> setk_pevd -> "
+                    "setk_directional_feats on device pointers, download -- one chunk's transfers under "
+                    "the other's kernels",
         "ms_per_utt": round(1e3 * dtr / len(pairs), 2), "value": round(len(pairs) * seconds / dtr, 1),
         "per_utterance_numpy_path_incl_stft_ms": None}
     # what compute_df_on_mask.py cost per utterance before: the SpectrogramReader's STFT
