@@ -288,9 +288,12 @@ def main():
     # (a'') the shard as 16-bit PCM (its own roofline block; the float32 headline is untouched)
     int16_leg = None
     if rank == 0 and world == 1 and args.int16_ingest:
-        int16_leg = int16_ingest_leg(args, ctx, _ffi, torch, opts, audio, masks, waves, C, N, T, L, U, nd,
-                                     {"stft_covar": round(stage_ms[0], 4), "beamform_istft": round(stage_ms[2], 4)})
-        if args.pmc:
+        try:
+            int16_leg = int16_ingest_leg(args, ctx, _ffi, torch, opts, audio, masks, waves, C, N, T, L, U, nd,
+                                         {"stft_covar": round(stage_ms[0], 4), "beamform_istft": round(stage_ms[2], 4)})
+        except Exception as e:  # an auxiliary leg never takes the headline line down with it
+            int16_leg = {"error": repr(e)}
+        if args.pmc and "error" not in int16_leg:
             tr = pcm_traffic(args)
             int16_leg["roofline"]["pmc"] = {k: (None if not isinstance(v, dict) else {
                 "hbm_read_bytes": v.get("hbm_read_bytes"), "hbm_write_bytes": v.get("hbm_write_bytes"),
@@ -362,12 +365,18 @@ def main():
             del audio, masks, waves
             audio = masks = waves = []
             torch.cuda.empty_cache()
-            out["other_configs"] = other_configs(torch, _ffi, synth, dev, args if args.pmc else None, rates)
+            try:  # (an auxiliary leg never takes the headline line down with it)
+                out["other_configs"] = other_configs(torch, _ffi, synth, dev, args if args.pmc else None, rates)
+            except Exception as e:
+                out["other_configs"] = {"error": repr(e)}
         if world == 1 and args.e2e_utts > 0:
             # free the resident shard first: the CLI leg is its own process
             audio = masks = waves = None
             torch.cuda.empty_cache()
-            out["end_to_end"] = end_to_end(args, C, N)
+            try:
+                out["end_to_end"] = end_to_end(args, C, N)
+            except Exception as e:
+                out["end_to_end"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
