@@ -53,7 +53,12 @@ def _build_locked(force, verbose):
     # scheduler measured 1-2 % faster there.  Pass 1 runs at a 128-VGPR budget
     # where the same scheduler spills (measured 1.14 vs 1.03 ms), so it keeps the
     # default.
-    extra = {"pass2.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    # Round 5 re-measured the strategies on the current sources (profiles/round5_sched_strategy_ab.txt):
+    # pass 1 no longer spills under max-ilp / max-memory-clause and gains 0.7 % (0.929 against 0.936
+    # ms), the matrix-core pass 2 0.6 % under max-ilp; iterative-maxocc costs pass 1 44 %.
+    extra = {"pass1.hip": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
+             "pass2_mc.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+             "pass2.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
              "solve.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
              "modular.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
              "cgmm.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
