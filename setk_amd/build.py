@@ -62,7 +62,9 @@ def _build_locked(force, verbose):
              "solve.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
              "modular.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
              "cgmm.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-             "cgmm_bin.hip": [],
+             # (round 5: 16.5 - 16.7 ms per configs[4] batch against 17.0 - 17.4 with the default
+             #  strategy, profiles/round5_cgmm_sched_ab.txt)
+             "cgmm_bin.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
              "cgmm_k.hip": [],
              "wpe.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
              "comm.hip": [],
