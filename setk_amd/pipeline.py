@@ -49,6 +49,10 @@ from .libs import wavio
 
 # how a payload gets from the page cache into the page-locked slab: "mmap" (default) or "preadv"
 READ_MODE = os.environ.get("SETK_READ_MODE", "mmap")
+# payloads below this size are read with preadv: an mmap + munmap pair costs ~250 us under load
+# (the unmap's TLB shootdown reaches every CPU the process's threads ran on), as much as copying
+# 2.5 MB (tools/ubench/read_small.py)
+MMAP_MIN_BYTES = int(os.environ.get("SETK_MMAP_MIN_KB", "256")) << 10
 
 ALIGN = 256
 
@@ -110,7 +114,7 @@ class Payload(object):
             return
         fd = os.open(self.path, os.O_RDONLY)
         try:
-            if READ_MODE == "mmap" and self.nbytes >= (256 << 10) and \
+            if READ_MODE == "mmap" and self.nbytes >= MMAP_MIN_BYTES and \
                     os.fstat(fd).st_size >= self.offset + self.nbytes:  # (a short file: IOError below)
                 # A read() marks every page accessed, and the FIRST access of a page moves it
                 # between the kernel's LRU lists under a shared lock: first reads of fresh

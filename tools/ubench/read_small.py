@@ -26,8 +26,27 @@ def make():
             f.write(blob)
 
 
+PINNED = os.environ.get("READ_SMALL_PINNED") == "1"
+_ctx = None
+
+
+def _slab(nbytes):
+    """plain numpy memory, or (READ_SMALL_PINNED=1) the page-locked memory the pipeline copies into"""
+    global _ctx
+    if not PINNED:
+        return np.ones(nbytes, dtype=np.uint8)
+    if _ctx is None:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+        from setk_amd import _ffi
+        _ffi.set_torch_free()
+        _ctx = _ffi.Context(0)
+    addr, view = _ctx.host_alloc(nbytes)
+    view[:] = 1
+    return view
+
+
 def run(nt, mode):
-    slab = np.ones(nt * SZ, dtype=np.uint8)
+    slab = _slab(nt * SZ)
 
     def work(k):
         dst = slab[k * SZ:(k + 1) * SZ]
@@ -57,9 +76,10 @@ def run(nt, mode):
 
 
 def main():
-    print(f"# {N} files of {SZ} bytes in /dev/shm; GB/s aggregate (us per file per thread)")
+    print(f"# {N} files of {SZ} bytes in /dev/shm; GB/s aggregate (us per file per thread); destination: "
+          f"{'page-locked (setk_host_alloc)' if PINNED else 'numpy'}")
     try:
-        for mode in ("preadv", "mmap_seq", "mmap_populate"):
+        for mode in (("mmap_seq",) if PINNED else ("preadv", "mmap_seq", "mmap_populate")):
             for nt in (6, 12, 24):
                 make()
                 a, ua = run(nt, mode)
