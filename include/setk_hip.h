@@ -380,6 +380,17 @@ int setk_wpe_batch(setk_handle_t h, int n_utts, const float* const* spec, int nu
                    const int* num_frames, int num_bins, int taps, int delay, int context,
                    int num_iters, float* const* out, int* status, void* stream);
 
+/* setk_wpe_batch for facted_wpd's batch (libs/wpe.py:113-177, apply_wpd.py:20-60): the
+ * variances of iteration 0 come per utterance from lambda_enh[u] (complex64 [T_u][F], |.|^2 of
+ * the previous enhanced signal; a NULL array or entry: compute_lambda of the input, as
+ * setk_wpe_batch), and inv_lambda_out[u] (float32 [T_u][F], NULL array: not wanted) receives
+ * 1 / lambda of the LAST iteration -- the per-utterance arguments of setk_wpe, for n_utts
+ * utterances behind one launch per iteration. */
+int setk_wpe_batch_var(setk_handle_t h, int n_utts, const float* const* spec, int num_channels,
+                       const int* num_frames, int num_bins, int taps, int delay, int context,
+                       int num_iters, const float* const* lambda_enh, float* const* out,
+                       float* const* inv_lambda_out, int* status, void* stream);
+
 /* The same with spec[u] / out[u] in the reference's own layout, F x N x T_u complex64 (the
  * `reverb` / return value of wpe(), libs/wpe.py:84-110): it is the layout the step kernel
  * works in, so no transposition happens on either side.  out[u] must not alias spec[u]. */

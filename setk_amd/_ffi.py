@@ -102,7 +102,7 @@ def exported_symbols():
         "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_pcm16_channel_stride", "setk_pcm16_deinterleave_batch", "setk_float_to_pcm16", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks", "setk_cgmm_masks_k",
         "setk_cgmm_masks_batch", "setk_cgmm_estimate_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
-        "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_wpe_batch", "setk_wpe_batch_fnt", "setk_set_profiling",
+        "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_wpe_batch", "setk_wpe_batch_fnt", "setk_wpe_batch_var", "setk_set_profiling",
         "setk_last_stage_ms",
         "setk_comm_unique_id", "setk_comm_create", "setk_comm_allreduce_f64", "setk_comm_barrier",
         "setk_comm_destroy", "setk_comm_last_error"
@@ -195,6 +195,9 @@ def load_library():
     lib.setk_wpe_batch.argtypes = [H, c_int, POINTER(c_void_p), c_int, POINTER(c_int), c_int, c_int,
                                    c_int, c_int, c_int, POINTER(c_void_p), fp, c_void_p]
     lib.setk_wpe_batch_fnt.argtypes = lib.setk_wpe_batch.argtypes
+    lib.setk_wpe_batch_var.argtypes = [H, c_int, POINTER(c_void_p), c_int, POINTER(c_int), c_int, c_int,
+                                       c_int, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p),
+                                       POINTER(c_void_p), fp, c_void_p]
     lib.setk_directional_feats.argtypes = [H, fp, fp, POINTER(c_int), c_int, c_int, c_int, c_int,
                                            fp, c_void_p]
     lib.setk_apply_weights_batch.argtypes = [
@@ -612,6 +615,22 @@ class Context:
         self.check(
             self._lib.setk_wpe_batch_fnt(self._h, n, sp, int(C), fr, int(F), int(taps), int(delay),
                                          int(context), int(num_iters), op, _ptr(status),
+                                         current_stream_ptr() if stream is None else stream))
+
+    def wpe_batch_var(self, specs, C, frames, F, taps, delay, context, num_iters, outs, lambda_enh=None,
+                      inv_lambda_outs=None, status=None, stream=None):
+        """wpe_batch with facted_wpd's per-utterance operands: lambda_enh[u] ([T_u][F] complex64 or
+        None) gives the variances of iteration 0, inv_lambda_outs[u] ([T_u][F] float32) receives
+        1 / lambda of the last one.  Arrays or device addresses; status int32 [n][F] or None."""
+        n = len(specs)
+        sp = (c_void_p * n)(*[_ptr(a) for a in specs])
+        op = (c_void_p * n)(*[_ptr(a) for a in outs])
+        le = (c_void_p * n)(*[_ptr(a) for a in lambda_enh]) if lambda_enh is not None else None
+        il = (c_void_p * n)(*[_ptr(a) for a in inv_lambda_outs]) if inv_lambda_outs is not None else None
+        fr = (c_int * n)(*[int(t) for t in frames])
+        self.check(
+            self._lib.setk_wpe_batch_var(self._h, n, sp, int(C), fr, int(F), int(taps), int(delay),
+                                         int(context), int(num_iters), le, op, il, _ptr(status),
                                          current_stream_ptr() if stream is None else stream))
 
     def wpe_step(self, spec, C, T, F, taps, delay, lambda_ft, out, status=None, stream=None):

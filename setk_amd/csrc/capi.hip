@@ -1721,20 +1721,21 @@ int setk_apply_weights_batch(setk_handle_t h, int n_utts, int num_channels,
 // compute_lambda(spec); later iterations use compute_lambda(dereverb).
 namespace {
 // n_utts utterances of the same channel count per call: one wpe_step launch per
-// iteration covers every (bin, utterance).  lambda_enh / lambda_ft / inv_lambda_out only
-// with n_utts == 1 (facted_wpd, wpe_step).  status: [n_utts][F] (host or device) or NULL.
+// iteration covers every (bin, utterance).  lambda_enh / inv_lambda_out: per-utterance arrays
+// (facted_wpd) or NULL; lambda_ft only with n_utts == 1 (wpe_step).  status: [n_utts][F] (host
+// or device) or NULL.
 // fnt: spec / out are in the reference's own layout, F x N x T (libs/wpe.py:84-110) -- which is
 // the layout the step kernel works in, so the two transposes fall away
 int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int num_channels,
                    const int* num_frames, int num_bins, int taps, int delay, int context,
-                   int num_iters, const float* lambda_enh, const double* lambda_ft,
-                   float* const* out, float* inv_lambda_out, int* status, void* stream,
+                   int num_iters, const float* const* lambda_enh, const double* lambda_ft,
+                   float* const* out, float* const* inv_lambda_out, int* status, void* stream,
                    bool fnt = false) {
     if (!h || n_utts <= 0 || !spec || !out || !num_frames || num_bins <= 0 || num_iters <= 0 ||
         delay < 0 || context < 0)
         return fail(h, SETK_ERR_INVALID, "bad args");
-    if ((lambda_enh || lambda_ft || inv_lambda_out) && n_utts != 1)
-        return fail(h, SETK_ERR_INVALID, "caller-supplied variances need n_utts == 1");
+    if (lambda_ft && n_utts != 1)
+        return fail(h, SETK_ERR_INVALID, "caller-supplied variances (wpe_step) need n_utts == 1");
     const int C = num_channels, F = num_bins;
     if (!wpe_supported(C, taps))
         return fail(h, SETK_ERR_UNSUPPORTED, wpe_limit_message(C, taps));
@@ -1746,6 +1747,8 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
         OutBuf ob;
         float *x_fct, *bufs[2];
         double* lam;
+        const float* d_enh;
+        OutBuf ob_il;
         int T;
     };
     std::vector<Utt> us(n_utts);
@@ -1766,20 +1769,20 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
         if (!q.x_fct || !q.bufs[0] || !q.bufs[1] || !q.lam) return fail(h, SETK_ERR_NOMEM, "arena");
         // F x N x T in and out: the last iteration writes the caller's (or its staged) output
         if (fnt) q.bufs[(num_iters - 1) & 1] = static_cast<float*>(q.ob.dev);
-    }
-    const float* d_enh = nullptr;
-    if (lambda_enh) {
-        rc = stage_in(h, lambda_enh, (size_t)us[0].T * F * 2, s, &d_enh);
-        if (rc) return rc;
+        q.d_enh = nullptr;
+        if (lambda_enh && lambda_enh[u]) {
+            rc = stage_in(h, lambda_enh[u], (size_t)q.T * F * 2, s, &q.d_enh);
+            if (rc) return rc;
+        }
+        if (inv_lambda_out) {
+            if (!inv_lambda_out[u]) return fail(h, SETK_ERR_INVALID, "null inv_lambda_out entry");
+            rc = stage_out(h, inv_lambda_out[u], (size_t)q.T * F * sizeof(float), &q.ob_il);
+            if (rc) return rc;
+        }
     }
     const double* d_lam_in = nullptr;
     if (lambda_ft) {
         rc = stage_in(h, lambda_ft, (size_t)us[0].T * F, s, &d_lam_in);
-        if (rc) return rc;
-    }
-    OutBuf ob_il;
-    if (inv_lambda_out) {
-        rc = stage_out(h, inv_lambda_out, (size_t)us[0].T * F * sizeof(float), &ob_il);
         if (rc) return rc;
     }
     int* d_st = static_cast<int*>(arena_alloc(h, (size_t)n_utts * F * sizeof(int) * (size_t)num_iters));
@@ -1815,8 +1818,8 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
                 // wpe_step (libs/wpe.py:58-81): the caller's variances as given, F x T float64
                 HIP_TRY(h, hipMemcpyAsync(q.lam, d_lam_in, (size_t)q.T * F * sizeof(double),
                                           hipMemcpyDeviceToDevice, s));
-            else if (it == 0 && d_enh)
-                HIP_TRY(h, launch_wpe_lambda_from_enh(d_enh, q.T, F, q.lam, s));
+            else if (it == 0 && q.d_enh)
+                HIP_TRY(h, launch_wpe_lambda_from_enh(q.d_enh, q.T, F, q.lam, s));
             else
                 HIP_TRY(h, launch_wpe_lambda(cur, C, q.T, F, context, q.lam, s));
             wpe_fill_args(tbl.data() + (size_t)u * ab, q.x_fct, q.lam, q.bufs[it & 1],
@@ -1838,11 +1841,11 @@ int wpe_batch_impl(setk_handle_t h, int n_utts, const float* const* spec, int nu
                                             static_cast<float*>(q.ob.dev), false, s));
         rc = copy_back(h, q.ob, s);
         if (rc) return rc;
-    }
-    if (inv_lambda_out) {
-        HIP_TRY(h, launch_wpe_inv_lambda(us[0].lam, us[0].T, F, static_cast<float*>(ob_il.dev), s));
-        rc = copy_back(h, ob_il, s);
-        if (rc) return rc;
+        if (inv_lambda_out) {
+            HIP_TRY(h, launch_wpe_inv_lambda(q.lam, q.T, F, static_cast<float*>(q.ob_il.dev), s));
+            rc = copy_back(h, q.ob_il, s);
+            if (rc) return rc;
+        }
     }
     if (status) {
         // worst status over the iterations, per utterance and bin: an error code (1..3) wins
@@ -1881,7 +1884,16 @@ int setk_wpe(setk_handle_t h, const float* spec, int num_channels, int num_frame
              int taps, int delay, int context, int num_iters, const float* lambda_enh,
              float* out, float* inv_lambda_out, int* status, void* stream) {
     return wpe_batch_impl(h, 1, &spec, num_channels, &num_frames, num_bins, taps, delay, context,
-                          num_iters, lambda_enh, nullptr, &out, inv_lambda_out, status, stream);
+                          num_iters, lambda_enh ? &lambda_enh : nullptr, nullptr, &out,
+                          inv_lambda_out ? &inv_lambda_out : nullptr, status, stream);
+}
+
+int setk_wpe_batch_var(setk_handle_t h, int n_utts, const float* const* spec, int num_channels,
+                       const int* num_frames, int num_bins, int taps, int delay, int context,
+                       int num_iters, const float* const* lambda_enh, float* const* out,
+                       float* const* inv_lambda_out, int* status, void* stream) {
+    return wpe_batch_impl(h, n_utts, spec, num_channels, num_frames, num_bins, taps, delay, context,
+                          num_iters, lambda_enh, nullptr, out, inv_lambda_out, status, stream);
 }
 
 int setk_wpe_step(setk_handle_t h, const float* spec, int num_channels, int num_frames,

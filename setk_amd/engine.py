@@ -8,6 +8,7 @@ utterances at once -- per-utterance work is microseconds on an MI355X, so the
 engineering unit is the batch, not the utterance.
 """
 import os
+import threading
 
 import numpy as np
 
@@ -965,9 +966,10 @@ class BatchDirectionalFeatures(object):
     spectrogram, and per utterance setk_covar -> setk_pevd -> setk_directional_feats run on
     device pointers -- the spectrogram (31 MB at 8 ch x 30 s), the covariance and the steer
     vector never visit the host; one slab of T x F features and the per-bin status words comes
-    down per chunk.  Two chunks are in flight (two library handles, two streams): the upload and
-    the host-side staging of one overlap the kernels and the download of the other -- the path is
-    bound by the PCIe transfer of samples, masks and feature maps.  run() takes [(samps C x N
+    down per chunk.  Two chunks are in flight (two library handles, two streams, each driven by
+    its own host thread): the staging copies, the upload and the launches of one overlap the
+    kernels and the download of the other -- the path is bound by the host's copies into and out
+    of the page-locked slabs and the PCIe transfer of samples, masks and feature maps.  run() takes [(samps C x N
     float32 | Pcm16Frames, mask T x F or F x T)] and returns [(features T x F float32 | None,
     status)]: status != 0 is numpy's LinAlgError case (np.linalg.eigh on a non-finite
     covariance).  Other transform sizes and more than 8 channels go through the stand-alone
@@ -1003,8 +1005,10 @@ class BatchDirectionalFeatures(object):
         except Exception:
             pass
 
-    def condition_mask(self, mask, T):
-        """compute_df_on_mask.py:44-47: F x T masks are turned, values above one clipped."""
+    def condition_mask(self, mask, T, out=None):
+        """compute_df_on_mask.py:44-47: F x T masks are turned, values above one clipped.  With
+        `out` (T x F float32, e.g. a view of the page-locked upload buffer) the clipped mask is
+        written there in one pass."""
         F = self.num_bins
         m = np.asarray(mask)
         if m.ndim != 2:
@@ -1013,6 +1017,8 @@ class BatchDirectionalFeatures(object):
             m = m.T
         if m.shape != (T, F):
             raise ValueError(f"mask {np.asarray(mask).shape} does not fit {T} frames x {F} bins")
+        if out is not None:
+            return np.minimum(m, 1, out=out, casting="unsafe")
         return np.minimum(m, 1).astype(np.float32, copy=False)
 
     def _lane(self, k):
@@ -1030,7 +1036,7 @@ class BatchDirectionalFeatures(object):
         by_channels = {}
         for i, (samps, _) in enumerate(utts):
             by_channels.setdefault(_channels_and_size(samps)[0], []).append(i)
-        turn = 0
+        chunks = []  # (channel count, utterance indices)
         for C, idx in by_channels.items():
             if any(max(p) >= C or min(p) < 0 for p in self.pairs):
                 raise ValueError(f"microphone pair out of range for {C} channels: {self.pairs}")
@@ -1042,16 +1048,36 @@ class BatchDirectionalFeatures(object):
             for i in idx + [None]:
                 n = 0 if i is None else _channels_and_size(utts[i][0])[1]
                 if chunk and (i is None or len(chunk) >= self.chunk_utts or load + n > self.max_batch_samples):
-                    lane = self._lane(turn & 1)
-                    self._collect(lane, out)          # the chunk this lane carried two turns ago
-                    self._submit(lane, utts, chunk, C)
-                    turn += 1
+                    chunks.append((C, chunk))
                     chunk, load = [], 0
                 if i is not None:
                     chunk.append(i)
                     load += n
-        for lane in self._lanes:
+        if len(chunks) == 1:
+            lane = self._lane(0)
+            self._submit(lane, utts, chunks[0][1], chunks[0][0])
             self._collect(lane, out)
+        elif chunks:
+            # two lanes, each driven by its own thread (the staging copies and the library calls
+            # release the interpreter lock): chunk k goes to lane k & 1, a lane stages, launches and
+            # fetches one chunk at a time while the other lane does the same half a period apart
+            lanes = [self._lane(0), self._lane(1)]
+            errors = []
+
+            def drive(k):
+                try:
+                    for C, chunk in chunks[k::2]:
+                        self._submit(lanes[k], utts, chunk, C)
+                        self._collect(lanes[k], out)
+                except BaseException as e:  # noqa: B902 (re-raised in the caller's thread)
+                    errors.append(e)
+
+            other = threading.Thread(target=drive, args=(1,), name="setk-df-lane1")
+            other.start()
+            drive(0)
+            other.join()
+            if errors:
+                raise errors[0]
         return out
 
     def _submit(self, lane, utts, batch, C):
@@ -1063,14 +1089,14 @@ class BatchDirectionalFeatures(object):
         aptr, ns, off_out, n_out = b.stage_audio(
             [utts[i][0] for i in batch], C, lambda N: al(4 * ctx.num_frames(N) * F) + 4 * F)
         frames = [ctx.num_frames(N) for N in ns]
-        masks = [self.condition_mask(utts[i][1], T) for i, T in zip(batch, frames)]
         moff, need_m = [], 0
         for T in frames:
             moff.append(need_m)
             need_m = al(need_m + 4 * T * F)
         mk.reserve(need_m, b.stream)
-        for m, o in zip(masks, moff):
-            mk.view[o:o + m.size * 4] = np.frombuffer(np.ascontiguousarray(m), dtype=np.uint8)
+        for i, T, o in zip(batch, frames, moff):
+            # (clipped straight into the page-locked buffer: one pass over the mask)
+            self.condition_mask(utts[i][1], T, out=mk.view[o:o + 4 * T * F].view(np.float32).reshape(T, F))
         ctx.memcpy_h2d_async(mk.d, mk.h, need_m, b.stream)
         # device scratch: spectrogram [C][T][F], covariance [F][C][C], steer vector [F][C] per utterance
         need, spec, cov, sv = 0, [], [], []
@@ -1148,8 +1174,9 @@ class BatchWpd(object):
     and the mask-weighted covariance, the MVDR weights and the beamformer.  Where the numpy
     mirror (setk_amd.libs.wpe.facted_wpd) carries every intermediate through host arrays, here
     the samples of a batch go up once, setk_stft_batch writes the spectrograms, and every stage
-    works on device pointers of one scratch block: setk_wpe -> setk_cgmm_masks -> setk_covar x 2
-    -> setk_weights -> setk_beamform, then setk_istft with the renorm to max |samples|
+    works on device pointers of one scratch block, outer iteration by outer iteration: setk_wpe per
+    utterance, ONE setk_cgmm_masks_batch for the batch, setk_covar x 2 -> setk_weights ->
+    setk_beamform per utterance, then setk_istft with the renorm to max |samples|
     (SpectrogramReader.maxabs) and the float -> PCM_16 conversion; one slab comes down per batch:
     [wave | status words | speech mask].  run() takes C x N float32 arrays or Pcm16Frames of one
     channel count and returns [(wave, mask T x F float32) | None]; None is the reference's
@@ -1172,6 +1199,7 @@ class BatchWpd(object):
         self.rank_deficient_bins = 0
         self._slabs = None
         self._scratch, self._scratch_cap = 0, 0
+        self._cgmm_per_utt = os.environ.get("SETK_WPD_CGMM_PER_UTT") == "1"
 
     def close(self):
         b, self._slabs = self._slabs, None
@@ -1212,7 +1240,7 @@ class BatchWpd(object):
         b = self._slabs
         al = lambda v: (v + 255) & ~255  # noqa: E731
         esz = 2 if self.pcm16 else 4
-        n_status = 2 * K * F  # per outer iteration: WPE's tap correlation, the MVDR solve
+        n_status = K * F  # per outer iteration: the MVDR solve (WPE's words come back with its call)
 
         def out_bytes(N):
             T = ctx.num_frames(N)
@@ -1221,7 +1249,7 @@ class BatchWpd(object):
         aptr, ns, off_out, n_out = b.stage_audio(utts, C, out_bytes)
         frames = [ctx.num_frames(N) for N in ns]
         lens = [ctx.istft_num_samples(T) for T in frames]
-        # scratch per utterance: spectrogram, dereverberated channels, 1 / lambda, posteriors,
+        # scratch per utterance: spectrogram, dereverberated channels, 1 / lambda,
         # two covariances, weights, enhanced spectrum, float wave (PCM16 output)
         lay, need = [], 0
 
@@ -1233,7 +1261,7 @@ class BatchWpd(object):
 
         for T, L in zip(frames, lens):
             lay.append(dict(spec=take(8 * C * T * F), der=take(8 * C * T * F), inv=take(4 * T * F),
-                            gamma=take(8 * T * F), Rd=take(8 * F * C * C), Rs=take(8 * F * C * C),
+                            Rd=take(8 * F * C * C), Rs=take(8 * F * C * C),
                             w=take(8 * F * C), enh=take(8 * T * F), wav=take(4 * L), norm=take(256)))
         if need > self._scratch_cap:
             ctx.stream_synchronize(b.stream)
@@ -1245,38 +1273,53 @@ class BatchWpd(object):
         ctx.stft_batch(C, aptr, ns, [base + q["spec"] for q in lay], stream=st)
         mvdr = _ffi.BfOpts(kind=_ffi.BF_MVDR)
         peaks = [np.array([self._peak(u)], dtype=np.float32) for u in utts]  # (kept alive until the fetch)
-        for k, (q, T, L) in enumerate(zip(lay, frames, lens)):
-            o_wave = b.d_out + off_out[k]
-            o_stat = o_wave + al(esz * L)
-            o_mask = o_stat + al(4 * n_status)
-            p = lambda name: base + q[name]  # noqa: E731
-            for it in range(K):
-                ctx.wpe(p("spec"), C, T, F, self.taps, self.delay, self.context, 1, p("der"),
-                        lambda_enh=p("enh") if it else None, inv_lambda_out=p("inv"),
-                        status=o_stat + 4 * F * (2 * it), stream=st)
-                ctx.cgmm_masks(p("der"), C, T, F, self.cgmm_iters, None, p("gamma"), o_mask, stream=st,
-                               update_alpha=self.update_alpha)
+        d_wave = [b.d_out + off_out[k] for k in range(len(utts))]
+        d_stat = [d_wave[k] + al(esz * L) for k, L in enumerate(lens)]
+        d_mask = [d_stat[k] + al(4 * n_status) for k in range(len(utts))]
+        # iteration-major: the CGMM of an outer iteration is ONE launch over (bin, utterance) for
+        # the whole batch -- 257 workgroups of one 10 s utterance fill an eighth of the chip, and the
+        # EM's 22 passes are latency, not throughput, at that size
+        wpe_status = np.zeros((K, len(utts), F), dtype=np.int32)
+        for it in range(K):
+            # (the WPE step too: one launch over (bin, utterance); its status words come back with
+            # the call, which drains the stream as every setk_wpe* call does)
+            ctx.wpe_batch_var([base + q["spec"] for q in lay], C, frames, F, self.taps, self.delay,
+                              self.context, 1, [base + q["der"] for q in lay],
+                              lambda_enh=[base + q["enh"] for q in lay] if it else None,
+                              inv_lambda_outs=[base + q["inv"] for q in lay], status=wpe_status[it],
+                              stream=st)
+            if self._cgmm_per_utt:  # A/B only (SETK_WPD_CGMM_PER_UTT=1): one EM launch per utterance
+                for k, (q, T) in enumerate(zip(lay, frames)):
+                    ctx.cgmm_masks_batch(C, [base + q["der"]], [T], F, self.cgmm_iters, None, [d_mask[k]],
+                                         stream=st, update_alpha=self.update_alpha)
+            else:
+                ctx.cgmm_masks_batch(C, [base + q["der"] for q in lay], frames, F, self.cgmm_iters, None,
+                                     d_mask, stream=st, update_alpha=self.update_alpha)
+            for k, (q, T) in enumerate(zip(lay, frames)):
+                p = lambda name: base + q[name]  # noqa: E731
                 # the mask 1 / lambda gives the power-weighted covariance up to a per-bin scale
                 # that cancels in the MVDR weight
                 ctx.covar(p("der"), p("inv"), C, T, F, p("Rd"), stream=st)
-                ctx.covar(p("der"), o_mask, C, T, F, p("Rs"), stream=st)
-                ctx.weights(mvdr, p("Rs"), p("Rd"), None, F, C, p("w"), o_stat + 4 * F * (2 * it + 1), stream=st)
+                ctx.covar(p("der"), d_mask[k], C, T, F, p("Rs"), stream=st)
+                ctx.weights(mvdr, p("Rs"), p("Rd"), None, F, C, p("w"), d_stat[k] + 4 * F * it, stream=st)
                 ctx.beamform(p("w"), p("der"), C, T, F, p("enh"), stream=st)
+        for k, (q, T, L) in enumerate(zip(lay, frames, lens)):
+            p = lambda name: base + q[name]  # noqa: E731
             ctx.memcpy_h2d_async(p("norm"), peaks[k].ctypes.data, 4, st)
             if self.pcm16:
                 ctx.istft(p("enh"), 1, T, None, p("norm"), p("wav"), stream=st)
-                ctx.float_to_pcm16(p("wav"), 1, L, o_wave, stream=st)
+                ctx.float_to_pcm16(p("wav"), 1, L, d_wave[k], stream=st)
             else:
-                ctx.istft(p("enh"), 1, T, None, p("norm"), o_wave, stream=st)
+                ctx.istft(p("enh"), 1, T, None, p("norm"), d_wave[k], stream=st)
         host = b.fetch(n_out)
         out = []
         for k, (T, L) in enumerate(zip(frames, lens)):
             o_wave = off_out[k]
             o_stat = o_wave + al(esz * L)
             o_mask = o_stat + al(4 * n_status)
-            status = np.frombuffer(host[o_stat:o_stat + 4 * n_status], dtype=np.int32).reshape(K, 2, F)
-            self.rank_deficient_bins += int(np.count_nonzero(status[:, 0] == _ffi.NUM_RANKDEF))
-            if _ffi.wpe_failed(status[:, 0]).any() or status[:, 1].any():
+            status = np.frombuffer(host[o_stat:o_stat + 4 * n_status], dtype=np.int32).reshape(K, F)
+            self.rank_deficient_bins += int(np.count_nonzero(wpe_status[:, k] == _ffi.NUM_RANKDEF))
+            if _ffi.wpe_failed(wpe_status[:, k]).any() or status.any():
                 out.append(None)
                 continue
             wave = np.frombuffer(host[o_wave:o_wave + esz * L], dtype=np.int16 if self.pcm16 else np.float32).copy()

@@ -481,6 +481,17 @@ def test_consumers_fixed_beamformer_and_directional_feats(tmp_path):
     for k, (feats_k, code) in zip(("u0", "u1"), res):
         assert code == 0 and feats_k.dtype == np.float32 and feats_k.shape == g[f"{k}.df"].shape
         assert np.max(np.abs(feats_k - g[f"{k}.df"])) < 2e-3
+    # several chunks: two lanes (handles, streams), each driven by its own thread -- the same
+    # features whatever the chunking
+    many = BatchDirectionalFeatures(pairs, chunk_utts=4, **kw)
+    two = [(Pcm16Frames(g["u0.pcm"]), g["u0.mask"]), (Pcm16Frames(g["u1.pcm"]), g["u1.mask"])]
+    ref2 = many.run(two)
+    for rep in range(2):
+        got = many.run(two * 9)
+        assert len(got) == 18
+        for i, (f_i, code) in enumerate(got):
+            assert code == 0 and np.array_equal(f_i, ref2[i % 2][0])
+    many.close()
     # a non-finite sample: numpy's eigh raises LinAlgError in the reference; here a status
     bad = g["u0.pcm"].T.astype(np.float32) / np.float32(32768)
     bad[1, 1000] = np.nan

@@ -107,6 +107,23 @@ def run(utts=16, seconds=10.0):
         sv = B.solve_pevd(B.compute_covar(obs, mask))
         return S.directional_feats(obs, sv.T, df_pair=[(0, 1), (0, 2), (1, 3)])
     res["df_on_mask_4ch_resident"]["per_utterance_numpy_path_incl_stft_ms"] = round(1e3 * timed(df_old, 5), 2)
+    # ---- factorised WPD (apply_wpd.py): resident engine against the per-utterance mirror ----
+    from setk_amd.engine import BatchWpd
+    wpd = BatchWpd(taps=10, delay=3, context=1, wpd_iters=3, cgmm_iters=20, frame_len=512,
+                   frame_hop=256, center=True, pcm16=True)
+    wmix = [Pcm16Frames(np.ascontiguousarray(wavio.float_to_pcm16(
+        synth.synth_utterance(3150 + i, 4, N).T))) for i in range(4)] * 2
+    wpd.run(wmix)
+    dtw = timed(lambda: wpd.run(wmix), 2)
+    dtm = timed(lambda: [wpd._one_by_mirror(u) for u in wmix[:2]], 1) / 2
+    wpd.close()
+    res["wpd_4ch_resident"] = {
+        "workload": f"4-ch {seconds:g} s, 10 taps, 3 outer iterations x 20 CGMM iterations, from 16-bit "
+                    f"frames to PCM_16 samples + speech mask, {len(wmix)} utterances per call "
+                    "(engine.BatchWpd: one scratch block, every stage on device pointers)",
+        "ms_per_utt": round(1e3 * dtw / len(wmix), 2), "value": round(len(wmix) * seconds / dtw, 1),
+        "per_utterance_numpy_mirror_ms": round(1e3 * dtm, 2),
+        "speedup": round(dtm / (dtw / len(wmix)), 2)}
     # ---- unfused engine: n_fft = 400, 12 channels ----
     for label, C, kw in (("mvdr_nfft400_4ch", 4, dict(frame_len=400, frame_hop=160,
                                                       round_power_of_two=False)),
