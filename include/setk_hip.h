@@ -147,6 +147,17 @@ int setk_device_alloc(setk_handle_t h, size_t bytes, void** out);
 int setk_device_free(setk_handle_t h, void* ptr);
 int setk_host_alloc(setk_handle_t h, size_t bytes, void** out);
 int setk_host_free(setk_handle_t h, void* ptr);
+/* The read stage of the command line's pipeline for one batch in one call (no handle: host code
+ * only).  Payload i is nbytes[i] bytes at offsets[i] of the file paths[i] -- a wave file's 16-bit
+ * frames, a mask's float32 rows, exactly as stored -- and is copied to dst[i] (the batch's
+ * page-locked slab) by a process-wide pool of n_threads native threads: a MADV_SEQUENTIAL
+ * mapping + memcpy for payloads of at least mmap_min_bytes, pread below.  status[i]: 0 or the
+ * errno of the failing call (EIO: the file ends inside the payload).  Thread safe; concurrent
+ * calls share the pool.  What the reference has in its place: WaveReader / ScriptReader._load,
+ * one utterance at a time on the interpreter's thread (libs/data_handler.py:345-413). */
+int setk_host_read_payloads(int n, const char* const* paths, const long long* offsets,
+                            const long long* nbytes, void* const* dst, int n_threads,
+                            long long mmap_min_bytes, int* status);
 int setk_stream_create(setk_handle_t h, void** out);
 int setk_stream_destroy(setk_handle_t h, void* stream);
 int setk_stream_synchronize(setk_handle_t h, void* stream);

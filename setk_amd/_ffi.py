@@ -105,7 +105,7 @@ def exported_symbols():
         "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_wpe_batch", "setk_wpe_batch_fnt", "setk_wpe_batch_var", "setk_set_profiling",
         "setk_last_stage_ms",
         "setk_comm_unique_id", "setk_comm_create", "setk_comm_allreduce_f64", "setk_comm_barrier",
-        "setk_comm_destroy", "setk_comm_last_error"
+        "setk_comm_destroy", "setk_comm_last_error", "setk_host_read_payloads"
     ]
 
 
@@ -195,6 +195,9 @@ def load_library():
     lib.setk_wpe_batch.argtypes = [H, c_int, POINTER(c_void_p), c_int, POINTER(c_int), c_int, c_int,
                                    c_int, c_int, c_int, POINTER(c_void_p), fp, c_void_p]
     lib.setk_wpe_batch_fnt.argtypes = lib.setk_wpe_batch.argtypes
+    lib.setk_host_read_payloads.argtypes = [c_int, POINTER(ctypes.c_char_p), POINTER(ctypes.c_longlong),
+                                            POINTER(ctypes.c_longlong), POINTER(c_void_p), c_int,
+                                            ctypes.c_longlong, POINTER(c_int)]
     lib.setk_wpe_batch_var.argtypes = [H, c_int, POINTER(c_void_p), c_int, POINTER(c_int), c_int, c_int,
                                        c_int, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p),
                                        POINTER(c_void_p), fp, c_void_p]
@@ -210,6 +213,25 @@ def load_library():
             fn.restype = c_int
     _lib = lib
     return lib
+
+
+def host_read_payloads(paths, offsets, nbytes, dsts, threads, mmap_min_bytes):
+    """setk_host_read_payloads: payload i = nbytes[i] bytes at offsets[i] of paths[i] -> address
+    dsts[i], by the library's pool of native reader threads.  Returns the list of errno values
+    (0: read).  No handle, no device: the call releases the interpreter lock for the whole batch."""
+    n = len(paths)
+    if not n:
+        return []
+    lib = load_library()
+    P = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    O = (ctypes.c_longlong * n)(*[int(v) for v in offsets])
+    B = (ctypes.c_longlong * n)(*[int(v) for v in nbytes])
+    D = (c_void_p * n)(*[int(v) for v in dsts])
+    S = (c_int * n)()
+    rc = lib.setk_host_read_payloads(n, P, O, B, D, int(threads), int(mmap_min_bytes), S)
+    if rc != 0:
+        raise SetkError(f"setk_host_read_payloads: bad arguments ({rc})")
+    return list(S)
 
 
 def _ptr(x):

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsetk_hip.so")
-SOURCES = ["pass1.hip", "pass1_mc.hip", "pass2.hip", "pass2_mc.hip", "solve.hip", "modular.hip", "cgmm.hip", "cgmm_bin.hip", "cgmm_k.hip", "wpe.hip", "comm.hip", "capi.hip"]
+SOURCES = ["pass1.hip", "pass1_mc.hip", "pass2.hip", "pass2_mc.hip", "solve.hip", "modular.hip", "cgmm.hip", "cgmm_bin.hip", "cgmm_k.hip", "wpe.hip", "comm.hip", "hostio.hip", "capi.hip"]
 HEADERS = ["common.h", "fft512.h", "dpp.h", "covar_fold.h", "mcdft.h", "mcdft_tables.h", os.path.join("..", "..", "include", "setk_hip.h")]
 ARCH = "gfx950"
 

@@ -47,8 +47,10 @@ import numpy as np
 from . import _ffi
 from .libs import wavio
 
-# how a payload gets from the page cache into the page-locked slab: "mmap" (default) or "preadv"
-READ_MODE = os.environ.get("SETK_READ_MODE", "mmap")
+# how a payload gets from the page cache into the page-locked slab: "native" (default: the
+# library's reader pool, one call per batch, setk_host_read_payloads), "mmap" or "preadv" (the
+# interpreter's reader threads, one task per utterance)
+READ_MODE = os.environ.get("SETK_READ_MODE", "native")
 # payloads below this size are read with preadv: an mmap + munmap pair costs ~250 us under load
 # (the unmap's TLB shootdown reaches every CPU the process's threads ran on), as much as copying
 # 2.5 MB (tools/ubench/read_small.py)
@@ -114,7 +116,7 @@ class Payload(object):
             return
         fd = os.open(self.path, os.O_RDONLY)
         try:
-            if READ_MODE == "mmap" and self.nbytes >= MMAP_MIN_BYTES and \
+            if READ_MODE != "preadv" and self.nbytes >= MMAP_MIN_BYTES and \
                     os.fstat(fd).st_size >= self.offset + self.nbytes:  # (a short file: IOError below)
                 # A read() marks every page accessed, and the FIRST access of a page moves it
                 # between the kernel's LRU lists under a shared lock: first reads of fresh
@@ -487,7 +489,10 @@ class StreamPipeline(object):
         out_total = _align(off_power + 8 * n)
         slot = self._get_slot(max(off, ALIGN), max(f32, ALIGN), out_total)
         t0 = time.perf_counter()
-        futs = [self.readers.submit(self._read_job, j, slot) for j in batch]
+        if READ_MODE == "native" and not self.zero_copy:
+            futs = [self.readers.submit(self._read_batch, batch, slot)]
+        else:
+            futs = [self.readers.submit(self._read_job, j, slot) for j in batch]
         self.launch_q.put((batch, slot, futs, off, off_status, off_power, out_total, t0))
 
     # ---- read stage (pool) --------------------------------------------------------
@@ -531,6 +536,50 @@ class StreamPipeline(object):
                 self.stats["staged_payloads"] += n - int(zc)
         except Exception as e:  # reported per utterance by the completer
             job.error = e
+
+    def _read_batch(self, batch, slot):
+        """The read stage of a whole batch: its file payloads in ONE call of the library's reader
+        pool (no interpreter lock between payloads), host arrays copied here."""
+        buf = slot.staging()
+        base = buf.ctypes.data
+        paths, offs, sizes, dsts, owner = [], [], [], [], []
+        arrays = []
+        for j in batch:
+            for p, off in ((j.audio, j.off_audio), (j.mask, j.off_mask),
+                           (j.itf, j.off_itf if j.itf is not None else 0)):
+                if p is None:
+                    continue
+                if p.array is not None:
+                    arrays.append((j, p, off))
+                else:
+                    paths.append(p.path)
+                    offs.append(p.offset)
+                    sizes.append(p.nbytes)
+                    dsts.append(base + off)
+                    owner.append(j)
+        try:
+            status = _ffi.host_read_payloads(paths, offs, sizes, dsts, self.read_threads, MMAP_MIN_BYTES)
+        except Exception as e:
+            for j in batch:
+                j.error = e
+            return
+        for j, path, st in zip(owner, paths, status):
+            if st and j.error is None:
+                j.error = IOError("truncated payload") if st == 5 else OSError(st, os.strerror(st), path)
+        for j, p, off in arrays:
+            try:
+                p.load_into(buf[off:off + p.nbytes])
+            except Exception as e:
+                j.error = e
+        if self.h2d == "payload":
+            for j in batch:
+                if j.error is None:
+                    for p, off in ((j.audio, j.off_audio), (j.mask, j.off_mask),
+                                   (j.itf, j.off_itf if j.itf is not None else 0)):
+                        if p is not None:
+                            self.ctx.memcpy_h2d_async(slot.d_in + off, base + off, p.nbytes, self.s_in)
+        with self.lock:
+            self.stats["staged_payloads"] += len(paths) + len(arrays)
 
     # ---- H2D + kernels + D2H (one thread owns the handle) ---------------------------
     def _launch_loop(self):
@@ -693,6 +742,7 @@ class StreamPipeline(object):
         st = dict(self.stats)
         st["wall_s"] = wall
         st["read_threads"] = self.read_threads
+        st["read_mode"] = "zero_copy" if self.zero_copy else READ_MODE
         st["depth"] = self.depth
         st["batch_utts"] = self.batch_utts
         return self.num_done, st

@@ -509,6 +509,70 @@ def test_payload_reads_by_name_and_holds_no_descriptor(tmp_path):
     assert len(os.listdir("/proc/self/fd")) == before
 
 
+def test_native_reader_pool_reads_what_the_interpreter_reads(built_lib, tmp_path):
+    """setk_host_read_payloads (csrc/hostio.hip): the read stage of a batch in one call -- byte
+    ranges of files into caller memory through the mapping (large payloads) and pread (small
+    ones), per-payload errno, concurrent calls sharing the pool, no descriptor left open."""
+    import errno
+    import threading
+    lib = ctypes.CDLL(built_lib)
+    fn = lib.setk_host_read_payloads
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_longlong),
+                   ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                   ctypes.c_longlong, ctypes.POINTER(ctypes.c_int)]
+    rng = np.random.default_rng(5)
+    blobs, paths = [], []
+    for i in range(24):
+        b = rng.integers(0, 256, size=70_000 + 4099 * i, dtype=np.uint8)
+        q = tmp_path / f"f{i}.bin"
+        q.write_bytes(b.tobytes())
+        blobs.append(b)
+        paths.append(str(q))
+
+    def call(idx, offs, sizes, threads, mmap_min):
+        n = len(idx)
+        dst = [np.full(max(sz, 1), 0xAB, dtype=np.uint8) for sz in sizes]
+        P = (ctypes.c_char_p * n)(*[os.fsencode(paths[i]) if i >= 0 else b"/nonexistent/x.bin" for i in idx])
+        O = (ctypes.c_longlong * n)(*offs)
+        B = (ctypes.c_longlong * n)(*sizes)
+        D = (ctypes.c_void_p * n)(*[d.ctypes.data for d in dst])
+        S = (ctypes.c_int * n)(*([77] * n))
+        assert fn(n, P, O, B, D, threads, mmap_min, S) == 0
+        return dst, list(S)
+
+    before = len(os.listdir("/proc/self/fd"))
+    for mmap_min in (1, 1 << 40):  # everything through the mapping / everything through pread
+        idx = list(range(24))
+        offs = [37 * i + (4096 if i % 3 == 0 else 0) for i in idx]   # page-aligned and odd offsets
+        sizes = [len(blobs[i]) - offs[i] - (i % 5) for i in idx]
+        dst, st = call(idx, offs, sizes, 5, mmap_min)
+        assert st == [0] * 24
+        for i in idx:
+            assert np.array_equal(dst[i], blobs[i][offs[i]:offs[i] + sizes[i]]), (mmap_min, i)
+        # a missing file, a payload that runs past the end of its file, an empty payload
+        dst, st = call([-1, 0, 1, 2], [0, 60_000, 0, 10], [100, 20_000, 0, 50], 3, mmap_min)
+        assert st[0] == errno.ENOENT and st[1] == errno.EIO and st[2] == 0 and st[3] == 0
+        assert np.array_equal(dst[3], blobs[2][10:60])
+    # concurrent calls share the pool
+    results = {}
+
+    def worker(k):
+        idx = [(k + 3 * r) % 24 for r in range(16)]
+        dst, st = call(idx, [k] * 16, [50_000] * 16, 4, 1)
+        results[k] = st == [0] * 16 and all(np.array_equal(d, blobs[i][k:k + 50_000]) for d, i in zip(dst, idx))
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert results == {k: True for k in range(6)}
+    assert len(os.listdir("/proc/self/fd")) == before
+    # argument checks: nothing is read
+    assert fn(-1, None, None, None, None, 1, 0, None) != 0
+    assert fn(0, None, None, None, None, 1, 0, None) == 0
+
+
 # ---------------------------------------------------------------------------
 # the solve of the bin-resident CGMM, as a numpy model (tests/jacobi_model.py)
 # ---------------------------------------------------------------------------

@@ -18,7 +18,7 @@ fi
 mkdir -p "$OUT"
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 pids=""
-for u in pass1 pass1_mc pass2 pass2_mc solve modular cgmm cgmm_bin cgmm_k wpe comm capi; do
+for u in pass1 pass1_mc pass2 pass2_mc solve modular cgmm cgmm_bin cgmm_k wpe comm hostio capi; do
   src="$ROOT/setk_amd/csrc/$u.hip"
   if [ ! -f "$OUT/$u.o" ] || [ "$src" -nt "$OUT/$u.o" ] || [ -n "$(find "$ROOT/setk_amd/csrc" "$ROOT/include" -name '*.h' -newer "$OUT/$u.o")" ]; then
     /opt/rocm/bin/hipcc --cuda-host-only --offload-arch=gfx950 -O1 -std=c++17 -fPIC -Wno-unused-result $SAN \

@@ -11,7 +11,7 @@ ILP="-mllvm -amdgpu-sched-strategy=max-ilp"; [ -n "$NOILP" ] && ILP=""; [ -n "$S
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-slp-vectorize $ILP \
   -Wno-unused-result "$@" -c "$ROOT/setk_amd/csrc/$UNIT.hip" -o "$ROOT/_abl/${UNIT}_$NAME.o"
 OBJS=""
-for u in pass1 pass1_mc pass2 pass2_mc solve modular cgmm cgmm_bin cgmm_k wpe comm capi; do
+for u in pass1 pass1_mc pass2 pass2_mc solve modular cgmm cgmm_bin cgmm_k wpe comm hostio capi; do
   if [ "$u" = "$UNIT" ]; then OBJS="$OBJS $ROOT/_abl/${UNIT}_$NAME.o"; else OBJS="$OBJS $ROOT/setk_amd/csrc/_obj/$u.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/_abl/libsetk_$NAME.so" $OBJS

@@ -45,7 +45,27 @@ def _slab(nbytes):
     return view
 
 
+def run_native(nt, per_call=64):
+    """the library's reader pool (setk_host_read_payloads): calls of `per_call` payloads, as the
+    pipeline issues them per batch"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from setk_amd import _ffi
+    _ffi.set_torch_free()
+    slab = _slab(per_call * SZ)
+    base = slab.ctypes.data
+    t0 = time.perf_counter()
+    for i0 in range(0, N, per_call):
+        idx = range(i0, min(N, i0 + per_call))
+        st = _ffi.host_read_payloads([f"{D}/{i}.bin" for i in idx], [0] * len(idx), [SZ] * len(idx),
+                                     [base + k * SZ for k in range(len(idx))], nt, 256 << 10)
+        assert not any(st), st
+    dt = time.perf_counter() - t0
+    return N * SZ / dt / 1e9, 1e6 * dt * nt / N
+
+
 def run(nt, mode):
+    if mode == "native":
+        return run_native(nt)
     slab = _slab(nt * SZ)
 
     def work(k):
@@ -79,7 +99,7 @@ def main():
     print(f"# {N} files of {SZ} bytes in /dev/shm; GB/s aggregate (us per file per thread); destination: "
           f"{'page-locked (setk_host_alloc)' if PINNED else 'numpy'}")
     try:
-        for mode in (("mmap_seq",) if PINNED else ("preadv", "mmap_seq", "mmap_populate")):
+        for mode in (("mmap_seq", "native") if PINNED else ("preadv", "mmap_seq", "mmap_populate", "native")):
             for nt in (6, 12, 24):
                 make()
                 a, ua = run(nt, mode)
