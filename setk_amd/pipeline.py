@@ -11,9 +11,13 @@ side is organised as a pipeline with every stage overlapped:
 
   plan      (caller's thread)  wave / mask headers only: channels, samples, frames,
                                payload offsets -> byte offsets inside a slab
-  read+H2D  (thread pool,      os.preadv of the payload into the slot's page-locked slab --
-             copy-in stream)   the wav's 16-bit frames and the mask's float32 rows exactly as
-                               stored, no host conversion -- and an async copy of that slice.
+  read+H2D  (library's reader  every file payload of the batch into the slot's page-locked slab --
+             pool, copy-in     the wav's 16-bit frames and the mask's float32 rows exactly as
+             stream)           stored, no host conversion -- by ONE call of setk_host_read_payloads
+                               (native threads: a MADV_SEQUENTIAL mapping + memcpy per payload, no
+                               interpreter lock in between; SETK_READ_MODE=mmap | preadv: the
+                               interpreter's thread pool, one task per utterance), then one async
+                               copy of the slab (or of each payload's slice).
                                Option zero_copy: mmap the file, pin its page-cache pages
                                (hipHostRegister) and DMA from where they lie; alone that is
                                0.23 ms + 52 GB/s per 7.7 MB file, inside the pipeline it
