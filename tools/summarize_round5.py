@@ -53,11 +53,13 @@ for k, v in oc.items():
 out.append(f"* full_batch: {d.get('full_batch')}")
 e = d.get("end_to_end", {})
 out.append(f"* end_to_end: marginal {e.get('marginal_ms_per_utt')} ms per utterance, {e.get('marginal_GBps_in')} GB/s of input")
+cu = oc.get("consumers_and_unfused", {})
+for k in ("df_on_mask_4ch_resident", "wpd_4ch_resident"):
+    if k in cu:
+        out.append(f"* {k}: " + str({kk: vv for kk, vv in cu[k].items() if kk != "workload"}))
 open(os.path.join(DST, "round5_summary.md"), "w").write("\n".join(out) + "\n")
 for src, dst in (("error_budget.txt", "round5_error_budget.txt"), ("e2e_p1_sweep.txt", "round5_e2e_p1_sweep.txt")):
     shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
-with open(os.path.join(DST, "round5_read_small.txt"), "w") as f:
-    for n in ("read_small_2p5MB.txt", "read_small_0p6MB.txt"):
-        f.write(open(os.path.join(SRC, n)).read())
+# (round5_read_small.txt was assembled by hand from three runs: numpy / page-locked destination)
 shutil.copy(os.path.join(ROOT, "gpurun_out", "stall_r5b", "summary.md"), os.path.join(DST, "round5_stall_table.md"))
 print(open(os.path.join(DST, "round5_summary.md")).read())
