@@ -85,6 +85,34 @@ def test_wpe_batch_equals_single_calls():
         assert wide[k].dtype == np.complex128 and np.array_equal(wide[k], single), k
 
 
+def test_wpe_batch_var_equals_single_calls():
+    """setk_wpe_batch_var (the WPE step of facted_wpd for a batch: per-utterance variances of a
+    previous enhanced signal in, 1 / lambda out, libs/wpe.py:146-162) == setk_wpe one utterance at
+    a time, bit for bit; without variances it is setk_wpe_batch."""
+    from setk_amd import _ffi
+    ctx = _ffi.default_context()
+    rng = np.random.default_rng(11)
+    C, F, frames = 3, 257, (90, 61, 140)
+    specs = [(rng.standard_normal((C, T, F)) + 1j * rng.standard_normal((C, T, F))).astype(np.complex64)
+             for T in frames]
+    enh = [(rng.standard_normal((T, F)) + 1j * rng.standard_normal((T, F))).astype(np.complex64) for T in frames]
+    for use_enh in (True, False):
+        outs = [np.empty_like(x) for x in specs]
+        invs = [np.empty((T, F), np.float32) for T in frames]
+        status = np.full((len(frames), F), -1, np.int32)
+        ctx.wpe_batch_var(specs, C, frames, F, 5, 2, 1, 1, outs, lambda_enh=enh if use_enh else None,
+                          inv_lambda_outs=invs, status=status)
+        assert not status.any()
+        for k, T in enumerate(frames):
+            one, inv1, st1 = np.empty_like(specs[k]), np.empty((T, F), np.float32), np.full(F, -1, np.int32)
+            ctx.wpe(specs[k], C, T, F, 5, 2, 1, 1, one, lambda_enh=enh[k] if use_enh else None,
+                    inv_lambda_out=inv1, status=st1)
+            assert not st1.any() and np.array_equal(outs[k], one) and np.array_equal(invs[k], inv1), (use_enh, k)
+    plain = [np.empty_like(x) for x in specs]
+    ctx.wpe_batch(specs, C, frames, F, 5, 2, 1, 1, plain)
+    assert all(np.array_equal(a, b) for a, b in zip(plain, outs))
+
+
 def test_wpe_beyond_256_tap_rows_is_refused():
     from setk_amd import _ffi
     from setk_amd.libs import wpe as W

@@ -57,7 +57,8 @@ def run_native(nt, per_call=64):
     for i0 in range(0, N, per_call):
         idx = range(i0, min(N, i0 + per_call))
         st = _ffi.host_read_payloads([f"{D}/{i}.bin" for i in idx], [0] * len(idx), [SZ] * len(idx),
-                                     [base + k * SZ for k in range(len(idx))], nt, 256 << 10)
+                                     [base + k * SZ for k in range(len(idx))], nt,
+                                     int(os.environ.get("READ_SMALL_MMAP_MIN_KB", "256")) << 10)
         assert not any(st), st
     dt = time.perf_counter() - t0
     return N * SZ / dt / 1e9, 1e6 * dt * nt / N
