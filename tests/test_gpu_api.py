@@ -595,10 +595,11 @@ def test_streaming_pipeline_equals_batch_path(tmp_path):
                                                 gauge=True)
     script = os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py")
 
-    def run(dst, fmt, mask_scp, *extra):
+    def run(dst, fmt, mask_scp, *extra, env=None):
         r = subprocess.run([sys.executable, script, "--mask-format", fmt, "--batch-utts", "3",
                             *extra, f"{td}/wav.scp", mask_scp, dst],
-                           capture_output=True, text=True, timeout=600)
+                           capture_output=True, text=True, timeout=600,
+                           env=None if env is None else dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-3000:]
         assert "Processed 8 utterances out of 9" in r.stderr
         assert r.stderr.count("Processing utterance") == 8
@@ -609,14 +610,22 @@ def test_streaming_pipeline_equals_batch_path(tmp_path):
     c = run(f"{td}/kaldi", "kaldi", f"{td}/ark.scp")
     d = run(f"{td}/zc", "numpy", f"{td}/mask.scp", "--zero-copy", "true", "--profile",
             f"{td}/prof_zc.json")
+    # the read stage's other forms (the default is the library's native reader pool, one call per
+    # batch): the interpreter's reader threads with a mapping (rounds 3 - 4) or preadv, and the
+    # native pool with every payload above its mapping threshold / per-payload copies up
+    e = run(f"{td}/mm", "numpy", f"{td}/mask.scp", env={"SETK_READ_MODE": "mmap"})
+    f = run(f"{td}/pr", "numpy", f"{td}/mask.scp", env={"SETK_READ_MODE": "preadv"})
+    g = run(f"{td}/nm", "numpy", f"{td}/mask.scp", "--h2d", "payload", env={"SETK_MMAP_MIN_KB": "4"})
     assert not os.path.exists(f"{td}/pipe/utt8.wav")
     for k, ref in refs.items():
         assert a[k].dtype == np.int16 and np.array_equal(a[k], b[k]), k
         assert np.array_equal(a[k], c[k]) and np.array_equal(a[k], d[k]), k
+        assert np.array_equal(a[k], e[k]) and np.array_equal(a[k], f[k]) and np.array_equal(a[k], g[k]), k
         assert pcm16_rel_rms(a[k], ref) < 1e-3, (k, pcm16_rel_rms(a[k], ref))
     import json
     prof = json.load(open(f"{td}/prof.json"))
     assert prof["mode"] == "pipeline" and prof["utts"] == 8 and prof["stages"]["batches"] >= 3
+    assert prof["stages"]["read_mode"] == "native"
     # --zero-copy: PCM16 wavs and float32 C-ordered masks leave the page cache without a host copy
     assert json.load(open(f"{td}/prof_zc.json"))["stages"]["zero_copy_payloads"] >= 8
     assert prof["stages"]["zero_copy_payloads"] == 0
