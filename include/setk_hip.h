@@ -310,6 +310,15 @@ int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int nu
 int setk_cgmm_masks_k(setk_handle_t h, const float* spec, int num_channels, int num_frames,
                       int num_bins, int num_classes, int num_iters, const double* gamma0,
                       const float* init_mask, float* gamma_out, int flags, void* stream);
+/* The same, reporting per bin what the reference's np.linalg.eigh would have refused
+ * (cluster.py:104-113, uncaught by estimate_cgmm_masks.py: its run ends with LinAlgError):
+ * status[F] (host or device, may be NULL) receives the worst SETK_NUM_* over classes and
+ * iterations -- SETK_NUM_NONFINITE for a covariance with NaN / inf, SETK_NUM_NOCONV when the
+ * Jacobi sweep limit was reached.  The posteriors are written either way. */
+int setk_cgmm_masks_k_status(setk_handle_t h, const float* spec, int num_channels, int num_frames,
+                             int num_bins, int num_classes, int num_iters, const double* gamma0,
+                             const float* init_mask, float* gamma_out, int flags, int* status,
+                             void* stream);
 
 /* Batched form: n_utts utterances per EM stage launch (device pointers only;
  * spec[u] = [C][num_frames[u]][spec_pitch] (0 = F), mask_out[u] = [num_frames[u]][F],

@@ -99,7 +99,7 @@ def exported_symbols():
         "setk_host_register", "setk_host_unregister", "setk_memcpy_h2d_async",
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_stft_batch", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
-        "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_pcm16_channel_stride", "setk_pcm16_deinterleave_batch", "setk_float_to_pcm16", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks", "setk_cgmm_masks_k",
+        "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_pcm16_channel_stride", "setk_pcm16_deinterleave_batch", "setk_float_to_pcm16", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks", "setk_cgmm_masks_k", "setk_cgmm_masks_k_status",
         "setk_cgmm_masks_batch", "setk_cgmm_estimate_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
         "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_wpe_batch", "setk_wpe_batch_fnt", "setk_wpe_batch_var", "setk_set_profiling",
@@ -176,6 +176,8 @@ def load_library():
     lib.setk_beamform.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, c_void_p]
     lib.setk_cgmm_masks.argtypes = [H, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, c_void_p]
     lib.setk_cgmm_masks_k.argtypes = [H, fp, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, c_void_p]
+    lib.setk_cgmm_masks_k_status.argtypes = [H, fp, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, fp,
+                                             c_void_p]
     lib.setk_cgmm_masks_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int), c_int,
                                           c_int, POINTER(c_void_p), POINTER(c_void_p), c_int,
                                           c_int, c_void_p]
@@ -515,15 +517,16 @@ class Context:
                                       current_stream_ptr() if stream is None else stream))
 
     def cgmm_masks_k(self, spec, C, T, F, K, num_iters, gamma0, init_mask, gamma_out, stream=None,
-                     update_alpha=False):
+                     update_alpha=False, status=None):
         """General CGMM (K <= 4 classes, C <= 16 channels): spec [C][T][F] complex64, gamma0
         [K][F][T] float64 or None (K = 2: init_mask [T][F] or the deterministic start),
-        gamma_out [K][T][F] float32."""
+        gamma_out [K][T][F] float32; status int32[F] (numpy or device address) or None: SETK_NUM_*
+        per bin (non-finite covariance, Jacobi sweep limit -- numpy.linalg.eigh's LinAlgError)."""
         self.check(
-            self._lib.setk_cgmm_masks_k(self._h, _ptr(spec), int(C), int(T), int(F), int(K),
-                                        int(num_iters), _ptr(gamma0), _ptr(init_mask), _ptr(gamma_out),
-                                        CGMM_UPDATE_ALPHA if update_alpha else 0,
-                                        current_stream_ptr() if stream is None else stream))
+            self._lib.setk_cgmm_masks_k_status(self._h, _ptr(spec), int(C), int(T), int(F), int(K),
+                                               int(num_iters), _ptr(gamma0), _ptr(init_mask),
+                                               _ptr(gamma_out), CGMM_UPDATE_ALPHA if update_alpha else 0,
+                                               _ptr(status), current_stream_ptr() if stream is None else stream))
 
     def cgmm_masks_batch(self, C, spec_ptrs, num_frames, F, num_iters, init_ptrs, out_ptrs,
                          stream=None, update_alpha=False, spec_pitch=0):

@@ -1574,6 +1574,14 @@ int setk_cgmm_masks(setk_handle_t h, const float* spec, int num_channels, int nu
 int setk_cgmm_masks_k(setk_handle_t h, const float* spec, int num_channels, int num_frames,
                       int num_bins, int num_classes, int num_iters, const double* gamma0,
                       const float* init_mask, float* gamma_out, int flags, void* stream) {
+    return setk_cgmm_masks_k_status(h, spec, num_channels, num_frames, num_bins, num_classes, num_iters,
+                                    gamma0, init_mask, gamma_out, flags, nullptr, stream);
+}
+
+int setk_cgmm_masks_k_status(setk_handle_t h, const float* spec, int num_channels, int num_frames,
+                             int num_bins, int num_classes, int num_iters, const double* gamma0,
+                             const float* init_mask, float* gamma_out, int flags, int* status,
+                             void* stream) {
     if (!h || !spec || !gamma_out || num_frames <= 0 || num_bins <= 0 || num_iters < 0)
         return fail(h, SETK_ERR_INVALID, "bad args");
     const int C = num_channels, T = num_frames, F = num_bins, K = num_classes;
@@ -1598,11 +1606,22 @@ int setk_cgmm_masks_k(setk_handle_t h, const float* spec, int num_channels, int 
     if (rc) return rc;
     double* d_work = static_cast<double*>(arena_alloc(h, cgmm_k_work_bytes(K, T, F)));
     if (!d_work) return fail(h, SETK_ERR_NOMEM, "arena");
+    OutBuf os;
+    if (status) {
+        rc = stage_out(h, status, (size_t)F * sizeof(int), &os);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemsetAsync(os.dev, 0, (size_t)F * sizeof(int), s));
+    }
     HIP_TRY(h, launch_cgmm_k(d_spec, reinterpret_cast<const double*>(d_g0f), d_init, static_cast<float*>(og.dev),
-                             d_work, C, T, F, K, num_iters, (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0, s));
+                             d_work, status ? static_cast<int*>(os.dev) : nullptr, C, T, F, K, num_iters,
+                             (flags & SETK_CGMM_UPDATE_ALPHA) ? 1 : 0, s));
     rc = copy_back(h, og, s);
     if (rc) return rc;
-    if (og.host) HIP_TRY(h, hipStreamSynchronize(s));
+    if (status) {
+        rc = copy_back(h, os, s);
+        if (rc) return rc;
+    }
+    if (og.host || (status && os.host)) HIP_TRY(h, hipStreamSynchronize(s));
     return SETK_OK;
 }
 

@@ -39,9 +39,19 @@ __device__ __forceinline__ zc zmk(double a, double b) { return zc{a, b}; }
 //   U = [[c, s e], [-s conj(e), c]],  A <- U^H A U,  V <- V U
 // (checked against numpy.linalg.eigh in the form of /tmp's numpy twin: eigenvalues 5e-15,
 // residual 3e-15 at n = 16).
-__device__ void jacobi_herm(zc* A, zc* V, int n) {
+// Returns false when the sweep limit was reached with rotations still pending.
+__device__ bool jacobi_herm(zc* A, zc* V, int n) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) V[i * n + j] = zmk(i == j ? 1.0 : 0.0, 0.0);
+    // an off-diagonal entry below the rounding level of the matrix is left alone: a rotation
+    // cannot make it smaller (its own arithmetic errs by ~eps trace), and a rank-deficient
+    // covariance -- more channels than sources: a_pp a_qq ~ 0 -- would otherwise rotate through all
+    // 60 sweeps at that level, in 220 of 257 bins of a 9-channel scene.  This is LAPACK's accuracy
+    // class too (absolute in the norm of the matrix); eigenvalues down there are floored at
+    // eps_float32 lambda_max afterwards (cluster.py:107-113)
+    double tr = 0.0;
+    for (int i = 0; i < n; ++i) tr += fabs(A[i * n + i].x);
+    const double abs2 = 1.6e-31 * tr * tr;  // (4e-16 trace)^2
     for (int sweep = 0; sweep < 60; ++sweep) {
         bool rot = false;
         for (int p = 0; p < n - 1; ++p)
@@ -49,7 +59,7 @@ __device__ void jacobi_herm(zc* A, zc* V, int n) {
                 const zc apq = A[p * n + q];
                 const double g2 = apq.x * apq.x + apq.y * apq.y;
                 const double app = A[p * n + p].x, aqq = A[q * n + q].x;
-                if (!(g2 > 1e-34 * fabs(app * aqq)) || g2 == 0.0) continue;
+                if (!(g2 > 1e-34 * fabs(app * aqq)) || !(g2 > abs2) || g2 == 0.0) continue;
                 rot = true;
                 const double g = sqrt(g2);
                 const double ex = apq.x / g, ey = apq.y / g;
@@ -73,8 +83,9 @@ __device__ void jacobi_herm(zc* A, zc* V, int n) {
                     A[q * n + j] = zmk((sx * rp.x + sy * rp.y) + c * rq.x, (sx * rp.y - sy * rp.x) + c * rq.y);
                 }
             }
-        if (!rot) break;
+        if (!rot) return true;
     }
+    return false;
 }
 
 struct CgmmKArgs {
@@ -83,6 +94,7 @@ struct CgmmKArgs {
     const float* init_mask;   // [T][F] (K = 2) or null
     float* gamma_out;         // [K][T][F]
     double* work;             // [F][2][K][T]: gamma | phi of the previous E-step
+    int* status;              // [F] SETK_NUM_* (worst over classes and iterations) or null
     int C, T, F, K, num_iters, update_alpha;
 };
 
@@ -193,9 +205,17 @@ __global__ __launch_bounds__(256) void cgmm_k_kernel(CgmmKArgs a) {
         if (tid < K) {
             zc* A = Ak + tid * C * C;
             zc* V = Vk + tid * C * C;
-            jacobi_herm(A, V, C);
+            const bool conv = jacobi_herm(A, V, C);
             double wmax = -1e300;
-            for (int i = 0; i < C; ++i) wmax = fmax(wmax, A[i * C + i].x);
+            bool finite = true;
+            for (int i = 0; i < C; ++i) {
+                wmax = fmax(wmax, A[i * C + i].x);
+                finite = finite && isfinite(A[i * C + i].x);
+            }
+            // numpy.linalg.eigh raises on these (cluster.py:104-113: "Eigenvalues did not converge");
+            // the posteriors go on being computed, the status says what they are worth
+            if (a.status && !(conv && finite))
+                atomicMax(a.status + f, finite ? SETK_NUM_NOCONV : SETK_NUM_NONFINITE);
             const double sc = fmax(wmax, kEpsK);
             double ld = 0.0;
             for (int i = 0; i < C; ++i) {
@@ -250,14 +270,15 @@ size_t cgmm_k_work_bytes(int K, int T, int F) { return (size_t)F * 2 * K * T * s
 bool cgmm_k_supported(int C, int K) { return C >= 1 && C <= kCMax && K >= 2 && K <= kKMax; }
 
 hipError_t launch_cgmm_k(const float* spec, const double* gamma0, const float* init_mask, float* gamma_out,
-                         double* work, int C, int T, int F, int K, int num_iters, int update_alpha,
-                         hipStream_t s) {
+                         double* work, int* status, int C, int T, int F, int K, int num_iters,
+                         int update_alpha, hipStream_t s) {
     CgmmKArgs a;
     a.spec = reinterpret_cast<const cf*>(spec);
     a.gamma0 = gamma0;
     a.init_mask = init_mask;
     a.gamma_out = gamma_out;
     a.work = work;
+    a.status = status;
     a.C = C;
     a.T = T;
     a.F = F;

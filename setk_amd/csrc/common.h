@@ -202,8 +202,8 @@ hipError_t launch_cgmm_batch(int C, const void* d_tbl, int n_utts, int F, int ma
 size_t cgmm_k_work_bytes(int K, int T, int F);
 bool cgmm_k_supported(int C, int K);
 hipError_t launch_cgmm_k(const float* spec, const double* gamma0, const float* init_mask, float* gamma_out,
-                         double* work, int C, int T, int F, int K, int num_iters, int update_alpha,
-                         hipStream_t s);
+                         double* work, int* status, int C, int T, int F, int K, int num_iters,
+                         int update_alpha, hipStream_t s);
 // bin-resident EM (cgmm_bin.hip)
 size_t cgmm_bin_args_bytes();
 int cgmm_bin_pitch(int T);

@@ -79,12 +79,18 @@ class CgmmTrainer(object):
             ctx.cgmm_masks(self.spec, M, T, F, num_iters, self.init, gamma, mask,
                            update_alpha=self.update_alpha)
         else:
+            status = np.zeros(F, dtype=np.int32)
             ctx.cgmm_masks_k(self.spec, M, T, F, K, num_iters, self.gamma0, self.init, gamma,
-                             update_alpha=self.update_alpha)
+                             update_alpha=self.update_alpha, status=status)
+            if status.any():
+                # what np.linalg.eigh refuses (cluster.py:104-113): a covariance with NaN / inf, or
+                # an eigendecomposition that did not converge
+                raise np.linalg.LinAlgError(f"Eigenvalues did not converge ({int(np.count_nonzero(status))} "
+                                            "frequency bins)")
         if not np.isfinite(gamma).all():
             # the reference's np.linalg.eigh raises on a covariance with NaN / inf
-            # (cluster.py:104-113) -- non-finite samples, or a model that broke down; the device
-            # EM has no status word for it, its posteriors say it
+            # (cluster.py:104-113) -- a model that broke down; the tuned K = 2 EM has no status
+            # word for it, its posteriors say it
             bad = int(np.count_nonzero(~np.isfinite(gamma).all(axis=(0, 1))))
             raise np.linalg.LinAlgError(f"Eigenvalues did not converge ({bad} frequency bins with "
                                         "non-finite posteriors)")

@@ -337,14 +337,31 @@ def test_cgmm_k_classes_match_oracle(K, C, N, iters, ua):
 
 def test_cgmm_non_finite_input_raises_like_the_reference():
     """A NaN in the spectrogram: the reference's np.linalg.eigh raises LinAlgError on the
-    covariance (cluster.py:104-113, uncaught by estimate_cgmm_masks.py: the run ends).  The
-    general device EM has no status word; CgmmTrainer reads it off the posteriors."""
+    covariance (cluster.py:104-113, uncaught by estimate_cgmm_masks.py: the run ends).
+    CgmmTrainer checks the samples; below it the general device EM reports the bin
+    (setk_cgmm_masks_k_status: SETK_NUM_NONFINITE where the reference's eigh would raise)."""
+    from setk_amd import _ffi
     from setk_amd.libs.cluster import CgmmTrainer
     obs = o.multichannel_stft(o.synth_scene(311, 4, 12000), transpose=False, **STFT_KW).copy()
+    clean = obs.copy()
     obs[1, 40, 7] = np.nan
     np.random.seed(777)
     with pytest.raises(np.linalg.LinAlgError):
         CgmmTrainer(obs, 3).train(3)
+    # the C ABI itself: a status word per bin, only bin 40 is flagged
+    ctx = _ffi.default_context()
+    M, F, T = obs.shape
+    K = 3
+    g0 = np.random.default_rng(1).uniform(size=(K, F, T))
+    g0 /= g0.sum(0, keepdims=True)
+    for arr, want in ((obs, {40}), (clean, set())):
+        spec = np.ascontiguousarray(np.transpose(arr, (0, 2, 1)), dtype=np.complex64)
+        gamma = np.empty((K, T, F), np.float32)
+        status = np.full(F, -1, np.int32)
+        ctx.cgmm_masks_k(spec, M, T, F, K, 3, np.ascontiguousarray(g0), None, gamma, status=status)
+        assert set(np.flatnonzero(status)) == want
+        assert all(status[f] == _ffi.NUM_NONFINITE for f in want)
+        assert np.isfinite(gamma[:, :, [f for f in range(F) if f not in want]]).all()
 
 
 @pytest.mark.parametrize("C", [9, 12, 16])
