@@ -79,7 +79,7 @@ def parse():
                     help="N=1 only: also time BASELINE configs[1], [3] and [4] (short runs) and "
                          "report them in `other_configs` (0 = skip)")
     ap.add_argument("--e2e-utts", type=int, default=192,
-                    help="N=1 only: utterances of the end-to-end CLI leg (0 = skip)")
+                    help="N=1 only: utterances of the end-to-end CLI leg: runs of n and 8 n (0 = skip)")
     ap.add_argument("--pmc", type=int, default=1,
                     help="N=1 only: collect HBM traffic and VALU instruction counts of the two "
                          "streaming kernels IN THIS RUN by re-running three timed steps under "
@@ -1109,7 +1109,7 @@ def host_copy_rate(threads=(1, 8), nbytes=64 << 20, reps=4):
 def end_to_end(args, C, N):
     """disk -> wav through the drop-in CLI (scripts/sptk/apply_adaptive_beamformer.py),
     PCM16 wav + numpy masks in, PCM16 wav out, on files written to /dev/shm (or
-    TMPDIR).  Two runs (n and 4n utterances) give the marginal cost per utterance;
+    TMPDIR).  Two runs (n and 8n utterances) give the marginal cost per utterance;
     each run reports two wall clocks: the whole process (python + torch import +
     plan + pinned pools) and the CLI's own clock from its first scp read to the
     last wav close."""
@@ -1119,7 +1119,9 @@ def end_to_end(args, C, N):
     from setk_amd import synth
     from setk_amd.libs import wavio
     n1 = args.e2e_utts
-    n2 = 4 * n1
+    # (8 x: the difference of two process clocks carries ~0.1 s of start-up noise; at 4 x the
+    #  marginal rate came out anywhere between 21 and 43 GB/s on the same build)
+    n2 = 8 * n1
     T = 1 + N // 256
     need = n2 * (2 * C * N + 4 * T * 257 + 2 * N) * 1.1
     base = None

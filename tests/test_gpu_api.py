@@ -326,7 +326,7 @@ def test_bench_contract_single_and_two_ranks():
     assert "2 C N" in i16["roofline"]["algorithmic_bytes"]
     assert one["uncached_call"]["ms_per_step"] > 0
     e2e = one["end_to_end"]
-    assert [r_["written"] for r_ in e2e["runs"]] == [6, 24] and "marginal_ms_per_utt" in e2e
+    assert [r_["written"] for r_ in e2e["runs"]] == [6, 48] and "marginal_ms_per_utt" in e2e
     assert e2e["host_copy_GBps"]["1"] > 0
 
     env = dict(os.environ, SETK_BENCH_SHARE_GPU="1", SETK_BENCH_BACKEND="gloo")
