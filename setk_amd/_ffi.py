@@ -88,6 +88,17 @@ def import_torch(what="this path"):
     return torch
 
 
+def env_atoi(name, default):
+    """An integer environment switch as the library's C side parses it (atoi: optional sign and
+    leading digits, anything else is 0); `default` when the variable is unset."""
+    import re
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    m = re.match(r"\s*([+-]?\d+)", v)
+    return int(m.group(1)) if m else 0
+
+
 def exported_symbols():
     """Names declared in include/setk_hip.h (checked by the CPU test-suite)."""
     return [

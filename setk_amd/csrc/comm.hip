@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -45,14 +46,25 @@ int fail(const std::string& what) {
 
 bool load_rccl() {
     if (g_rccl.so) return true;
+    // SETK_RCCL_LIB names the library instead (a deployment with its own build; the tests point it
+    // at a missing file to exercise the callers' TCP fallback)
+    const char* forced = getenv("SETK_RCCL_LIB");
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* so = nullptr;
-    for (const char* n : names) {
-        so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (so) break;
+    std::string why;
+    if (forced && *forced) {
+        so = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!so) { const char* e = dlerror(); why = e ? e : "?"; }   // (dlerror() clears on read: once)
+    } else {
+        for (const char* n : names) {
+            so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (so) break;
+            const char* e = dlerror();
+            why = e ? e : "?";
+        }
     }
     if (!so) {
-        g_err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+        g_err = "librccl not found: " + why;
         return false;
     }
     Rccl r;

@@ -15,12 +15,18 @@
 // out of it (a read() marks every page accessed and moves fresh pages between the kernel's LRU
 // lists under a shared lock: 15 - 19 GB/s however many threads), preadv for small payloads (a
 // map / unmap pair costs a TLB shootdown).
+//
+// A mapped file that another process TRUNCATES between the fstat and the copy raises SIGBUS in
+// the copying thread (the pread form reports EIO for the same race).  Inputs that can shrink
+// while they are read (network or scratch file systems with concurrent writers) should run with
+// mmap_min_bytes above every payload (command line: SETK_READ_MODE=preadv).
 #include <atomic>
 #include <cerrno>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -113,12 +119,18 @@ struct Pool {
         }
     }
 
-    void grow(int want) {
+    // Returns the number of live workers (0: none could be started -- the caller reads inline).
+    int grow(int want) {
         std::lock_guard<std::mutex> g(m);
         while (threads < want) {
-            std::thread(&Pool::worker, this).detach();
+            try {
+                std::thread(&Pool::worker, this).detach();
+            } catch (const std::system_error&) {  // thread limit of the process / cgroup reached
+                break;                            // (nothing may cross the extern "C" boundary)
+            }
             ++threads;
         }
+        return threads;
     }
 
     void run(ReadBatch& b) {
@@ -132,8 +144,19 @@ struct Pool {
     }
 };
 
+// One pool per PROCESS: a fork()ed child inherits the counters of its parent's pool but none of
+// its threads, so it builds its own (the parent's object is left alone: its mutex may have been
+// held at the moment of the fork).
 Pool& pool() {
-    static Pool* p = new Pool;
+    static std::mutex guard;
+    static Pool* p = nullptr;
+    static pid_t owner = 0;
+    std::lock_guard<std::mutex> g(guard);
+    const pid_t me = getpid();
+    if (!p || owner != me) {
+        p = new Pool;
+        owner = me;
+    }
     return *p;
 }
 
@@ -159,7 +182,10 @@ extern "C" int setk_host_read_payloads(int n, const char* const* paths, const lo
     b.status = status;
     b.left.store(n);
     Pool& p = pool();
-    p.grow(n_threads);
+    if (p.grow(n_threads) < 1) {
+        for (int i = 0; i < n; ++i) status[i] = read_one(paths[i], offsets[i], nbytes[i], dst[i], mmap_min_bytes);
+        return SETK_OK;
+    }
     p.run(b);
     return SETK_OK;
 }

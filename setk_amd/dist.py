@@ -37,12 +37,22 @@ def _recv_exact(sock, n):
     return buf
 
 
+_MAGIC = b"SETK"
+
+
 class _Star(object):
     """Rank 0 listens on MASTER_ADDR:MASTER_PORT, ranks 1..W-1 connect (with retries while the
     listener comes up) and stay connected: a W-way exchange is one round trip through rank 0.
     Carries the RCCL rendezvous (128 bytes) and, as backend "tcp", the barrier and the sums."""
 
-    def __init__(self, rank, world, addr, port, timeout=300.0):
+    def __init__(self, rank, world, addr, port, timeout=None):
+        # The rendezvous is lazy (first collective), and for most command lines that is the
+        # closing barrier: ranks may arrive as far apart as their shards' run times differ.  So the
+        # wait for peers is long (SETK_DIST_TIMEOUT seconds, default a day: the launcher ends the
+        # other ranks when one dies) and an established socket never times out -- TCP keep-alive
+        # reports a peer that vanished.
+        if timeout is None:
+            timeout = float(os.environ.get("SETK_DIST_TIMEOUT", "86400"))
         self.rank, self.world = rank, world
         self.peers = []
         self.sock = None
@@ -51,13 +61,21 @@ class _Star(object):
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", port))
             srv.listen(world)
-            srv.settimeout(timeout)
+            deadline = time.time() + timeout
             got = {}
             while len(got) < world - 1:
+                srv.settimeout(max(0.05, deadline - time.time()))
                 c, _ = srv.accept()
-                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                c.settimeout(timeout)
-                r = struct.unpack("<i", _recv_exact(c, 4))[0]
+                try:
+                    c.settimeout(10.0)   # a stray connection must not stall the job
+                    magic, r = struct.unpack("<4si", _recv_exact(c, 8))
+                except (OSError, ConnectionError, struct.error):
+                    c.close()
+                    continue
+                if magic != _MAGIC or not 1 <= r < world or r in got:
+                    c.close()    # not one of this job's ranks (or a duplicate): refused
+                    continue
+                self._established(c)
                 got[r] = c
             srv.close()
             self.peers = [got[r] for r in range(1, world)]
@@ -71,10 +89,15 @@ class _Star(object):
                     if time.time() > deadline:
                         raise
                     time.sleep(0.05)
-            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            s.settimeout(timeout)
-            s.sendall(struct.pack("<i", rank))
+            s.sendall(_MAGIC + struct.pack("<i", rank))
+            self._established(s)
             self.sock = s
+
+    @staticmethod
+    def _established(sock):
+        sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        sock.setsockopt(socket.SOL_SOCKET, socket.SO_KEEPALIVE, 1)
+        sock.settimeout(None)
 
     def broadcast(self, payload, nbytes):
         """rank 0's `payload` (bytes) to everybody."""

@@ -207,9 +207,11 @@ class BatchEnhancer(object):
         self.pcm16 = pcm16
         # wave files' 16-bit samples go into the fused kernels as stored (de-interleaved, never
         # widened to float32) when the geometry is the matrix-core pass 2's: hop = n_fft / 2
+        # (the two library switches are read the way csrc/capi.hip reads them -- atoi -- so that
+        #  e.g. SETK_MC_PASS2=false disables the form on both sides of the ABI)
         self.pcm_direct_ok = n_fft == 512 and 2 * frame_hop == n_fft and \
-            os.environ.get("SETK_PCM16_DIRECT", "1") != "0" and \
-            os.environ.get("SETK_MC_PASS2", "1") != "0" and os.environ.get("SETK_LEGACY_FFT", "0") == "0"
+            _ffi.env_atoi("SETK_PCM16_DIRECT", 1) != 0 and \
+            _ffi.env_atoi("SETK_MC_PASS2", 1) != 0 and _ffi.env_atoi("SETK_LEGACY_FFT", 0) == 0
         self.vad_proportion = vad_proportion
         self.max_batch_samples = max_batch_samples
 

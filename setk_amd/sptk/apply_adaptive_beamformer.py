@@ -62,11 +62,13 @@ _OPTIONS = (
     (("--online.channels",), dict(default=4, type=int, dest="channels",
                                   help="Number of channels available")),
     (("--strict-reference",), dict(default=False, type=strtobool,
-                                   help="[setk_amd] skip an utterance exactly where the reference's "
-                                        "numpy.linalg.solve raises LinAlgError (an exactly zero LU pivot in "
-                                        "complex64: duplicated / silent channel, all-zero noise covariance); "
-                                        "default: such covariances are regularised and the utterance is "
-                                        "enhanced (INTEGRATION.md)")),
+                                   help="[setk_amd] skip the utterances whose noise covariance is "
+                                        "structurally singular, as the reference's numpy.linalg.solve does "
+                                        "(an exactly zero complex64 LU pivot: duplicated / silent channel, "
+                                        "all-zero covariance; the decision per utterance is reproduced on the "
+                                        "tested table tests/golden/ref_skipset.json, individual bins can differ "
+                                        "from LAPACK's by rounding); default: such covariances are regularised "
+                                        "and the utterance is enhanced (INTEGRATION.md)")),
     (("--batch-utts",), dict(default=32, type=int,
                              help="[setk_amd] utterances enhanced per GPU batch")),
     (("--device",), dict(default=-1, type=int,

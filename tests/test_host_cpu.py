@@ -38,6 +38,77 @@ def test_library_exports_header_symbols(built_lib):
     assert lib.setk_abi_version() == 1
 
 
+def test_rccl_load_failure_is_an_error_code_not_a_crash(built_lib):
+    """A host whose librccl cannot be loaded: setk_comm_unique_id / setk_comm_create return
+    SETK_ERR_UNSUPPORTED with the loader's message (round-5 advice: the message was built from
+    two dlerror() calls, the second of which returns NULL -> a crash instead of the TCP
+    fallback of dist.py).  SETK_RCCL_LIB forces the failure; no GPU work is involved."""
+    code = ("import ctypes, sys\n"
+            f"lib = ctypes.CDLL({built_lib!r})\n"
+            "lib.setk_comm_last_error.restype = ctypes.c_char_p\n"
+            "buf = ctypes.create_string_buffer(128)\n"
+            "rc = lib.setk_comm_unique_id(buf)\n"
+            "msg = lib.setk_comm_last_error().decode()\n"
+            "comm = ctypes.c_void_p()\n"
+            "rc2 = lib.setk_comm_create(ctypes.byref(comm), 0, buf.raw, 0, 1)\n"
+            "print(rc, rc2, msg)\n")
+    env = dict(os.environ, SETK_RCCL_LIB="/nonexistent/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    rc, rc2, msg = r.stdout.strip().split(" ", 2)
+    assert int(rc) == -2 and int(rc2) == -2 and "librccl not found" in msg and "/nonexistent" in msg
+
+
+def test_star_rendezvous_refuses_strays_and_duplicates():
+    """Rank 0 of the TCP star accepts exactly the job's ranks 1..W-1 once each: a connection
+    that does not speak the handshake, a rank id out of range and a duplicate id are closed and
+    the job still forms; established sockets carry no timeout."""
+    import socket
+    import struct
+    import threading
+    from setk_amd.dist import _Star, _MAGIC
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = {}
+
+    def rank0():
+        res[0] = _Star(0, 3, "127.0.0.1", port, timeout=60)
+
+    th = threading.Thread(target=rank0)
+    th.start()
+
+    def raw(payload):
+        for _ in range(200):
+            try:
+                c = socket.create_connection(("127.0.0.1", port), timeout=5)
+                break
+            except OSError:
+                import time
+                time.sleep(0.02)
+        c.sendall(payload)
+        return c
+    strays = [raw(b"GET / HTTP/1.0\r\n\r\n"), raw(_MAGIC + struct.pack("<i", 7)), raw(_MAGIC + struct.pack("<i", 0))]
+    res[1] = _Star(1, 3, "127.0.0.1", port, timeout=60)
+    dup = raw(_MAGIC + struct.pack("<i", 1))
+    res[2] = _Star(2, 3, "127.0.0.1", port, timeout=60)
+    th.join(timeout=60)
+    assert not th.is_alive() and len(res[0].peers) == 2
+    assert all(p.gettimeout() is None for p in res[0].peers) and res[1].sock.gettimeout() is None
+    out = {}
+    ts = [threading.Thread(target=lambda r=r: out.__setitem__(r, res[r].allreduce([r + 1.0, 2.0]))) for r in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert out[0] == out[1] == out[2] == [6.0, 6.0]
+    for c in strays + [dup]:
+        c.close()
+    for r in range(3):
+        res[r].close()
+
+
 def test_no_gpu_means_loud_failure(built_lib):
     """The product path must not fall back to the CPU."""
     import torch

@@ -5,7 +5,7 @@ set -u
 TAG=${1:-q}; ENVS=${2:-}
 OUT=gpurun_out/pmcmc_${TAG}
 mkdir -p "$OUT"; export TMPDIR=/tmp
-BENCH="python bench.py --pmc-child 1 --gpus 1 --steps 3 --warmup 1"
+BENCH="python bench.py --child 1 --gpus 1 --steps 3 --warmup 1"
 rocprofv3 -L 2>/dev/null | grep -io "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u > "$OUT/mfma_counters.txt"
 pass() { # name counters...
   local n=$1; shift

@@ -5,7 +5,7 @@ set -u
 TAG=${1:-s}; ENVS=${2:-}
 OUT=gpurun_out/pmcsolve_${TAG}
 mkdir -p "$OUT"; export TMPDIR=/tmp
-BENCH="python bench.py --pmc-child 1 --gpus 1 --steps 3 --warmup 1"
+BENCH="python bench.py --child 1 --gpus 1 --steps 3 --warmup 1"
 env $ENVS rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/kt.log" 2>&1
 env $ENVS rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/p1" -- $BENCH > "$OUT/p1.log" 2>&1
 env $ENVS rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d "$OUT/p2" -- $BENCH > "$OUT/p2.log" 2>&1
