@@ -77,6 +77,36 @@ def _write_inputs(td, n, C, N):
     return nd
 
 
+_PORT_WORKER = r"""
+import os, sys, time, json
+for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ[v] = "1"
+sys.path.insert(0, sys.argv[1])
+from oracle import np_oracle as o
+n, C, N, kind = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+utts = []
+for i in range(min(n, 2)):
+    mix, sp, nz = o.synth_utterance(i, C, N, return_parts=True)
+    utts.append((mix, o.irm_mask(sp, nz)))
+o.enhance_utterance(*utts[0], kind=kind)
+t0 = time.time()
+for i in range(n):
+    o.enhance_utterance(*utts[i % len(utts)], kind=kind)
+print(json.dumps(dict(wall=time.time() - t0)))
+"""
+
+
+def _port_one_core(n, C, N, kind):
+    """bench.py's `cpu_baseline` port (oracle/np_oracle.enhance_utterance, compute only, 1 thread)
+    on the SAME cores in the SAME run: the ratio port : reference that bench.py applies on the GPU
+    box, where only the port can run."""
+    r = subprocess.run([sys.executable, "-c", _PORT_WORKER, ROOT, str(n), str(C), str(N), kind],
+                       capture_output=True, text=True, timeout=3600)
+    if r.returncode != 0:
+        raise RuntimeError("port worker failed: " + r.stderr[-800:])
+    return json.loads(r.stdout.strip().splitlines()[-1])["wall"]
+
+
 def _run(td, shards, kind):
     start_at = time.time() + 6.0 + 0.05 * len(shards)
     procs = [subprocess.Popen([sys.executable, "-c", _WORKER, ROOT, td, str(s), kind, repr(start_at)],
@@ -113,7 +143,13 @@ def measure(utts=8, channels=8, seconds=30.0, kind="mvdr", nj=None, per_proc=2):
         for j in range(nj):
             shard(f"j{j}", per_proc)
         walln, late = _run(td, [f"j{j}" for j in range(nj)], kind)
+    wallp = _port_one_core(utts, C, N, kind)
+    ref1 = utts * seconds / wall1
+    port1 = utts * seconds / wallp
     return {
+        "port_one_core": {"value": round(port1, 2), "cores": 1, "utts": utts, "wall_s": round(wallp, 2),
+                          "what": "oracle/np_oracle.enhance_utterance, compute only, same cores, same run"},
+        "port_over_reference": {"one_core": round(port1 / ref1, 3)},
         "what": "unmodified reference scripts/sptk/apply_adaptive_beamformer.py through "
                 "oracle/ref_harness.py (five import shims, no source change), PCM16 wav + numpy "
                 "masks in, PCM16 wav out, first scp read to last wav close",

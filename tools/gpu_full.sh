@@ -7,7 +7,7 @@ TAG=${1:-run}; WHAT=${2:-both}
 O=gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 if [ "$WHAT" != bench ]; then
-  ( time timeout 3000 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider --durations=15 ) > $O/pytest_gpu.log 2>&1
+  ( time timeout 3000 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider -rs --durations=15 ) > $O/pytest_gpu.log 2>&1
   tail -25 $O/pytest_gpu.log | cut -c1-300
 fi
 if [ "$WHAT" != tests ]; then
