@@ -1329,8 +1329,8 @@ int run_cgmm_bin(setk_handle_t h, int C, int n_utts, const float* const* spec, c
     const char* timing_path = getenv("SETK_CGMM_TIMING");
     void* d_timing = nullptr;
     if (timing_path && *timing_path) {
-        d_timing = arena_alloc(h, (size_t)F * 8 * sizeof(long long));
-        if (d_timing) HIP_TRY(h, hipMemsetAsync(d_timing, 0, (size_t)F * 8 * sizeof(long long), s));
+        d_timing = arena_alloc(h, (size_t)F * cgmm_bin_timing_slots() * sizeof(long long));
+        if (d_timing) HIP_TRY(h, hipMemsetAsync(d_timing, 0, (size_t)F * cgmm_bin_timing_slots() * sizeof(long long), s));
     }
     for (int u = 0; u < n_utts; ++u) {
         const int T = frames[u], Tp = cgmm_bin_pitch(T);
@@ -1391,15 +1391,18 @@ int run_cgmm_bin(setk_handle_t h, int C, int n_utts, const float* const* spec, c
                                static_cast<float* const*>(d_gp), n_utts, F, max_frames, num_iters,
                                nout, s));
     if (d_timing) {
-        std::vector<long long> tm((size_t)F * 8);
+        const int ns = cgmm_bin_timing_slots();
+        std::vector<long long> tm((size_t)F * ns);
         HIP_TRY(h, hipMemcpyAsync(tm.data(), d_timing, tm.size() * sizeof(long long),
                                   hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
         if (FILE* fp = fopen(timing_path, "w")) {
-            fprintf(fp, "# bin frames rowsum barrier solve tail passes (shader cycles, summed over passes)\n");
+            fprintf(fp, "# bin | 0 frames 1 - 2 barrier 3 solve 4 tail 5 passes 6 nfast0 7 nfast1 | -DSETK_CGMM_PHASES: 8 E0 9 E1 10 P "
+                        "11 R-acc 12 R-sum 13 I-acc 14 I-sum | 16 solve:sums 17 scale 18 chol 19 bound 20 logdet 21 exact-path "
+                        "(shader cycles of wave 0, summed over passes)\n");
             for (int f = 0; f < F; ++f) {
                 fprintf(fp, "%d", f);
-                for (int k = 0; k < 8; ++k) fprintf(fp, " %lld", tm[(size_t)f * 8 + k]);
+                for (int k = 0; k < ns; ++k) fprintf(fp, " %lld", tm[(size_t)f * ns + k]);
                 fprintf(fp, "\n");
             }
             fclose(fp);
@@ -1998,7 +2001,7 @@ int setk_enhance_batch_taps(setk_handle_t h, const setk_bf_opts* opts, int n_utt
                     "16-bit PCM input (SETK_FLAG_IN_PCM16) needs hop = n_fft / 2 and the matrix-core "
                     "pass 2; convert with setk_pcm16_to_float_batch");
     const int quant2 = mc2 ? 8 : kSuperTile;
-    const int target2 = mc2 ? choose_target(all_frames, h->mc_p2_items > 0 ? h->mc_p2_items : h->mc_cus * pass2_mc_wgs_per_cu(C), quant2, 64)
+    const int target2 = mc2 ? choose_target(all_frames, h->mc_p2_items > 0 ? h->mc_p2_items : h->mc_cus * pass2_mc_wgs_per_cu(C, in_pcm), quant2, 64)
                             : choose_target(all_frames, h->p2_items, kSuperTile, kSuperTile * 4);
     int nparts_total = 0, max_parts = 0;
     for (int u = 0; u < n_utts; ++u) {

@@ -65,30 +65,11 @@ constexpr int kMaxSweeps = 14;
 constexpr double kTol2 = 1e-18;    // rotate while |a_pq|^2 > kTol2 a_pp a_qq
 constexpr double kLast2 = 1e-8;    // a sweep whose rotations all start below this is the last
 
-// Diagnostic build (-DSETK_CGMM_PHASES, tools/cgmm_phases.sh): wave 0's clock at the phase
-// boundaries of a pass, summed per bin into slots 8.. of the SETK_CGMM_TIMING array.  The
-// product build reads no clock inside a pass.
-constexpr int kTimingSlots = 24;
-#ifdef SETK_CGMM_PHASES
-#define PH_BEGIN(tm, on) long long ph_t_ = ((tm) && (on)) ? (long long)__builtin_readcyclecounter() : 0
-#define PH(tm, on, slot)                                                     \
-    do {                                                                     \
-        if ((tm) && (on)) {                                                  \
-            const long long n_ = (long long)__builtin_readcyclecounter();    \
-            (tm)[slot] += n_ - ph_t_;                                        \
-            ph_t_ = n_;                                                      \
-        }                                                                    \
-    } while (0)
-#else
-#define PH_BEGIN(tm, on)
-#define PH(tm, on, slot)
-#endif
-
 struct CgmmBinArgs {
     const cf* xb;            // [F][C][Tp]
     const float* init_mask;  // [T][F] or null
     float* gamma_bm;         // [nout][F][Tp]
-    long long* timing;       // diagnostic (SETK_CGMM_TIMING): [F][kTimingSlots] cycle counts, or null
+    long long* timing;       // diagnostic (SETK_CGMM_TIMING): [F][8] cycle counts, or null
     int T, Tp, F, update_alpha, nout, pad_;
 };
 
@@ -185,9 +166,6 @@ ZD void static_for(Fn&& fn) {
     }
 }
 
-ZD float sgprl(float v, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
 ZD float sgpr(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
@@ -358,12 +336,7 @@ ZD void write_factor(float* p, const zd lcol, const int i, const int j, const bo
 // lambda_max(R) >= M eps holds by construction (trace(R_eff^-1 R) = M^2, R_eff^-1 <= I / eps).
 template <int C, int NT>
 __device__ __noinline__ void solve_class(BinSmem<C, NT>& sm, const int k, const int lane,
-                                         const int mode, const int T, const int update_alpha,
-                                         long long* tm) {
-    const bool ph_on = (k == 0 && lane == 0);
-    (void)tm;
-    (void)ph_on;
-    PH_BEGIN(tm, ph_on);
+                                         const int mode, const int T, const int update_alpha) {
     typedef BinSmem<C, NT> S;
     typedef ParLayout<C> PL;
     constexpr int M = S::M, NP = S::NP, NPO = S::NPO, NV = S::NV;
@@ -402,7 +375,6 @@ __device__ __noinline__ void solve_class(BinSmem<C, NT>& sm, const int k, const 
         sm.tot[k][v] = t;
     }
     wave_lds_fence();
-    PH(tm, ph_on, 16);
     zd a = zmk(0.0, 0.0);
     const double sumg = sm.tot[k][NV - 1];
     if (in) {
@@ -422,104 +394,66 @@ __device__ __noinline__ void solve_class(BinSmem<C, NT>& sm, const int k, const 
         else if (update_alpha) par[PL::ALPHA] = (float)(sumg / (double)T);
     }
 
-    // --- power-of-two scale: trace in [0.5, 1) (the diagonal sums are in `tot`: no round trip) ---
+    // --- power-of-two scale: trace in [0.5, 1) ---
+    if (act) A[lane] = a;
+    wave_lds_fence();
     double tr = 0.0;
-    {
-        const double rd = (mode == kModeInitId) ? 1.0 / (double)T : 1.0 / fmax(sumg, kEpsD);
 #pragma unroll
-        for (int d = 0; d < C; ++d) tr += sm.tot[k][pair_index(d, d, C)] * rd;
-    }
+    for (int d = 0; d < C; ++d) tr += A[d * M + d].x;
     int ex = 0;
     if (tr > 0.0 && tr < 1e300) ex = __builtin_amdgcn_frexp_exp(tr);
     const double scl = __builtin_amdgcn_ldexp(1.0, ex), rscl = __builtin_amdgcn_ldexp(1.0, -ex);
     a = zscale(a, rscl);
     tr *= rscl;
-    PH(tm, ph_on, 17);
+    wave_lds_fence();
 
     // --- fast path: Cholesky of R itself when the eigenvalue floor provably rests ---
     if (!exact) {
         bool ok;
         const zd lcol = chol_lanes<C, M>(A, a, i, j, lane, in, ok);
-        PH(tm, ph_on, 18);
-        // P = prod 1 / L_ii (uniform: the diagonal lanes are known at compile time), det R = 1 / P^2
-        double pd = 1.0;
+        // A now holds garbage of the elimination; publish L for the bound
+        if (in && i >= j) W[lane] = (i == j) ? zmk(lcol.x, lcol.y) : lcol;
+        wave_lds_fence();
+        // column `lane` of L^-1 by forward substitution (float32 is plenty for a bound)
+        float n2 = 0.f;
+        if (lane < C) {
+            float yr[C], yi[C];
 #pragma unroll
-        for (int d = 0; d < C; ++d) {
-            const unsigned lo = __builtin_amdgcn_readlane((unsigned)__double2loint(lcol.y), d * M + d);
-            const unsigned hi = __builtin_amdgcn_readlane((unsigned)__double2hiint(lcol.y), d * M + d);
-            pd *= __hiloint2double((int)hi, (int)lo);
-        }
-        const bool all_ok = __all(ok);
-        // First certificate, from what the factorisation already holds (eigenvalues l_1 >= .. >= l_C):
-        //   l_C = det / (l_1 .. l_{C-1}),   l_1 .. l_{C-1} <= f(l_1) = l_1 ((trace - l_1) / (C - 2))^(C - 2)   (AM-GM
-        //   on the middle ones), f rises up to trace / (C - 1) and falls after it, and
-        //   l_1 >= |R|_F^2 / trace  (sum l_i^2 <= l_1 sum l_i)  -- so  l_C >= det / f(max(|R|_F^2 / trace, trace / (C - 1))).
-        // With  1 >= 1.1 eps trace f P^2  (det = 1 / P^2) that is  l_C >= 1.1 eps trace >= 1.1 eps l_1: the
-        // reference's eigenvalue floor rests.  One wave sum and a dozen uniform operations; the L^-1
-        // bound below decides what this one leaves open.
-        float fr = in ? (float)(a.x * a.x + a.y * a.y) : 0.f;
-        fr += dppf<0xB1>(fr);    // quad_perm:[1,0,3,2]
-        fr += dppf<0x4E>(fr);    // quad_perm:[2,3,0,1]
-        fr += dppf<0x141>(fr);   // row_half_mirror
-        fr += dppf<0x140>(fr);   // row_mirror: every lane of a row holds the row's sum
-        const float fro = sgprl(fr, 0) + sgprl(fr, 16) + sgprl(fr, 32) + sgprl(fr, 48);
-        double fP;
-        if constexpr (C >= 3) {
-            const double m = (double)fro * (1.0 - 1e-5) / tr;   // (float32 sum of <= 64 terms: 4e-6)
-            const double x = fmax(m, tr / (double)(C - 1));
-            const double y = fmax(tr - x, 0.0) * (1.0 / (double)(C - 2));
-            fP = x;
+            for (int r = 0; r < C; ++r) {
+                float sr = (r == lane) ? 1.f : 0.f, si = 0.f;
 #pragma unroll
-            for (int d = 0; d < C - 2; ++d) fP *= y;
-        } else {
-            fP = (C == 2) ? tr : 1.0;
-        }
-        bool certified = all_ok && pd > 0.0 && pd < 1e140 && fP > 0.0 && (1.1 * kEpsD * tr * fP * pd * pd <= 1.0);
-        if (!certified) {
-            // Second certificate: lambda_min >= 1 / trace(R^-1), trace(R^-1) = |L^-1|_F^2.
-            // A now holds garbage of the elimination; publish L for the bound
-            if (in && i >= j) W[lane] = (i == j) ? zmk(lcol.x, lcol.y) : lcol;
-            wave_lds_fence();
-            // column `lane` of L^-1 by forward substitution (float32 is plenty for a bound)
-            float n2 = 0.f;
-            if (lane < C) {
-                float yr[C], yi[C];
-#pragma unroll
-                for (int r = 0; r < C; ++r) {
-                    float sr = (r == lane) ? 1.f : 0.f, si = 0.f;
-#pragma unroll
-                    for (int c2 = 0; c2 < r; ++c2) {
-                        const zd l = W[r * M + c2];
-                        const float lr = (float)l.x, li = (float)l.y;
-                        sr -= lr * yr[c2] - li * yi[c2];
-                        si -= lr * yi[c2] + li * yr[c2];
-                    }
-                    const float rdg = (float)W[r * M + r].y;
-                    yr[r] = (r < lane) ? 0.f : sr * rdg;
-                    yi[r] = (r < lane) ? 0.f : si * rdg;
-                    n2 += yr[r] * yr[r] + yi[r] * yi[r];
+                for (int c2 = 0; c2 < r; ++c2) {
+                    const zd l = W[r * M + c2];
+                    const float lr = (float)l.x, li = (float)l.y;
+                    sr -= lr * yr[c2] - li * yi[c2];
+                    si -= lr * yi[c2] + li * yr[c2];
                 }
-                sm.cert[k][lane] = n2;
+                const float rdg = (float)W[r * M + r].y;
+                yr[r] = (r < lane) ? 0.f : sr * rdg;
+                yi[r] = (r < lane) ? 0.f : si * rdg;
+                n2 += yr[r] * yr[r] + yi[r] * yi[r];
             }
-            wave_lds_fence();
-            float tinv = 0.f;
-#pragma unroll
-            for (int d = 0; d < C; ++d) tinv += sm.cert[k][d];
-            // lambda_min >= 1 / trace(R^-1); lambda_max <= trace(R)
-            certified = all_ok && (tinv * (float)tr * (1.1f * kEpsF) < 1.0f) && tinv > 0.f;
+            sm.cert[k][lane] = n2;
         }
-        PH(tm, ph_on, 19);
+        wave_lds_fence();
+        float tinv = 0.f;
+#pragma unroll
+        for (int d = 0; d < C; ++d) tinv += sm.cert[k][d];
+        // lambda_min >= 1 / trace(R^-1); lambda_max <= trace(R)
+        const bool certified = __all(ok) && (tinv * (float)tr * (1.1f * kEpsF) < 1.0f) && tinv > 0.f;
         if (certified) {
             write_factor<C>(par, lcol, i, j, in);
+            // log det R = -2 sum log(1 / L_ii)
+            if (lane < C) sm.cert[k][lane] = __logf((float)W[lane * M + lane].y);
+            wave_lds_fence();
+            float ld = 0.f;
+#pragma unroll
+            for (int d = 0; d < C; ++d) ld += sm.cert[k][d];
             if (lane == 0) {
-                // log det R = -2 log P, P = m 2^e
-                const double m = __builtin_amdgcn_frexp_mant(pd);
-                const int e = __builtin_amdgcn_frexp_exp(pd);
-                par[PL::LD] = -2.0f * (__logf((float)m) + (float)e * 0.6931471805599453f);
+                par[PL::LD] = -2.0f * ld;
                 sm.hasV[k] = 0;  // the eigenvectors are stale now
                 sm.nfast[k] += 1;
             }
-            PH(tm, ph_on, 20);
             return;
         }
         wave_lds_fence();
@@ -647,7 +581,6 @@ __device__ __noinline__ void solve_class(BinSmem<C, NT>& sm, const int k, const 
         par[PL::LD] = ld;
         sm.hasV[k] = 1;
     }
-    PH(tm, ph_on, 21);   // the exact path: everything after the fast path's attempt
 }
 
 // ---- one pass over the thread's frames -----------------------------------------------------
@@ -671,9 +604,6 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
     };
     float w0[U], w1[U];
     float sg0 = 0.f, sg1 = 0.f;
-    long long* tm = a.timing ? a.timing + (size_t)f * kTimingSlots : nullptr;
-    (void)tm;
-    PH_BEGIN(tm, tid == 0);
     if constexpr (MODE == kModeInitId) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -709,7 +639,6 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
             });
         }
         reload_fence();
-        PH(tm, tid == 0, 8);
         {
             ClassPar<C> p;
             load_par<C>(sm.par[1], p);
@@ -725,7 +654,6 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
             });
         }
         reload_fence();
-        PH(tm, tid == 0, 9);
         constexpr float kLog2e = 1.4426950408889634f;
         const float ld0 = sgpr(sm.par[0][PL::LD]) * kLog2e, ld1 = sgpr(sm.par[1][PL::LD]) * kLog2e;
         const float al0 = sgpr(sm.par[0][PL::ALPHA]), al1 = sgpr(sm.par[1][PL::ALPHA]);
@@ -755,7 +683,6 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
                 }
             }
         }
-        PH(tm, tid == 0, 10);
         if constexpr (MODE == kModeFinal) return;
     }
 
@@ -785,7 +712,6 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
             }
             reload_fence();
         });
-        PH(tm, tid == 0, 11);
         float tot[Bfly<2 * NP>::N2];
         butterfly_sum<2 * NP>(acc, tot, lane);
         if (wr) {
@@ -797,7 +723,6 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
         }
     }
     reload_fence();
-    PH(tm, tid == 0, 12);
     // ---- imaginary parts, i < j (class k at k NPO + e), and the posterior sums ----
     {
         constexpr int NI = 2 * NPO + 2;
@@ -822,7 +747,6 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
             }
             reload_fence();
         });
-        PH(tm, tid == 0, 13);
         acc[2 * NPO] = sg0;
         acc[2 * NPO + 1] = sg1;
         float tot[Bfly<NI>::N2];
@@ -841,7 +765,6 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
             }
         }
     }
-    PH(tm, tid == 0, 14);
 }
 
 template <int C, int NT, int U, int RF, int WPS>
@@ -913,14 +836,13 @@ __global__ __launch_bounds__(NT, WPS) void cgmm_bin_em_kernel(const CgmmBinArgs*
             // the two solving waves are this workgroup's critical path while the CU's
             // other workgroup streams frames: let them issue first
             __builtin_amdgcn_s_setprio(3);
-            solve_class<C, NT>(sm, wave, lane, mode, T, a.update_alpha,
-                               a.timing ? a.timing + (size_t)f * kTimingSlots : nullptr);
+            solve_class<C, NT>(sm, wave, lane, mode, T, a.update_alpha);
             __builtin_amdgcn_s_setprio(0);
         }
         const long long tc4 = a.timing ? (long long)__builtin_readcyclecounter() : 0;
         __syncthreads();
         if (a.timing && tid == 0) {
-            long long* tm = a.timing + (size_t)f * kTimingSlots;
+            long long* tm = a.timing + (size_t)f * 8;
             tm[0] += tc2 - tc0;   // frames + row sums
             tm[2] += tc3 - tc2;   // barrier wait (wave 0)
             tm[3] += tc4 - tc3;   // solve (wave 0 = class 0)
@@ -1084,7 +1006,7 @@ bool cfg_fits_c(int C, int cfg, int max_frames) {
 }  // namespace
 
 size_t cgmm_bin_args_bytes() { return sizeof(CgmmBinArgs); }
-int cgmm_bin_timing_slots() { return kTimingSlots; }
+int cgmm_bin_timing_slots() { return 8; }
 
 // frames pitch of the bin-major arrays
 int cgmm_bin_pitch(int T) { return (T + 3) & ~3; }

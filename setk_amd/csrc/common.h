@@ -153,7 +153,7 @@ hipError_t launch_pass1(int C, bool dump, const Pass1Args& a, int n_items, hipSt
 hipError_t launch_pass1_mc(int C, const Pass1Args& a, int n_items, hipStream_t s);
 bool pass1_mc_supported(int C, int hop);
 hipError_t launch_pass2_mc(int C, const Pass2Args& a, int n_items, hipStream_t s, bool pcm16 = false);
-int pass2_mc_wgs_per_cu(int C);
+int pass2_mc_wgs_per_cu(int C, bool pcm16 = false);
 // STFT of whole utterances into the bin-major [F][C][Tp] layout of cgmm_bin.hip
 // (items: 64-frame blocks; UttDesc::wave_out = the utterance's output)
 hipError_t launch_stft_binmajor(int C, const Pass1Args& a, int n_items, hipStream_t s);
@@ -206,6 +206,7 @@ hipError_t launch_cgmm_k(const float* spec, const double* gamma0, const float* i
                          int update_alpha, hipStream_t s);
 // bin-resident EM (cgmm_bin.hip)
 size_t cgmm_bin_args_bytes();
+int cgmm_bin_timing_slots();
 int cgmm_bin_pitch(int T);
 int cgmm_bin_threads(int C, int max_frames);
 void cgmm_bin_fill_args(void* out, const float* xb, const float* init_mask, float* gamma_bm, int T,

@@ -76,18 +76,32 @@ SETK_DEV void load_raw_mc2(float (&v)[8], FloatPtr x, int n_samp, int s, int lan
 #ifndef SETK_P2MC_PF2
 #define SETK_P2MC_PF2 0
 #endif
+// 16-bit PCM form: ONE 1024-thread workgroup per CU (the tables once instead of twice) whose waves
+// carry the group-boundary half frame of every channel through LDS as packed int16 (8 bytes per
+// lane and channel = 4 KB per wave) instead of re-reading it from HBM at the next group -- the
+// re-read was 1/3 of the kernel's audio traffic (counter traffic 1.35 x algorithmic).
+#ifndef SETK_P2MC_PCM_THREADS
+#define SETK_P2MC_PCM_THREADS 1024
+#endif
+#ifndef SETK_P2MC_PCM_CARRY
+#define SETK_P2MC_PCM_CARRY 1
+#endif
 struct False { static constexpr bool value = false; };
 struct True { static constexpr bool value = true; };
 constexpr int kP2McThreads = SETK_P2MC_THREADS;
-constexpr int kP2McWaves = kP2McThreads / 64;
+constexpr int kP2McPcmThreads = SETK_P2MC_PCM_THREADS;
+constexpr bool kP2McPcmCarry = SETK_P2MC_PCM_CARRY != 0;
+constexpr int p2mc_threads(bool pcm) { return pcm ? kP2McPcmThreads : kP2McThreads; }
 
 constexpr int kP2McTiles = SETK_P2MC_KLDS ? (SETK_P2MC_WLDS ? 25 : 20) : 12;  // BR_H .. IT_L (10 tiles, contiguous words) + OT_H, OT_L + the forward's 8
 // LDS plan (bytes): wtab C * 257 * 8 | operand tiles 25 * 1024 | synthesis rows
 // 2048 | a16 scratch NW * 8 * kOddPitch * 4 | yodd NW * 16 * 4 | red 64
-size_t pass2_mc_lds_bytes(int C) {
+// | PCM carry NW * C * 64 * 8
+size_t pass2_mc_lds_bytes(int C, bool pcm) {
+    const size_t nw = p2mc_threads(pcm) / 64;
     const size_t wt = ((size_t)C * kBins * sizeof(cf) + 15) & ~(size_t)15;
-    return wt + kP2McTiles * 1024 + 2048 + (size_t)kP2McWaves * SETK_P2MC_GROUP * 8 * mc::kOddPitch * sizeof(float) +
-           kP2McWaves * 16 * sizeof(float) + 64;
+    return wt + kP2McTiles * 1024 + 2048 + nw * SETK_P2MC_GROUP * 8 * mc::kOddPitch * sizeof(float) +
+           nw * 16 * sizeof(float) + 64 + ((pcm && kP2McPcmCarry) ? nw * C * 64 * 8 : 0);
 }
 
 // sum over the first 8 lanes of every 16-lane row, result in lanes 0..7 of the row
@@ -131,10 +145,11 @@ SETK_DEV float wave_max_nonneg(float x) {
 // PCM: UttDesc::audio is planar 16-bit PCM (kAudioPcm16) -- sign-extending 2-byte loads, one
 // conversion per sample, and 2^-15 (read_wav's int16 / 32768) folded into the window rows.
 template <int C, bool PCM = false>
-__global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamform_istft_mc_kernel(Pass2Args a) {
-    constexpr int NT = kP2McThreads;
-    constexpr int NW = kP2McWaves;
+__global__ __launch_bounds__(p2mc_threads(PCM), SETK_P2MC_WAVES_PER_SIMD) void beamform_istft_mc_kernel(Pass2Args a) {
+    constexpr int NT = p2mc_threads(PCM);
+    constexpr int NW = NT / 64;
     constexpr int F = kBins;
+    constexpr bool CARRY = PCM && kP2McPcmCarry;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* p = smem;
@@ -149,6 +164,8 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
     float* yodd_s = reinterpret_cast<float*>(p);  // [NW][16]
     p += NW * 16 * sizeof(float);
     float* red = reinterpret_cast<float*>(p);
+    p += 64;
+    uint2* carry_s = reinterpret_cast<uint2*>(p);  // [NW][C][64] packed int16 x 4 (CARRY only)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -257,7 +274,30 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
         if constexpr (PCM) return (gcshort_p)gptr(ud.audio) + (size_t)c * ud.ch_stride;
         else return gptr(ud.audio) + (size_t)c * n_samp;
     };
-    auto load_full = [&](float (&v)[8], int t, int c, auto edge) __attribute__((always_inline)) {
+    // CARRY: the lane's own four samples of the half frame a group ends with, per channel -- a
+    // thread reads back exactly what it wrote (program order suffices, no barrier)
+    uint2* carry_l = carry_s + (size_t)wave * C * 64 + lane;  // + 64 c
+    auto load_full = [&](float (&v)[8], int t, int c, auto edge, bool first) __attribute__((always_inline)) {
+        (void)first;
+        if constexpr (CARRY) {
+            // first half: what this lane parked at the end of the previous group (or the prefill
+            // before the first); second half: the only samples of the frame not seen yet
+            const uint2 pk = carry_l[64 * c];
+            v[0] = (float)(short)(pk.x & 0xffff);
+            v[1] = (float)((int)pk.x >> 16);
+            v[2] = (float)(short)(pk.y & 0xffff);
+            v[3] = (float)((int)pk.y >> 16);
+            const auto x = chan(c);
+            const int s0 = min(t, T - 1) * hop - a.g.pad + 256, o = 64 * g + c16;
+            if (!decltype(edge)::value) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 + e] = x[s0 + o + 16 * e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 + e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
+            }
+            return;
+        }
 #ifdef SETK_P2MC_ABL_L2  // ablation: every wave reads the same 1 MB (L2 resident) -- wrong results
         gcfloat_p x = gptr(a.utts[0].audio) + (size_t)c * n_samp;
         (void)chan;
@@ -293,6 +333,20 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
             for (int e = 0; e < 4; ++e) {
                 v[e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
                 v[4 + e] = x[reflect_index(s0 + o + 256 + 16 * e, n_samp)];
+            }
+        }
+    };
+    // the same half as raw 16-bit samples (CARRY): converted and packed for the carry where consumed
+    auto load_half_raw = [&](int (&r)[4], int t, int c, auto edge) __attribute__((always_inline)) {
+        if constexpr (PCM) {
+            const auto x = chan(c);
+            const int s0 = min(t, T - 1) * hop - a.g.pad + 256, o = 64 * g + c16;
+            if (!decltype(edge)::value) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = x[s0 + o + 16 * e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
             }
         }
     };
@@ -334,7 +388,9 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
     // the R transforms of every channel of one group; `nxt` arrives holding frame (t0, channel 0)
     // and leaves holding frame (t0 + R, channel 0)
     float nxt[8];
-    auto group = [&](int t0, auto edge) __attribute__((always_inline)) {
+    int nraw[4];  // CARRY: the half frame in flight, as loaded
+    auto group = [&](int t0, auto edge, bool first_next) __attribute__((always_inline)) {
+        (void)first_next;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             yr[k] = (mc::f4){0.f, 0.f, 0.f, 0.f};
@@ -361,14 +417,18 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
                 // two transforms ahead: during (t0, c) the whole frame (t0, c + 1), during
                 // (t0 + 1, c) the second half of (t0 + 1, c + 1)
                 if (c + 1 < C) {
-                    if (k == 0) load_full(nxt, t0, c + 1, edge);
+                    if (k == 0) load_full(nxt, t0, c + 1, edge, true);
                     else load_half4(nxth, t0 + 1, c + 1, edge);
                 }
 #else
                 // what comes next travels while this transform runs: the second half of the
                 // next frame of the group, or the first frame of the next channel / group
-                if (k + 1 < R) load_half(nxt, t0 + k + 1, c, edge);
-                else if (c + 1 < C) load_full(nxt, t0, c + 1, edge);
+                if (k + 1 < R) {
+                    if constexpr (CARRY) load_half_raw(nraw, t0 + k + 1, c, edge);
+                    else load_half(nxt, t0 + k + 1, c, edge);
+                } else if (c + 1 < C) {
+                    load_full(nxt, t0, c + 1, edge, first_next);
+                }
 #endif
                 mc::f4 zr, zi, a16;
 #if SETK_P2MC_KLDS && SETK_P2MC_WLDS
@@ -402,8 +462,15 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
 #if SETK_P2MC_PF2
                         x[4 + e] = xh[e];
 #else
-                        x[4 + e] = nxt[4 + e];
+                        if constexpr (CARRY) x[4 + e] = (float)nraw[e];
+                        else x[4 + e] = nxt[4 + e];
 #endif
+                    }
+                    if constexpr (CARRY) {
+                        // the group's last half frame is the next group's first: R == 2, k == 0
+                        static_assert(!CARRY || R == 2, "the LDS carry is written for groups of two frames");
+                        carry_l[64 * c] = make_uint2(__builtin_amdgcn_perm((unsigned)nraw[1], (unsigned)nraw[0], 0x05040100u),
+                                                     __builtin_amdgcn_perm((unsigned)nraw[3], (unsigned)nraw[2], 0x05040100u));
                     }
                 }
                 // one transform at a time: interleaved by the scheduler, the R unrolled
@@ -416,26 +483,44 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
         const int lo = t0 * hop - a.g.pad, hi = (t0 + R - 1) * hop - a.g.pad + kNfft;
         return lo < 0 || hi > n_samp || t0 + R > T;
     };
-    auto request_group = [&](int t0) __attribute__((always_inline)) {
+    auto request_group = [&](int t0, bool first) __attribute__((always_inline)) {
         if (span_is_edge(t0)) {
-            load_full(nxt, t0, 0, True());
+            load_full(nxt, t0, 0, True(), first);
 #if SETK_P2MC_PF2
             load_half4(nxth, t0 + 1, 0, True());
 #endif
         } else {
-            load_full(nxt, t0, 0, False());
+            load_full(nxt, t0, 0, False(), first);
 #if SETK_P2MC_PF2
             load_half4(nxth, t0 + 1, 0, False());
 #endif
         }
     };
-    if (tw < tb) request_group(tw);
+    if constexpr (CARRY) {
+        // the first half of the wave's first frame, every channel: from here on a group reads two
+        // half frames per channel from HBM, never three
+        if (tw < tb) {
+#pragma unroll 1
+            for (int c = 0; c < C; ++c) {
+                const auto x = chan(c);
+                const int s0 = tw * hop - a.g.pad, o = 64 * g + c16;
+                int r[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
+                carry_l[64 * c] = make_uint2(__builtin_amdgcn_perm((unsigned)r[1], (unsigned)r[0], 0x05040100u),
+                                             __builtin_amdgcn_perm((unsigned)r[3], (unsigned)r[2], 0x05040100u));
+            }
+        }
+    }
+    if (tw < tb) request_group(tw, true);
 #pragma unroll 1
     for (int t0 = tw; t0 < tb; t0 += R) {
         const int nf = min(R, tb - t0);
-        if (span_is_edge(t0)) group(t0, True());
-        else group(t0, False());
-        if (t0 + R < tb) request_group(t0 + R);  // (issued here: its span decides the path)
+        // (the channels 1.. of this group are fetched inside it: from the carry unless it is the
+        //  wave's first group)
+        if (span_is_edge(t0)) group(t0, True(), t0 == tw);
+        else group(t0, False(), t0 == tw);
+        if (t0 + R < tb) request_group(t0 + R, false);  // (issued here: its span decides the path)
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             if (k >= nf) break;
@@ -574,20 +659,20 @@ __global__ __launch_bounds__(kP2McThreads, SETK_P2MC_WAVES_PER_SIMD) void beamfo
 }
 
 // workgroups of this kernel a CU holds (registers and LDS), for the work-list cut of capi.hip
-int pass2_mc_wgs_per_cu(int C) {
-    const int by_waves = SETK_P2MC_WAVES_PER_SIMD * 4 / kP2McWaves;
-    const int by_lds = (int)((160u << 10) / pass2_mc_lds_bytes(C));
+int pass2_mc_wgs_per_cu(int C, bool pcm) {
+    const int by_waves = SETK_P2MC_WAVES_PER_SIMD * 4 / (p2mc_threads(pcm) / 64);
+    const int by_lds = (int)((160u << 10) / pass2_mc_lds_bytes(C, pcm));
     return by_waves < by_lds ? (by_waves > 0 ? by_waves : 1) : (by_lds > 0 ? by_lds : 1);
 }
 
 template <int C, bool PCM = false>
 static hipError_t launch_pass2_mc_t(const Pass2Args& a, int n_items, hipStream_t s) {
-    const size_t lds = pass2_mc_lds_bytes(C);
+    const size_t lds = pass2_mc_lds_bytes(C, PCM);
     auto k = beamform_istft_mc_kernel<C, PCM>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(n_items), dim3(kP2McThreads), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(n_items), dim3(p2mc_threads(PCM)), lds, s, a);
     return hipGetLastError();
 }
 

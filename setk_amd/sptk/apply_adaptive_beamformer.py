@@ -280,9 +280,25 @@ def _fast_path_ok(args):
     return True
 
 
+def _since_process_start():
+    """Seconds since this process was created (diagnostic: the `marks` of --profile)."""
+    import time
+    try:
+        with open("/proc/self/stat") as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+        return time.clock_gettime(time.CLOCK_BOOTTIME) - ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def run_offline(args, shard):
     import time
     t_start = time.perf_counter()
+    marks = {"process_start_to_first_scp_read": _since_process_start()}
+    args._marks, args._t_start = marks, t_start
+
+    def mark(name):
+        marks[name] = round(time.perf_counter() - t_start, 4)
     wav_reader = WaveReader(args.wav_scp, sr=args.sr)
     MaskReader = {"numpy": NumpyReader, "kaldi": ScriptReader}[args.fmt]
     tgt = MaskReader(args.tgt_mask)
@@ -305,6 +321,7 @@ def run_offline(args, shard):
                            rank1_appro=args.rank1_appro, post_mask=bool(args.mask),
                            vad_proportion=args.vad_proportion, pcm16=True, device=device,
                            strict_reference=bool(getattr(args, "strict_reference", False)))
+    mark("tables_read_engine_built")   # (the engine's first use of the library initialises HIP)
     # before any thread pool or pinned slab exists: they inherit the placement
     from setk_amd import numa
     placement = numa.bind(engine.ctx, getattr(args, "numa", "auto"))
@@ -312,8 +329,9 @@ def run_offline(args, shard):
         logger.info(f"rank {shard.rank}: bound to NUMA node {placement['node']} "
                     f"({placement['cpus']} CPUs, GPU {placement.get('pci_bus_id')})")
     keys = _deal(args, shard, wav_reader)
+    mark("numa_bound_keys_dealt")
     summary = dict(mode="batch", utts=0, rank=shard.rank, world=shard.world,
-                   assigned_samples=shard.assigned_weight, numa=placement)
+                   assigned_samples=shard.assigned_weight, numa=placement, marks=marks)
     num_done = 0
     with WaveWriter(args.dst_dir, sr=args.sr) as writer:
         _arm_fault_injection(shard, writer)
@@ -322,6 +340,7 @@ def run_offline(args, shard):
             summary.update(mode="pipeline", stages=stats)
         else:
             num_done = _run_batches(args, engine, writer, wav_reader, tgt, itf, keys)
+    mark("last_wav_closed")
     summary["wall_s"] = time.perf_counter() - t_start
     summary["utts"] = num_done
     logger.info(f"rank {shard.rank}: {num_done} utterances in {summary['wall_s']:.2f} s "
@@ -371,6 +390,9 @@ def _run_pipeline(args, engine, writer, wav_reader, tgt, itf, keys):
     pipe = StreamPipeline(engine, sink, announce=announce, batch_utts=args.batch_utts,
                           depth=args.pipeline_depth, read_threads=args.read_threads or None,
                           zero_copy=args.zero_copy, h2d=args.h2d)
+    import time
+    marks, t_start = getattr(args, "_marks", {}), getattr(args, "_t_start", time.perf_counter())
+    marks["pipeline_built"] = round(time.perf_counter() - t_start, 4)
     wide = []  # more than 8 channels: stand-alone operators, after the pipeline drained
     try:
         for key in keys:
@@ -385,8 +407,10 @@ def _run_pipeline(args, engine, writer, wav_reader, tgt, itf, keys):
                 continue
             pipe.submit(key, audio, mask_source(tgt, key, files, engine.num_bins),
                         None if itf is None else mask_source(itf, key, files, engine.num_bins))
+        marks["all_submitted"] = round(time.perf_counter() - t_start, 4)
     finally:
         num_done, stats = pipe.close()
+        marks["pipeline_closed_slabs_released"] = round(time.perf_counter() - t_start, 4)
         files.close()
     if wide:
         num_done += _run_batches(args, engine, writer, wav_reader, tgt, itf, wide)
@@ -458,7 +482,3 @@ def run(args):
 def main(argv=None):
     args = build_parser().parse_args(argv)
     run(args)
-
-
-if __name__ == "__main__":
-    main()

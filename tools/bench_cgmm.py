@@ -28,8 +28,8 @@ def main():
     N = int(a.seconds * 16000)
     ctx = _ffi.Context(0)
     est = CgmmEstimator(num_iters=a.iters, ctx=ctx)
-    audio = [torch.from_numpy(synth.synth_utterance(i % 8, a.channels, N)).to(dev)
-             for i in range(a.utts)]
+    distinct = [torch.from_numpy(synth.synth_utterance(i, a.channels, N)).to(dev) for i in range(min(8, a.utts))]
+    audio = [distinct[i] if i < 8 else distinct[i % 8].clone() for i in range(a.utts)]
     T = ctx.num_frames(N) if ctx.plan else None
     est._plan()
     T = ctx.num_frames(N)

@@ -8,7 +8,8 @@ import os
 import sys
 
 root = sys.argv[1]
-KERNELS = ("stft_covar_kernel<8, false", "beamform_istft_mc_kernel<8", "solve_kernel<8")
+KERNELS = tuple(os.environ["SETK_STALL_KERNELS"].split(";")) if os.environ.get("SETK_STALL_KERNELS") else \
+    ("stft_covar_kernel<8, false", "beamform_istft_mc_kernel<8", "solve_kernel<8")
 for lib in sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d))):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for p in glob.glob(os.path.join(root, lib, "g*", "**", "*counter_collection.csv"), recursive=True):
