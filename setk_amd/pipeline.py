@@ -340,7 +340,7 @@ class StreamPipeline(object):
     """
 
     def __init__(self, engine, sink, announce=None, batch_utts=32, depth=3, read_threads=None,
-                 write_threads=4, slab_mb=0, zero_copy=False, h2d="batch"):
+                 write_threads=4, slab_mb=0, zero_copy=False, h2d="batch", batch_mb=80):
         self.engine = engine
         self.ctx = engine.ctx
         self.sink = sink
@@ -353,6 +353,14 @@ class StreamPipeline(object):
             raise ValueError(f"h2d must be 'payload' or 'batch', got {h2d!r}")
         self.h2d = h2d
         self.batch_utts = max(1, int(batch_utts))
+        # A batch closes at `batch_utts` utterances OR `batch_mb` MB of input, whichever comes
+        # first: what a run pays per slab -- page-locking it, the ramp until three are in flight,
+        # unpinning it at the end -- grows with its BYTES, while ~80 MB already keeps the copy
+        # engine and the kernels busy (round 6, profiles/round6/e2e_batch_size_sweep.txt: 192 files
+        # of 8-ch 30 s in 0.54 s with 77 MB slabs against 0.82 s with 307 MB ones; 1536 files 0.87 - 0.91
+        # against 0.95 s).  0 = count only.
+        self.batch_bytes = max(0, int(batch_mb)) << 20
+        self.pending_bytes = 0
         self.F = engine.num_bins
         ncpu = os.cpu_count() or 4
         # more readers are slower: the page-cache copies of many threads contend in the kernel
@@ -416,9 +424,10 @@ class StreamPipeline(object):
             self._dispatch()
         self.group = g
         self.pending.append(job)
+        self.pending_bytes += job.audio.nbytes + job.mask.nbytes + (job.itf.nbytes if job.itf is not None else 0)
         with self.lock:
             self.stats["t_plan"] += time.perf_counter() - t0
-        if len(self.pending) >= self.batch_utts:
+        if len(self.pending) >= self.batch_utts or (self.batch_bytes and self.pending_bytes >= self.batch_bytes):
             self._dispatch()
 
     def _mask_payload(self, m, T):
@@ -462,6 +471,7 @@ class StreamPipeline(object):
 
     def _dispatch(self):
         batch, self.pending = self.pending, []
+        self.pending_bytes = 0
         if not batch:
             return
         # slab layout: [audio payloads | masks | itf masks]; out: [pcm16 waves | status | power]
@@ -749,6 +759,7 @@ class StreamPipeline(object):
         st["read_mode"] = "zero_copy" if self.zero_copy else READ_MODE
         st["depth"] = self.depth
         st["batch_utts"] = self.batch_utts
+        st["batch_mb"] = self.batch_bytes >> 20
         return self.num_done, st
 
 

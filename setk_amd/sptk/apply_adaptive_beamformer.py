@@ -70,7 +70,10 @@ _OPTIONS = (
                                         "from LAPACK's by rounding); default: such covariances are regularised "
                                         "and the utterance is enhanced (INTEGRATION.md)")),
     (("--batch-utts",), dict(default=32, type=int,
-                             help="[setk_amd] utterances enhanced per GPU batch")),
+                             help="[setk_amd] utterances enhanced per GPU batch (at most)")),
+    (("--batch-mb",), dict(default=80, type=int,
+                           help="[setk_amd] streaming pipeline: a batch also closes at this many MB of "
+                                "input (page-locked slab size; 0 = by --batch-utts alone)")),
     (("--device",), dict(default=-1, type=int,
                          help="[setk_amd] GPU ordinal (default: LOCAL_RANK or 0)")),
     (("--device-ingest",), dict(default=True, type=lambda v: str(v).lower() in ("true", "1", "yes"),
@@ -387,7 +390,7 @@ def _run_pipeline(args, engine, writer, wav_reader, tgt, itf, keys):
             writer.record(key, dst)
         return True
 
-    pipe = StreamPipeline(engine, sink, announce=announce, batch_utts=args.batch_utts,
+    pipe = StreamPipeline(engine, sink, announce=announce, batch_utts=args.batch_utts, batch_mb=args.batch_mb,
                           depth=args.pipeline_depth, read_threads=args.read_threads or None,
                           zero_copy=args.zero_copy, h2d=args.h2d)
     import time
