@@ -21,6 +21,7 @@
 #include "mcdft.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace setk {
 
@@ -86,12 +87,26 @@ SETK_DEV void load_raw_mc2(float (&v)[8], FloatPtr x, int n_samp, int s, int lan
 #ifndef SETK_P2MC_PCM_CARRY
 #define SETK_P2MC_PCM_CARRY 1
 #endif
+// float32 form: the same carry for the first SETK_P2MC_F32_CARRY_CH channels only (16 bytes per
+// lane and channel: four channels are the 4 KB per wave that fit), 1024-thread workgroups; 0 = the
+// two-workgroup form without a carry -- the default: with 4 the 8-channel kernel holds two load
+// paths (24 spilled registers) and measured 6.6 % SLOWER in stage 3 at MORE traffic (1.37 x against
+// 1.31 x; profiles/rejected/round6_pass2_f32_partial_carry_ab.txt)
+#ifndef SETK_P2MC_F32_CARRY_CH
+#define SETK_P2MC_F32_CARRY_CH 0
+#endif
 struct False { static constexpr bool value = false; };
 struct True { static constexpr bool value = true; };
 constexpr int kP2McThreads = SETK_P2MC_THREADS;
 constexpr int kP2McPcmThreads = SETK_P2MC_PCM_THREADS;
 constexpr bool kP2McPcmCarry = SETK_P2MC_PCM_CARRY != 0;
-constexpr int p2mc_threads(bool pcm) { return pcm ? kP2McPcmThreads : kP2McThreads; }
+constexpr int kP2McF32CarryCh = SETK_P2MC_F32_CARRY_CH;
+constexpr int p2mc_threads(bool pcm) { return pcm ? kP2McPcmThreads : (kP2McF32CarryCh > 0 ? 1024 : kP2McThreads); }
+// channels whose group-boundary half frame a wave carries through LDS, and the bytes per lane
+constexpr int p2mc_carry_ch(int C, bool pcm) {
+    return pcm ? (kP2McPcmCarry ? C : 0) : (C < kP2McF32CarryCh ? C : kP2McF32CarryCh);
+}
+constexpr int p2mc_carry_bytes(bool pcm) { return pcm ? 8 : 16; }
 
 constexpr int kP2McTiles = SETK_P2MC_KLDS ? (SETK_P2MC_WLDS ? 25 : 20) : 12;  // BR_H .. IT_L (10 tiles, contiguous words) + OT_H, OT_L + the forward's 8
 // LDS plan (bytes): wtab C * 257 * 8 | operand tiles 25 * 1024 | synthesis rows
@@ -101,7 +116,7 @@ size_t pass2_mc_lds_bytes(int C, bool pcm) {
     const size_t nw = p2mc_threads(pcm) / 64;
     const size_t wt = ((size_t)C * kBins * sizeof(cf) + 15) & ~(size_t)15;
     return wt + kP2McTiles * 1024 + 2048 + nw * SETK_P2MC_GROUP * 8 * mc::kOddPitch * sizeof(float) +
-           nw * 16 * sizeof(float) + 64 + ((pcm && kP2McPcmCarry) ? nw * C * 64 * 8 : 0);
+           nw * 16 * sizeof(float) + 64 + nw * p2mc_carry_ch(C, pcm) * 64 * p2mc_carry_bytes(pcm);
 }
 
 // sum over the first 8 lanes of every 16-lane row, result in lanes 0..7 of the row
@@ -149,7 +164,9 @@ __global__ __launch_bounds__(p2mc_threads(PCM), SETK_P2MC_WAVES_PER_SIMD) void b
     constexpr int NT = p2mc_threads(PCM);
     constexpr int NW = NT / 64;
     constexpr int F = kBins;
-    constexpr bool CARRY = PCM && kP2McPcmCarry;
+    constexpr int CC = p2mc_carry_ch(C, PCM);   // channels 0 .. CC - 1 are carried
+    constexpr bool CARRY = CC > 0;
+    typedef typename std::conditional<PCM, uint2, mc::f4>::type carry_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* p = smem;
@@ -165,7 +182,7 @@ __global__ __launch_bounds__(p2mc_threads(PCM), SETK_P2MC_WAVES_PER_SIMD) void b
     p += NW * 16 * sizeof(float);
     float* red = reinterpret_cast<float*>(p);
     p += 64;
-    uint2* carry_s = reinterpret_cast<uint2*>(p);  // [NW][C][64] packed int16 x 4 (CARRY only)
+    carry_t* carry_s = reinterpret_cast<carry_t*>(p);  // [NW][CC][64]: packed int16 x 4 / float x 4
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -276,27 +293,35 @@ __global__ __launch_bounds__(p2mc_threads(PCM), SETK_P2MC_WAVES_PER_SIMD) void b
     };
     // CARRY: the lane's own four samples of the half frame a group ends with, per channel -- a
     // thread reads back exactly what it wrote (program order suffices, no barrier)
-    uint2* carry_l = carry_s + (size_t)wave * C * 64 + lane;  // + 64 c
+    carry_t* carry_l = carry_s + (size_t)wave * CC * 64 + lane;  // + 64 c
     auto load_full = [&](float (&v)[8], int t, int c, auto edge, bool first) __attribute__((always_inline)) {
         (void)first;
         if constexpr (CARRY) {
             // first half: what this lane parked at the end of the previous group (or the prefill
             // before the first); second half: the only samples of the frame not seen yet
-            const uint2 pk = carry_l[64 * c];
-            v[0] = (float)(short)(pk.x & 0xffff);
-            v[1] = (float)((int)pk.x >> 16);
-            v[2] = (float)(short)(pk.y & 0xffff);
-            v[3] = (float)((int)pk.y >> 16);
-            const auto x = chan(c);
-            const int s0 = min(t, T - 1) * hop - a.g.pad + 256, o = 64 * g + c16;
-            if (!decltype(edge)::value) {
+            if (CC == C || c < CC) {
+                if constexpr (PCM) {
+                    const uint2 pk = carry_l[64 * c];
+                    v[0] = (float)(short)(pk.x & 0xffff);
+                    v[1] = (float)((int)pk.x >> 16);
+                    v[2] = (float)(short)(pk.y & 0xffff);
+                    v[3] = (float)((int)pk.y >> 16);
+                } else {
+                    const mc::f4 pk = carry_l[64 * c];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 + e] = x[s0 + o + 16 * e];
-            } else {
+                    for (int e = 0; e < 4; ++e) v[e] = pk[e];
+                }
+                const auto x = chan(c);
+                const int s0 = min(t, T - 1) * hop - a.g.pad + 256, o = 64 * g + c16;
+                if (!decltype(edge)::value) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 + e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
+                    for (int e = 0; e < 4; ++e) v[4 + e] = x[s0 + o + 16 * e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 + e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
+                }
+                return;
             }
-            return;
         }
 #ifdef SETK_P2MC_ABL_L2  // ablation: every wave reads the same 1 MB (L2 resident) -- wrong results
         gcfloat_p x = gptr(a.utts[0].audio) + (size_t)c * n_samp;
@@ -424,7 +449,7 @@ __global__ __launch_bounds__(p2mc_threads(PCM), SETK_P2MC_WAVES_PER_SIMD) void b
                 // what comes next travels while this transform runs: the second half of the
                 // next frame of the group, or the first frame of the next channel / group
                 if (k + 1 < R) {
-                    if constexpr (CARRY) load_half_raw(nraw, t0 + k + 1, c, edge);
+                    if constexpr (CARRY && PCM) load_half_raw(nraw, t0 + k + 1, c, edge);
                     else load_half(nxt, t0 + k + 1, c, edge);
                 } else if (c + 1 < C) {
                     load_full(nxt, t0, c + 1, edge, first_next);
@@ -462,15 +487,19 @@ __global__ __launch_bounds__(p2mc_threads(PCM), SETK_P2MC_WAVES_PER_SIMD) void b
 #if SETK_P2MC_PF2
                         x[4 + e] = xh[e];
 #else
-                        if constexpr (CARRY) x[4 + e] = (float)nraw[e];
+                        if constexpr (CARRY && PCM) x[4 + e] = (float)nraw[e];
                         else x[4 + e] = nxt[4 + e];
 #endif
                     }
                     if constexpr (CARRY) {
                         // the group's last half frame is the next group's first: R == 2, k == 0
                         static_assert(!CARRY || R == 2, "the LDS carry is written for groups of two frames");
-                        carry_l[64 * c] = make_uint2(__builtin_amdgcn_perm((unsigned)nraw[1], (unsigned)nraw[0], 0x05040100u),
-                                                     __builtin_amdgcn_perm((unsigned)nraw[3], (unsigned)nraw[2], 0x05040100u));
+                        if constexpr (PCM) {
+                            carry_l[64 * c] = make_uint2(__builtin_amdgcn_perm((unsigned)nraw[1], (unsigned)nraw[0], 0x05040100u),
+                                                         __builtin_amdgcn_perm((unsigned)nraw[3], (unsigned)nraw[2], 0x05040100u));
+                        } else if (CC == C || c < CC) {
+                            carry_l[64 * c] = (mc::f4){nxt[4], nxt[5], nxt[6], nxt[7]};
+                        }
                     }
                 }
                 // one transform at a time: interleaved by the scheduler, the R unrolled
@@ -501,14 +530,21 @@ __global__ __launch_bounds__(p2mc_threads(PCM), SETK_P2MC_WAVES_PER_SIMD) void b
         // half frames per channel from HBM, never three
         if (tw < tb) {
 #pragma unroll 1
-            for (int c = 0; c < C; ++c) {
+            for (int c = 0; c < CC; ++c) {
                 const auto x = chan(c);
                 const int s0 = tw * hop - a.g.pad, o = 64 * g + c16;
-                int r[4];
+                if constexpr (PCM) {
+                    int r[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
-                carry_l[64 * c] = make_uint2(__builtin_amdgcn_perm((unsigned)r[1], (unsigned)r[0], 0x05040100u),
-                                             __builtin_amdgcn_perm((unsigned)r[3], (unsigned)r[2], 0x05040100u));
+                    for (int e = 0; e < 4; ++e) r[e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
+                    carry_l[64 * c] = make_uint2(__builtin_amdgcn_perm((unsigned)r[1], (unsigned)r[0], 0x05040100u),
+                                                 __builtin_amdgcn_perm((unsigned)r[3], (unsigned)r[2], 0x05040100u));
+                } else {
+                    mc::f4 r;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] = x[reflect_index(s0 + o + 16 * e, n_samp)];
+                    carry_l[64 * c] = r;
+                }
             }
         }
     }

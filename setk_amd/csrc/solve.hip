@@ -799,7 +799,9 @@ __global__ __launch_bounds__(64, (C > 8) ? 1 : SETK_SOLVE_WAVES) void solve_kern
 // against the unmodified reference (tests/golden/ref_skipset.json), is the decision per
 // utterance.
 // ---------------------------------------------------------------------------
+// CM: the matrix the thread's (scratch) arrays are sized for -- 4, 8 or 16 >= num_channels
 #pragma clang fp contract(off)
+template <int CM>
 __global__ __launch_bounds__(64) void lu_refusal_kernel(SolveArgs a, int pitch, int which) {
     const int C = a.num_channels, F = a.num_bins;
     const int NP = npairs(C);
@@ -807,7 +809,7 @@ __global__ __launch_bounds__(64) void lu_refusal_kernel(SolveArgs a, int pitch, 
     const long prob = (long)blockIdx.x * 64 + threadIdx.x;
     if (prob >= n_prob) return;
     const int u = (int)(prob / F), f = (int)(prob % F);
-    float ar[kMaxChannels16][kMaxChannels16], ai[kMaxChannels16][kMaxChannels16];
+    float ar[CM][CM], ai[CM][CM];
     const bool fused = a.partials != nullptr;
     const size_t slab = (size_t)(4 * NP + 2) * pitch;
     const float* base = a.covar + (size_t)u * a.planes * pitch + f;
@@ -963,8 +965,10 @@ hipError_t launch_solve(const SolveArgs& a, hipStream_t s) {
          a.kind == SETK_BF_MPDR_WHITEN)) {
         // the matrix the reference's numpy.linalg.solve factors: Rn (MVDR, PMWF), Ry (MPDR)
         const int which = (a.kind == SETK_BF_MVDR || a.kind == SETK_BF_PMWF) ? 1 : 2;
-        hipLaunchKernelGGL(lu_refusal_kernel, dim3((unsigned)((n_prob + 63) / 64)), dim3(64), 0, s, a,
-                           pitch, which);
+        const dim3 grid((unsigned)((n_prob + 63) / 64));
+        if (a.num_channels <= 4) hipLaunchKernelGGL(lu_refusal_kernel<4>, grid, dim3(64), 0, s, a, pitch, which);
+        else if (a.num_channels <= 8) hipLaunchKernelGGL(lu_refusal_kernel<8>, grid, dim3(64), 0, s, a, pitch, which);
+        else hipLaunchKernelGGL(lu_refusal_kernel<kMaxChannels16>, grid, dim3(64), 0, s, a, pitch, which);
         e = hipGetLastError();
     }
     return e;

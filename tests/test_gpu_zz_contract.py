@@ -89,7 +89,7 @@ def test_bench_contract_single_rank():
     assert "error" not in e2e, e2e
     assert e2e["sizes"]["6"]["written"] == [6, 6]
     # the flat scalars: at the top level and inside the contract's roofline object
-    for k in ("stage1_ms", "stage3_ms", "pcm16_from_frames_ms_per_step", "pcm16_from_frames_value",
+    for k in ("stage1_ms", "stage3_ms", "steady_state_ms_per_step", "pcm16_from_frames_ms_per_step", "pcm16_from_frames_value",
               "pcm16_from_frames_roofline_frac", "pass2_traffic_over_algorithmic", "e2e_process_rtf"):
         assert k in one and k in roof, k
         assert one[k] == roof[k]
@@ -106,9 +106,9 @@ def test_bench_contract_aux_legs():
     assert one["sustained"]["steps"] >= 50 and one["uncached_call"]["ms_per_step"] > 0
     e2e = one["end_to_end"]
     assert "error" not in e2e, e2e
-    assert e2e["sizes"]["6"]["written"] == [6, 6, 6] and e2e["sizes"]["48"]["written"] == [48, 48, 48]
+    assert e2e["sizes"]["6"]["written"] == [6, 6, 6] and e2e["sizes"]["96"]["written"] == [96] * 5
     for k in ("median", "min", "max", "spread"):
-        assert k in e2e["sizes"]["48"]["process_rtf"]
+        assert k in e2e["sizes"]["96"]["process_rtf"] and k in e2e["marginal_GBps_in"]
     assert e2e["host_copy_GBps"]["1"] > 0
     assert one["roofline"]["pmc"] is None and one["roofline"]["traffic"] is None   # --pmc 0
 

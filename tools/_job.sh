@@ -1,14 +1,20 @@
 export TMPDIR=/tmp
-O=gpurun_out/round6_d; mkdir -p $O
-for r in 1 2; do for L in default _abl/libsetk_cgr5.so; do
+O=gpurun_out/round6_e; mkdir -p $O
+for r in 1 2 3; do for L in default _abl/libsetk_p2f32nc.so; do
   if [ "$L" = default ]; then unset SETK_LIB; else export SETK_LIB=$PWD/$L; fi
-  echo "CGMM round $r $L: $(timeout 300 python tools/bench_cgmm.py --utts 125 --channels 6 --seconds 30 --iters 20 --steps 5 2>&1 | tail -1)"
-done; done 2>&1 | tee $O/cgmm_solve_ab.txt
+  python bench.py --steps 100 --warmup 30 --cpu-sample 0 --full-batch 0 --e2e-utts 0 --int16-ingest 0 2>/dev/null | tail -1 > /tmp/ab.json
+  python - "$L" $r <<'PY'
+import json, sys
+d = json.load(open("/tmp/ab.json"))
+p2 = d["roofline"].get("pass2", {})
+print(f"AB round {sys.argv[2]} {sys.argv[1]}: step {d['ms_per_step']} stages {d['stage_ms']} pass2 traffic/alg {d.get('pass2_traffic_over_algorithmic')} "
+      f"frac {d['roofline']['frac']}")
+PY
+done; done 2>&1 | tee $O/ab_f32_carry.txt
 unset SETK_LIB
-SETK_LIB=$PWD/_abl/libsetk_cgphases.so SETK_CGMM_TIMING=$PWD/$O/timing_phases.txt timeout 300 python tools/bench_cgmm.py --utts 125 --channels 6 --seconds 30 --iters 20 --steps 1 > /dev/null
-SETK_CGMM_TIMING=$PWD/$O/timing_product.txt timeout 300 python tools/bench_cgmm.py --utts 125 --channels 6 --seconds 30 --iters 20 --steps 1 > /dev/null
-python tools/cgmm_phases.py $O/timing_phases.txt $O/timing_product.txt | tee $O/phases.md
-timeout 600 python -m pytest tests/test_gpu_cgmm.py -q -x -m gpu -p no:cacheprovider 2>&1 | tail -3 | tee $O/pytest_cgmm.txt
-for B in 4 8 12 16; do timeout 300 python tools/e2e_fixed.py --reps 3 --extra "--batch-utts $B" 2>&1 | grep "^#" | sed "s/^/192 files, batch-utts $B: /"; done | tee $O/e2e_batch_utts.txt
-for B in 4 8 12 16 32; do timeout 600 python tools/e2e_fixed.py --utts 1536 --reps 3 --extra "--batch-utts $B" 2>&1 | grep "^#" | sed "s/^/1536 files, batch-utts $B: /"; done | tee -a $O/e2e_batch_utts.txt
-for B in 8 16 32 64; do timeout 600 python tools/e2e_fixed.py --utts 2048 --seconds 10 --reps 3 --extra "--batch-utts $B" 2>&1 | grep "^#" | sed "s/^/2048 files of 10 s, batch-utts $B: /"; done | tee -a $O/e2e_batch_utts.txt
+for L in default _abl/libsetk_p2f32nc.so; do
+  if [ "$L" = default ]; then unset SETK_LIB; else export SETK_LIB=$PWD/$L; fi
+  echo "bits $L"; timeout 300 python tools/ab_bits.py 2>&1 | tail -8
+done | tee $O/ab_bits.txt
+unset SETK_LIB
+timeout 900 python -m pytest tests/test_gpu_enhance.py tests/test_gpu_baseline_sizes.py tests/test_gpu_api.py -q -x -m gpu -p no:cacheprovider 2>&1 | tail -3 | tee $O/pytest.txt

@@ -19,7 +19,7 @@ import json
 rec = json.loads([l for l in open("$O/bench_aux.json") if l.startswith("{")][-1])
 print(json.dumps({k: v for k, v in rec.items() if not isinstance(v, (dict, list))}))
 e = rec.get("end_to_end", {})
-print("e2e:", {k: e.get(k) for k in ("process_rtf", "process_wall_s", "process_rtf_8n", "marginal_GBps_in", "marginal_ms_per_utt", "error")})
+print("e2e:", {k: e.get(k) for k in ("process_rtf", "process_wall_s", "process_rtf_16n", "marginal_GBps_in", "marginal_ms_per_utt", "error")})
 for k, v in (rec.get("other_configs") or {}).items():
     if isinstance(v, dict) and "ms_per_step" in v: print(k, v["ms_per_step"], v.get("value"))
 print("power:", rec.get("power")); print("cpu all cores:", (rec.get("cpu_baseline") or {}).get("all_cores"))
