@@ -492,14 +492,20 @@ def test_streaming_pipeline_equals_batch_path(tmp_path):
     e = run(f"{td}/mm", "numpy", f"{td}/mask.scp", env={"SETK_READ_MODE": "mmap"})
     f = run(f"{td}/pr", "numpy", f"{td}/mask.scp", env={"SETK_READ_MODE": "preadv"})
     g = run(f"{td}/nm", "numpy", f"{td}/mask.scp", "--h2d", "payload", env={"SETK_MMAP_MIN_KB": "4"})
+    # batches closed by bytes (--batch-mb, round 6) instead of by count: other batch boundaries
+    h = run(f"{td}/mb", "numpy", f"{td}/mask.scp", "--batch-utts", "32", "--batch-mb", "1", "--profile",
+            f"{td}/prof_mb.json")
     assert not os.path.exists(f"{td}/pipe/utt8.wav")
     for k, ref in refs.items():
         assert a[k].dtype == np.int16 and np.array_equal(a[k], b[k]), k
         assert np.array_equal(a[k], c[k]) and np.array_equal(a[k], d[k]), k
         assert np.array_equal(a[k], e[k]) and np.array_equal(a[k], f[k]) and np.array_equal(a[k], g[k]), k
         assert pcm16_rel_rms(a[k], ref) < 1e-3, (k, pcm16_rel_rms(a[k], ref))
+        assert pcm16_rel_rms(h[k], ref) < 1e-3 and np.max(np.abs(h[k].astype(np.int32) - a[k].astype(np.int32))) <= 1, k
     import json
     prof = json.load(open(f"{td}/prof.json"))
+    mb = json.load(open(f"{td}/prof_mb.json"))["stages"]
+    assert mb["batch_mb"] == 1 and mb["batches"] >= 3 and "marks" in prof   # (1 MB closes the first batch after six utterances; the 2-channel one splits the rest)
     assert prof["mode"] == "pipeline" and prof["utts"] == 8 and prof["stages"]["batches"] >= 3
     assert prof["stages"]["read_mode"] == "native"
     # --zero-copy: PCM16 wavs and float32 C-ordered masks leave the page cache without a host copy

@@ -108,7 +108,10 @@ def test_bench_contract_aux_legs():
     assert "error" not in e2e, e2e
     assert e2e["sizes"]["6"]["written"] == [6, 6, 6] and e2e["sizes"]["96"]["written"] == [96] * 5
     for k in ("median", "min", "max", "spread"):
-        assert k in e2e["sizes"]["96"]["process_rtf"] and k in e2e["marginal_GBps_in"]
+        assert k in e2e["sizes"]["96"]["process_rtf"]
+    # (the marginal rate is a difference of two process clocks: present, and None when these
+    #  miniature sizes drown in the noise -- its VALUE is never asserted)
+    assert "marginal_GBps_in" in e2e and "marginal_ms_per_utt" in e2e
     assert e2e["host_copy_GBps"]["1"] > 0
     assert one["roofline"]["pmc"] is None and one["roofline"]["traffic"] is None   # --pmc 0
 

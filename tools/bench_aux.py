@@ -31,8 +31,7 @@ def issue_rates_leg():
     pinned instruction streams (tools/ubench/valu_rate3 --fma-only, ~1 s; built on demand)."""
     import re
     import subprocess
-    here = os.path.dirname(os.path.abspath(__file__))
-    exe = os.path.join(here, "tools", "ubench", "valu_rate3")
+    exe = os.path.join(ROOT, "tools", "ubench", "valu_rate3")
     src = exe + ".hip"
     try:
         if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
@@ -458,10 +457,11 @@ def end_to_end(args, C, N, full=False):
             out["process_rtf_16n"] = out["sizes"][str(n2)]["process_rtf"]["median"]
             w1 = out["sizes"][str(n1)]["wall_s_process"]["median"]
             dms = [(w2 - w1) / (n2 - n1) for w2 in walls[n2]]
-            if min(dms) > 0:
-                out["marginal_ms_per_utt"] = stats([1e3 * dm for dm in dms])
-                out["marginal_GBps_in"] = stats([in_bytes / dm / 1e9 for dm in dms])
-                out["marginal_value"] = stats([(N / SR) / dm for dm in dms])
+            # (None when a difference of two process clocks is not positive: sizes too small for the noise)
+            ok = min(dms) > 0
+            out["marginal_ms_per_utt"] = stats([1e3 * dm for dm in dms]) if ok else None
+            out["marginal_GBps_in"] = stats([in_bytes / dm / 1e9 for dm in dms]) if ok else None
+            out["marginal_value"] = stats([(N / SR) / dm for dm in dms]) if ok else None
             # what the host can copy at all (threads -> GB/s): the input bytes are copied once
             # from the page cache into page-locked slabs before the DMA
             out["host_copy_GBps"] = host_copy_rate()
