@@ -2,6 +2,7 @@
 # The rocprofv3 evidence behind the bench line, one lease:  bash tools/gpu_profile.sh <tag>
 #   gpurun_out/<tag>/cfg2_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the driver's bench command
 #                                               (float32 and PCM16 forms of both streaming kernels, the de-interleave)
+#   gpurun_out/<tag>/cfg{1,3}_kernel_stats.csv  the same command at configs[1] (4-ch 10 s x 500) and configs[3] (8-ch GEV)
 #   gpurun_out/<tag>/cfg4_kernel_stats.csv      the same for configs[4] (tools/bench_cgmm.py)
 #   gpurun_out/<tag>/bench_aux.json             python bench.py --aux 1 (every leg)
 TAG=${1:-prof}; O=gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
@@ -10,7 +11,11 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- $B
 cp $(find $O/kt2 -name "*kernel_stats.csv" | head -1) $O/cfg2_kernel_stats.csv
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt4 -- python tools/bench_cgmm.py --utts 125 --channels 6 --seconds 30 --iters 20 --steps 3 > $O/kt4.log 2>&1
 cp $(find $O/kt4 -name "*kernel_stats.csv" | head -1) $O/cfg4_kernel_stats.csv
-rm -rf $O/kt2 $O/kt4
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- $B --channels 4 --seconds 10 --utts 500 > $O/kt1.log 2>&1
+cp $(find $O/kt1 -name "*kernel_stats.csv" | head -1) $O/cfg1_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- $B --beamformer gevd > $O/kt3.log 2>&1
+cp $(find $O/kt3 -name "*kernel_stats.csv" | head -1) $O/cfg3_kernel_stats.csv
+rm -rf $O/kt1 $O/kt2 $O/kt3 $O/kt4
 head -8 $O/cfg2_kernel_stats.csv | cut -c1-200
 ( time timeout 1500 python bench.py --aux 1 ) > $O/bench_aux.json 2> $O/bench_aux.err
 tail -4 $O/bench_aux.err
