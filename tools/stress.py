@@ -58,8 +58,28 @@ def main():
         st = ctx.enhance_batch(opts, C, [t.data_ptr() for t in a], lens, [t.data_ptr() for t in m], None,
                                [t.data_ptr() for t in outs])
         torch.cuda.synchronize()
+        pcm_note = ""
+        if hop == 256:
+            # the 16-bit PCM form of both streaming kernels (SETK_FLAG_IN_PCM16; pass 2 with its LDS carry)
+            # must equal the float32 call on pcm / 32768 bit for bit, whatever the ragged lengths
+            frames = [torch.clamp(torch.round(t.T * 32767.0), -32768, 32767).to(torch.int16).contiguous() for t in a]
+            f32q = [(q.T.to(torch.float32) / 32768.0).contiguous() for q in frames]
+            planar = [torch.zeros((C, ctx.pcm16_channel_stride(N)), dtype=torch.int16, device=dev) for N in lens]
+            ctx.pcm16_deinterleave_batch(C, [q.data_ptr() for q in frames], lens, [p.data_ptr() for p in planar])
+            o_pcm = [torch.empty_like(w) for w in outs]
+            o_f32 = [torch.empty_like(w) for w in outs]
+            po = _ffi.BfOpts(flags=_ffi.FLAG_CLAMP_MASK | _ffi.FLAG_IN_PCM16, **okw)
+            st_p = ctx.enhance_batch(po, C, [p.data_ptr() for p in planar], lens, [t.data_ptr() for t in m], None,
+                                     [t.data_ptr() for t in o_pcm])
+            st_f = ctx.enhance_batch(opts, C, [t.data_ptr() for t in f32q], lens, [t.data_ptr() for t in m], None,
+                                     [t.data_ptr() for t in o_f32])
+            torch.cuda.synchronize()
+            same = list(st_p) == list(st_f) and all(bool(torch.equal(x, y)) for x, y in zip(o_pcm, o_f32))
+            pcm_note = "   pcm16 == f32 bit for bit" if same else "   <-- CHECK: pcm16 form differs from the float32 call"
+            if not same:
+                worst = max(worst, 1.0)
         errs = []
-        note = ""
+        note = pcm_note
         for i, (w, r, s) in enumerate(zip(outs, refs, st)):
             w = w.cpu().numpy()
             assert w.shape == r.shape, (w.shape, r.shape)
