@@ -261,6 +261,22 @@ int setk_pcm16_deinterleave_batch(setk_handle_t h, int n_utts, int num_channels,
                                   const int16_t* const* pcm, const int* num_samples,
                                   int16_t* const* out, double* power0, void* stream);
 
+/* Kaldi CompressedMatrix bodies -> float32 matrices on the device, a batch per launch: the masks
+ * of the streaming command line travel as the 1 - 2 bytes per element the archive holds.
+ * Replaces `uncompress` (scripts/sptk/libs/kaldi_io.py:248-292; formats CM / CM2 / CM3 =
+ * kOneByteWithColHeaders / kTwoByte / kOneByte) with the same float32 operations in the same
+ * order: results equal numpy's bit for bit.  Per matrix i: kinds[i] (SETK_KALDI_CM..CM3), the global
+ * header's (vmin, vrange, rows, cols), src[i] = the bytes that follow that 16-byte header (CM: the
+ * per-column headers, then the column-major bytes), dst[i] = rows x cols float32 row-major -- or, with
+ * transpose[i] != 0, cols x rows: the transpose (a mask stored F x T, apply_adaptive_beamformer.py:
+ * 146-151).  Device pointers (CM / CM2 bodies 2-byte aligned), host tables, asynchronous on `stream`. */
+#define SETK_KALDI_CM 1
+#define SETK_KALDI_CM2 2
+#define SETK_KALDI_CM3 3
+int setk_kaldi_cm_decode_batch(setk_handle_t h, int n, const int* kinds, const float* vmin, const float* vrange,
+                               const int* rows, const int* cols, const int* transpose,
+                               const void* const* src, float* const* dst, void* stream);
+
 /* The way back for a multi-channel result (apply_wpe.py:58-61 -> write_wav,
  * libs/utils.py:45-62 -> soundfile.write, float -> PCM_16): float32 rows audio[C][N] ->
  * interleaved frames pcm[N][C], lrint(x * 32767) without clipping (libsndfile's default;

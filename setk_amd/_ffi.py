@@ -110,7 +110,7 @@ def exported_symbols():
         "setk_host_register", "setk_host_unregister", "setk_memcpy_h2d_async",
         "setk_stft_plan", "setk_stft_num_frames", "setk_istft_num_samples",
         "setk_stft", "setk_stft_batch", "setk_istft", "setk_covar", "setk_pevd", "setk_weights",
-        "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_pcm16_channel_stride", "setk_pcm16_deinterleave_batch", "setk_float_to_pcm16", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks", "setk_cgmm_masks_k", "setk_cgmm_masks_k_status",
+        "setk_pcm16_to_float", "setk_pcm16_to_float_batch", "setk_pcm16_channel_stride", "setk_pcm16_deinterleave_batch", "setk_kaldi_cm_decode_batch", "setk_float_to_pcm16", "setk_ban", "setk_rank1", "setk_beamform", "setk_cgmm_masks", "setk_cgmm_masks_k", "setk_cgmm_masks_k_status",
         "setk_cgmm_masks_batch", "setk_cgmm_estimate_batch", "setk_enhance_batch", "setk_enhance_batch_taps",
         "setk_apply_weights_batch",
         "setk_directional_feats", "setk_wpe", "setk_wpe_step", "setk_wpe_batch", "setk_wpe_batch_fnt", "setk_wpe_batch_var", "setk_set_profiling",
@@ -183,6 +183,9 @@ def load_library():
                                                   POINTER(c_void_p), c_void_p, c_void_p]
     lib.setk_pcm16_to_float_batch.argtypes = [H, c_int, c_int, POINTER(c_void_p), POINTER(c_int),
                                               POINTER(c_void_p), c_void_p, c_void_p]
+    lib.setk_kaldi_cm_decode_batch.argtypes = [H, c_int, POINTER(c_int), POINTER(c_float), POINTER(c_float),
+                                               POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                               POINTER(c_void_p), POINTER(c_void_p), c_void_p]
     lib.setk_rank1.argtypes = [H, fp, fp, c_int, c_int, fp, fp, c_void_p]
     lib.setk_beamform.argtypes = [H, fp, fp, c_int, c_int, c_int, fp, c_void_p]
     lib.setk_cgmm_masks.argtypes = [H, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, c_void_p]
@@ -502,6 +505,25 @@ class Context:
             self._lib.setk_pcm16_deinterleave_batch(
                 self._h, n, int(C), P, NS, O, _ptr(power0),
                 current_stream_ptr() if stream is None else stream))
+
+    def kaldi_cm_decode_batch(self, items, stream=None):
+        """Kaldi CompressedMatrix bodies -> float32 matrices on the device, ONE launch.  items:
+        (kind 'CM' | 'CM2' | 'CM3', vmin, vrange, rows, cols, transpose, src address, dst address);
+        the bytes at src are what follows the archive's 16-byte global header (libs/kaldi_io.py
+        `uncompress`: same float32 operations, same results bit for bit)."""
+        n = len(items)
+        code = {"CM": 1, "CM2": 2, "CM3": 3}
+        K = (c_int * n)(*[code[it[0]] for it in items])
+        VMIN = (c_float * n)(*[float(it[1]) for it in items])
+        VRNG = (c_float * n)(*[float(it[2]) for it in items])
+        R = (c_int * n)(*[int(it[3]) for it in items])
+        Cc = (c_int * n)(*[int(it[4]) for it in items])
+        TR = (c_int * n)(*[int(bool(it[5])) for it in items])
+        S = (c_void_p * n)(*[int(it[6]) for it in items])
+        D = (c_void_p * n)(*[int(it[7]) for it in items])
+        self.check(self._lib.setk_kaldi_cm_decode_batch(
+            self._h, n, K, VMIN, VRNG, R, Cc, TR, S, D,
+            current_stream_ptr() if stream is None else stream))
 
     def ban(self, weight, Rn, F, C, out, stream=None):
         self.check(

@@ -1245,6 +1245,33 @@ int setk_pcm16_deinterleave_batch(setk_handle_t h, int n_utts, int num_channels,
     return SETK_OK;
 }
 
+int setk_kaldi_cm_decode_batch(setk_handle_t h, int n, const int* kinds, const float* vmin, const float* vrange,
+                               const int* rows, const int* cols, const int* transpose,
+                               const void* const* src, float* const* dst, void* stream) {
+    if (!h || n <= 0 || !kinds || !vmin || !vrange || !rows || !cols || !src || !dst)
+        return fail(h, SETK_ERR_INVALID, "bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    arena_reset(h, s);
+    std::vector<char> tbl(cm_item_bytes() * n);
+    long max_elems = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!src[i] || !dst[i] || rows[i] <= 0 || cols[i] <= 0) return fail(h, SETK_ERR_INVALID, "null or empty matrix");
+        if (kinds[i] < SETK_KALDI_CM || kinds[i] > SETK_KALDI_CM3)
+            return fail(h, SETK_ERR_UNSUPPORTED, "compressed matrix kind: 1 (CM), 2 (CM2) or 3 (CM3)");
+        if (kinds[i] != SETK_KALDI_CM3 && (reinterpret_cast<uintptr_t>(src[i]) & 1))
+            return fail(h, SETK_ERR_INVALID, "CM / CM2 bodies must be 2-byte aligned");
+        cm_item_fill(tbl.data(), i, src[i], dst[i], vmin[i], vrange[i], rows[i], cols[i], kinds[i],
+                     transpose ? transpose[i] : 0);
+        max_elems = std::max(max_elems, (long)rows[i] * cols[i]);
+    }
+    void* d_tbl;
+    int rc = upload(h, tbl.data(), tbl.size(), s, &d_tbl);
+    if (rc) return rc;
+    HIP_TRY(h, launch_kaldi_cm_decode_batch(d_tbl, n, max_elems, s));
+    return SETK_OK;
+}
+
 int setk_rank1(setk_handle_t h, const float* Rs, const float* Rn, int num_bins,
                int num_channels, float* out, int* status, void* stream) {
     if (!h || !Rs || !out || num_bins <= 0) return fail(h, SETK_ERR_INVALID, "bad args");

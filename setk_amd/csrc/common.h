@@ -225,6 +225,10 @@ hipError_t launch_pack_fixed_weights(const float* sets, const int* index, int n_
                                      float* out, hipStream_t s);
 hipError_t launch_float_to_pcm16(const float* in, int C, int N, int16_t* out, hipStream_t s);
 hipError_t launch_pcm16_to_float(const int16_t* pcm, int C, int N, float* out, hipStream_t s);
+size_t cm_item_bytes();
+void cm_item_fill(void* tbl, int i, const void* src, float* dst, float vmin, float vrange, int rows, int cols,
+                  int kind, int transpose);
+hipError_t launch_kaldi_cm_decode_batch(const void* d_items, int n, long max_elems, hipStream_t s);
 size_t pcm_item_bytes();
 void pcm_item_fill(void* dst, int i, const int16_t* pcm, float* out, int n);
 hipError_t launch_pcm16_to_float_batch(const void* d_items, int n_utts, int C, int max_n,

@@ -685,6 +685,81 @@ hipError_t launch_pcm16_deinterleave_batch(const void* d_items, int n_utts, int 
 }
 
 // ---------------------------------------------------------------------------
+// Kaldi CompressedMatrix bodies -> float32 masks [T][F], a batch per launch (the streaming CLI
+// ships a compressed mask as its 1 - 2 bytes per element instead of decoding it on the host to 4).
+// Replaces (funcwj/setk): `uncompress`, scripts/sptk/libs/kaldi_io.py:248-292 -- the same
+// float32 operations in the same order (no fused multiply-adds, IEEE division), so the result
+// equals numpy's bit for bit:
+//   CM  (kOneByteWithColHeaders): per column four uint16 percentiles p = u16 * range / 65535 + min,
+//        then one byte q per element, COLUMN-major: q <= 64: q (p25 - p0) / 64 + p0;
+//        q >= 193: (q - 192)(p100 - p75) / 63 + p75; else (q - 64)(p75 - p25) / 128 + p25
+//   CM2 (kTwoByte): min + u16 * float32(range / 65535.0), row-major;  CM3 (kOneByte): min + u8 * float32(range / 255.0)
+// transpose: the stored matrix is F x T (apply_adaptive_beamformer.py:146-151 turns it): the
+// output is its transpose.  One thread per output element; the bodies are 0.5 - 1 MB, L2 serves the
+// strided byte reads of the column-major form.
+// ---------------------------------------------------------------------------
+struct CmItem {
+    const unsigned char* src;
+    float* dst;
+    float vmin, vrange;
+    int rows, cols, kind, transpose;
+};
+size_t cm_item_bytes() { return sizeof(CmItem); }
+void cm_item_fill(void* tbl, int i, const void* src, float* dst, float vmin, float vrange, int rows, int cols,
+                  int kind, int transpose) {
+    CmItem* it = static_cast<CmItem*>(tbl) + i;
+    it->src = static_cast<const unsigned char*>(src);
+    it->dst = dst;
+    it->vmin = vmin;
+    it->vrange = vrange;
+    it->rows = rows;
+    it->cols = cols;
+    it->kind = kind;
+    it->transpose = transpose;
+}
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void kaldi_cm_decode_batch_kernel(const CmItem* __restrict__ items) {
+    const CmItem it = items[blockIdx.y];
+    const long n = (long)it.rows * it.cols;
+    const int ocols = it.transpose ? it.rows : it.cols;
+    const unsigned short* hdr = reinterpret_cast<const unsigned short*>(it.src);   // CM: [cols][4]
+    const unsigned char* body = it.src + (it.kind == 1 ? (size_t)8 * it.cols : 0);
+    const float step2 = (float)((double)it.vrange / 65535.0), step3 = (float)((double)it.vrange / 255.0);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int orow = (int)(i / ocols), ocol = (int)(i - (long)orow * ocols);
+        const int r = it.transpose ? ocol : orow, c = it.transpose ? orow : ocol;
+        float v;
+        if (it.kind == 1) {
+            const float p0 = (float)hdr[4 * c + 0] * it.vrange / 65535.0f + it.vmin;
+            const float p25 = (float)hdr[4 * c + 1] * it.vrange / 65535.0f + it.vmin;
+            const float p75 = (float)hdr[4 * c + 2] * it.vrange / 65535.0f + it.vmin;
+            const float p100 = (float)hdr[4 * c + 3] * it.vrange / 65535.0f + it.vmin;
+            const float q = (float)body[(size_t)c * it.rows + r];
+            if (q <= 64.f) v = q * (p25 - p0) / 64.0f + p0;
+            else if (q >= 193.f) v = (q - 192.f) * (p100 - p75) / 63.0f + p75;
+            else v = (q - 64.f) * (p75 - p25) / 128.0f + p25;
+        } else if (it.kind == 2) {
+            const float q = (float)reinterpret_cast<const unsigned short*>(body)[(size_t)r * it.cols + c];
+            v = it.vmin + q * step2;
+        } else {
+            const float q = (float)body[(size_t)r * it.cols + c];
+            v = it.vmin + q * step3;
+        }
+        it.dst[i] = v;
+    }
+}
+#pragma clang fp contract(fast)
+
+hipError_t launch_kaldi_cm_decode_batch(const void* d_items, int n, long max_elems, hipStream_t s) {
+    long bx = (max_elems + 256 * 4 - 1) / (256 * 4);
+    bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+    hipLaunchKernelGGL(kaldi_cm_decode_batch_kernel, dim3((unsigned)bx, n), dim3(256), 0, s,
+                       static_cast<const CmItem*>(d_items));
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Helpers of the fixed-weight path (apply_fixed_beamformer.py:38-48):
 // max |audio| per utterance (SpectrogramReader.maxabs, the renorm target) and
 // the reference's F x M weight sets -> the planar [C][264] layout of pass 2.

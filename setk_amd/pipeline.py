@@ -63,6 +63,11 @@ MMAP_MIN_BYTES = int(os.environ.get("SETK_MMAP_MIN_KB", "256")) << 10
 ALIGN = 256
 
 
+# SETK_CM_DEVICE=0: compressed Kaldi masks are decoded on the host (libs/kaldi_io.uncompress) as in
+# rounds 1 - 5 instead of on the device
+DEVICE_CM_DECODE = os.environ.get("SETK_CM_DEVICE", "1") != "0"
+
+
 def _align(n):
     return (n + ALIGN - 1) // ALIGN * ALIGN
 
@@ -102,11 +107,14 @@ class Payload(object):
     table in a multi-threaded process waits for an RCU grace period: 0.1 - 0.15 s each on the
     256-core host, tools/ubench/open_probe.py.)"""
 
-    __slots__ = ("path", "offset", "nbytes", "array", "fsize")
+    __slots__ = ("path", "offset", "nbytes", "array", "fsize", "cm")
 
-    def __init__(self, path=None, offset=0, nbytes=0, array=None, fsize=0):
+    def __init__(self, path=None, offset=0, nbytes=0, array=None, fsize=0, cm=None):
         self.path, self.offset, self.nbytes, self.array = path, offset, nbytes, array
         self.fsize = fsize  # size of the file (0: unknown -> staged path)
+        # a Kaldi CompressedMatrix body (kind, vmin, vrange, rows, cols): the bytes go up as stored
+        # and are expanded to float32 [T][F] on the device (setk_kaldi_cm_decode_batch)
+        self.cm = cm
 
     def zero_copy_ok(self):
         """The payload is (nearly) the whole file: worth pinning the file's pages."""
@@ -250,12 +258,35 @@ def probe_kaldi_matrix(files, path, offset):
     return rows, cols, np.dtype("<f4" if tok == b"FM " else "<f8"), offset + p + 10
 
 
+def probe_kaldi_compressed(files, path, offset):
+    """Binary Kaldi CompressedMatrix at `offset` -> (kind, vmin, vrange, rows, cols, body offset,
+    body bytes), or None.  Layout (libs/kaldi_io.py:295-318 of the reference): '\\0B', the token
+    'CM ' | 'CM2 ' | 'CM3 ', the global header <f32 min, f32 range, i32 rows, i32 cols>, the body."""
+    fd = files.get(path)
+    head = os.pread(fd, 40, offset)
+    p = 2 if head[:2] == b"\x00B" else 0
+    for tok, kind in ((b"CM2 ", "CM2"), (b"CM3 ", "CM3"), (b"CM ", "CM")):
+        if head[p:p + len(tok)] == tok:
+            p += len(tok)
+            break
+    else:
+        return None
+    if len(head) < p + 16:
+        return None
+    vmin, vrange, rows, cols = struct.unpack("<ffii", head[p:p + 16])
+    if rows <= 0 or cols <= 0:
+        return None
+    nbytes = {"CM": cols * (8 + rows), "CM2": 2 * rows * cols, "CM3": rows * cols}[kind]
+    return kind, vmin, vrange, rows, cols, offset + p + 16, nbytes
+
+
 # ----------------------------------------------------------------------------
 # one utterance of a batch
 # ----------------------------------------------------------------------------
 class Job(object):
     __slots__ = ("key", "C", "N", "T", "L", "pcm16", "audio", "mask", "itf", "off_audio",
-                 "off_mask", "off_itf", "off_f32", "off_out", "error", "power", "pw_idx")
+                 "off_mask", "off_itf", "off_f32", "off_out", "error", "power", "pw_idx",
+                 "off_mask_f32", "off_itf_f32")
 
     def __init__(self, key):
         self.key = key
@@ -431,6 +462,18 @@ class StreamPipeline(object):
             self._dispatch()
 
     def _mask_payload(self, m, T):
+        if isinstance(m, Payload) and m.cm is not None:
+            # (the shape rules of engine.condition_mask / apply_adaptive_beamformer.py:146-151)
+            rows, cols = m.cm[3], m.cm[4]
+            if rows == self.F and cols != self.F:
+                rows, cols = cols, rows
+            if cols != self.F:
+                raise ValueError("Input mask matrix should be shape as " +
+                                 f"[num_frames x num_bins], now is {(m.cm[3], m.cm[4])}")
+            if rows != T:
+                raise ValueError("Shape of input obs do not match with mask matrix, " +
+                                 f"{T} frames vs {(m.cm[3], m.cm[4])}")
+            return m
         if isinstance(m, Payload):
             if m.nbytes != T * self.F * 4:
                 raise ValueError("Shape of input obs do not match with mask matrix, " +
@@ -495,6 +538,11 @@ class StreamPipeline(object):
             j.off_f32 = f32
             if j.pcm16:
                 f32 = _align(f32 + (2 * j.C * ((j.N + 7) & ~7) if direct else 4 * j.C * j.N))
+            for p, name in ((j.mask, "off_mask_f32"), (j.itf, "off_itf_f32")):
+                setattr(j, name, None)
+                if p is not None and p.cm is not None:
+                    setattr(j, name, f32)          # the expanded mask lives in the device-only slab
+                    f32 = _align(f32 + 4 * j.T * self.F)
             j.off_out = out
             out = _align(out + 2 * j.L)
         n = len(batch)
@@ -648,9 +696,21 @@ class StreamPipeline(object):
                    [j.N for j in pcm], [base_f32 + j.off_f32 for j in pcm],
                    power0=base_out + off_power, stream=stream)
         tt.append(time.perf_counter())
+        # Kaldi CompressedMatrix masks: the archive's bytes came up as stored, expanded here
+        cms = []
+        for j in jobs:
+            for p, off_raw, off_f32 in ((j.mask, j.off_mask, j.off_mask_f32),
+                                        (j.itf, j.off_itf if j.itf is not None else 0, j.off_itf_f32)):
+                if p is not None and p.cm is not None:
+                    kind, vmin, vrange, rows, cols = p.cm
+                    cms.append((kind, vmin, vrange, rows, cols, rows == self.F and cols != self.F,
+                                base_in + off_raw, base_f32 + off_f32))
+        if cms:
+            ctx.kaldi_cm_decode_batch(cms, stream=stream)
         aptr = [(base_f32 + j.off_f32) if j.pcm16 else (base_in + j.off_audio) for j in jobs]
-        mptr = [base_in + j.off_mask for j in jobs]
-        iptr = [base_in + j.off_itf for j in jobs] if has_itf else None
+        mptr = [(base_in + j.off_mask) if j.off_mask_f32 is None else (base_f32 + j.off_mask_f32) for j in jobs]
+        iptr = [(base_in + j.off_itf) if j.off_itf_f32 is None else (base_f32 + j.off_itf_f32)
+                for j in jobs] if has_itf else None
         wptr = [base_out + j.off_out for j in jobs]
         kind = eng.opts_kw["kind"]
         if has_itf and kind == _ffi.BF_MPDR:
@@ -833,6 +893,10 @@ def mask_source(reader, key, files, num_bins, lock=None):
             if hit and hit[2] == np.dtype("<f4") and hit[1] == num_bins:
                 return Payload(path=path, offset=hit[3], nbytes=4 * hit[0] * hit[1],
                                fsize=os.fstat(files.get(path)).st_size)
+            if hit is None and DEVICE_CM_DECODE:
+                cm = probe_kaldi_compressed(files, path, offset)
+                if cm and num_bins in (cm[3], cm[4]):
+                    return Payload(path=path, offset=cm[5], nbytes=cm[6], cm=cm[:5])
     except (OSError, ValueError, KeyError, SyntaxError):
         pass
     with lock or _NO_LOCK:

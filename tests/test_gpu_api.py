@@ -9,6 +9,7 @@ import sys
 
 import numpy as np
 import pytest
+import scipy.io.wavfile
 
 from conftest import ROOT, load_golden, rms, rel_rms, pcm16_rel_rms
 from oracle import np_oracle as o
@@ -511,6 +512,102 @@ def test_streaming_pipeline_equals_batch_path(tmp_path):
     # --zero-copy: PCM16 wavs and float32 C-ordered masks leave the page cache without a host copy
     assert json.load(open(f"{td}/prof_zc.json"))["stages"]["zero_copy_payloads"] >= 8
     assert prof["stages"]["zero_copy_payloads"] == 0
+
+
+def _cm_body(kind, mat, vmin, vrange, rng):
+    """A Kaldi CompressedMatrix body holding (an approximation of) `mat`: what follows the archive's
+    16-byte global header (formats of the reference's libs/kaldi_io.py:248-292)."""
+    rows, cols = mat.shape
+    u = np.clip((mat - vmin) / vrange, 0.0, 1.0)
+    if kind == "CM2":
+        return np.rint(u * 65535).astype("<u2").tobytes()
+    if kind == "CM3":
+        return np.rint(u * 255).astype(np.uint8).tobytes()
+    # CM: per column four sorted uint16 percentiles, then one byte per element, column-major
+    pch = np.sort(rng.integers(0, 65536, size=(cols, 4)).astype("<u2"), axis=1)
+    body = rng.integers(0, 256, size=(cols, rows)).astype(np.uint8)
+    body[:, :8] = np.array([0, 63, 64, 65, 192, 193, 194, 255], dtype=np.uint8)[None, :min(8, rows)]
+    return pch.tobytes() + body.tobytes()
+
+
+def test_kaldi_compressed_masks_decoded_on_the_device(tmp_path):
+    """SURVEY 8f-3 "Kaldi compressed-matrix (CM) mask decode": setk_kaldi_cm_decode_batch against the
+    host decode (libs/kaldi_io.uncompress, itself pinned on the reference's own `uncompress`,
+    kaldi_io.py:248-292) -- bit for bit, all three formats, both orientations, one launch; the
+    reference-decoded golden bodies; and the streaming command line on a compressed mask archive:
+    the same wave files as with the host decode, with a quarter of the mask bytes shipped."""
+    import json
+    import struct
+    import torch
+    from setk_amd import _ffi
+    from setk_amd.libs import kaldi_io, wavio
+    rng = np.random.default_rng(11)
+    ctx = _ffi.default_context()
+    g = load_golden("ref_kaldi.npz")
+    head = (float(g["cm.head"][0]), float(g["cm.head"][1]), 9, 6)
+    cases = [("CM", g["cm.pch"].tobytes() + g["cm.body"].tobytes(), head, g["cm.decoded"]),
+             ("CM2", g["cm2.body"].tobytes(), head, g["cm2.decoded"]),
+             ("CM3", g["cm3.body"].tobytes(), head, g["cm3.decoded"])]
+    for kind in ("CM", "CM2", "CM3"):
+        for rows, cols in ((63, 257), (257, 63), (1, 5), (300, 257)):
+            vmin, vrange = float(np.float32(rng.uniform(-2, 0))), float(np.float32(rng.uniform(0.5, 3)))
+            mat = rng.uniform(vmin, vmin + vrange, size=(rows, cols))
+            cases.append((kind, _cm_body(kind, mat, vmin, vrange, rng), (vmin, vrange, rows, cols), None))
+    items, keep, want = [], [], []
+    for kind, body, hd, golden in cases:
+        for tr in (False, True):
+            src = torch.from_numpy(np.frombuffer(body, dtype=np.uint8).copy()).cuda()
+            rows, cols = hd[2], hd[3]
+            dst = torch.full((cols, rows) if tr else (rows, cols), np.nan, dtype=torch.float32, device="cuda")
+            host = kaldi_io.uncompress(body, kind, hd).astype(np.float32)
+            if golden is not None:
+                assert np.allclose(host, golden, atol=1e-6)
+            items.append((kind, hd[0], hd[1], rows, cols, tr, src.data_ptr(), dst.data_ptr()))
+            keep.append((src, dst))
+            want.append(np.ascontiguousarray(host.T) if tr else host)
+    ctx.kaldi_cm_decode_batch(items)
+    torch.cuda.synchronize()
+    for (src, dst), w, it in zip(keep, want, items):
+        assert np.array_equal(dst.cpu().numpy(), w), it[:6]
+    with pytest.raises(_ffi.SetkError):
+        ctx.kaldi_cm_decode_batch([("CM2", 0.0, 1.0, 0, 4, False, keep[0][0].data_ptr(), keep[0][1].data_ptr())])
+
+    # ---- the command line on an archive of compressed masks ----
+    td = str(tmp_path)
+    lens, fmts = [16000, 9000, 23456, 12000], ["CM2", "CM3", "CM2", "CM"]
+    refs = {}
+    with open(f"{td}/wav.scp", "w") as ws, open(f"{td}/masks.ark", "wb") as ark, open(f"{td}/mask.scp", "w") as ms:
+        for i, (n, kind) in enumerate(zip(lens, fmts)):
+            mix, sp, nz = o.synth_utterance(700 + i, 4, n, return_parts=True)
+            mask = (0.1 + 0.8 * o.irm_mask(sp, nz)).astype(np.float32)
+            stored = np.ascontiguousarray(mask.T) if i == 2 else mask       # utt2: F x T
+            body = _cm_body(kind, stored.astype(np.float64), 0.0, 1.0, rng)
+            hd = (0.0, 1.0, stored.shape[0], stored.shape[1])
+            key = f"utt{i}"
+            pcm = wavio.float_to_pcm16(mix.T)
+            wavio.write_pcm16(f"{td}/{key}.wav", pcm, 16000)
+            ws.write(f"{key} {td}/{key}.wav\n")
+            ark.write(key.encode() + b" ")
+            ms.write(f"{key} {td}/masks.ark:{ark.tell()}\n")
+            ark.write(b"\0B" + kind.encode() + b" " + struct.pack("<ffii", *hd) + body)
+            dec = kaldi_io.uncompress(body, kind, hd).astype(np.float32)
+            refs[key] = o.enhance_utterance(pcm.T.astype(np.float32) / 32768, dec.T if i == 2 else dec,
+                                            kind="mvdr", gauge=True)
+    script = os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py")
+    outs = {}
+    for mode in ("1", "0"):
+        r = subprocess.run([sys.executable, script, "--mask-format", "kaldi", "--profile", f"{td}/prof{mode}.json",
+                            f"{td}/wav.scp", f"{td}/mask.scp", f"{td}/enh{mode}"], capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, SETK_CM_DEVICE=mode))
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "Processed 4 utterances out of 4" in r.stderr
+        outs[mode] = {k: scipy.io.wavfile.read(f"{td}/enh{mode}/{k}.wav")[1] for k in refs}
+    for k, ref in refs.items():
+        assert np.array_equal(outs["1"][k], outs["0"][k]), k            # device decode == host decode
+        assert pcm16_rel_rms(outs["1"][k], ref) < 1e-3, (k, pcm16_rel_rms(outs["1"][k], ref))
+    b1 = json.load(open(f"{td}/prof1.json"))["stages"]["bytes_in"]
+    b0 = json.load(open(f"{td}/prof0.json"))["stages"]["bytes_in"]
+    assert b1 < b0      # the archive's bytes went up, not their float32 expansion
 
 
 def test_rccl_comm_through_the_c_abi_single_rank():
