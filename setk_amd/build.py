@@ -69,6 +69,14 @@ def _build_locked(force, verbose):
              "wpe.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
              "comm.hip": [],
              "capi.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+    # solve.hip and modular.hip hold a kernel each that must round like numpy operation by operation
+    # (lu_refusal_kernel's LAPACK-order elimination; the Kaldi compressed-matrix decode) behind
+    # `#pragma clang fp contract(off)`.  Plain `fast` lets the BACKEND fuse across the pragma (round 5's
+    # lu_refusal_kernel was compiled with fused multiply-adds although its comment says otherwise);
+    # `fast-honor-pragmas` honours it.  Every other kernel of the two units compiles to the same ISA
+    # under both (diffed); cgmm.hip / cgmm_k.hip do not (float64 builtins lose the contract flag), so
+    # the switch stays per unit.
+    honor = {"solve.hip", "modular.hip"}
     jobs = []
     objs = []
     for src in SOURCES:
@@ -76,7 +84,9 @@ def _build_locked(force, verbose):
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([_hipcc()] + flags + extra.get(src, []) + ["-c", s, "-o", o])
+            fl = [f if f != "-ffp-contract=fast" or src not in honor else "-ffp-contract=fast-honor-pragmas"
+                  for f in flags]
+            jobs.append([_hipcc()] + fl + extra.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

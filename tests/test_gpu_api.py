@@ -569,7 +569,7 @@ def test_kaldi_compressed_masks_decoded_on_the_device(tmp_path):
     torch.cuda.synchronize()
     for (src, dst), w, it in zip(keep, want, items):
         assert np.array_equal(dst.cpu().numpy(), w), it[:6]
-    with pytest.raises(_ffi.SetkError):
+    with pytest.raises(ValueError):     # SETK_ERR_INVALID: API misuse <-> ValueError
         ctx.kaldi_cm_decode_batch([("CM2", 0.0, 1.0, 0, 4, False, keep[0][0].data_ptr(), keep[0][1].data_ptr())])
 
     # ---- the command line on an archive of compressed masks ----
