@@ -141,6 +141,15 @@ def fused(ctx, C, lens, kind):
     ctx.float_to_pcm16(rng.standard_normal((C, lens[0])).astype(np.float32), C, lens[0],
                        np.empty((lens[0], C), np.int16))
     ctx.float_to_pcm16(audio[0], C, lens[0], dmalloc(2 * C * lens[0]))
+    # Kaldi compressed-matrix bodies (the stand-in runs no kernels: the host side of the call)
+    ctx.kaldi_cm_decode_batch([("CM", -1.0, 2.0, 7, 5, False, dmalloc(5 * (8 + 7)), dmalloc(4 * 35)),
+                               ("CM2", 0.0, 1.0, 7, 5, True, dmalloc(2 * 35), dmalloc(4 * 35)),
+                               ("CM3", 0.0, 1.0, 7, 5, False, dmalloc(35), dmalloc(4 * 35))])
+    try:
+        ctx.kaldi_cm_decode_batch([("CM3", 0.0, 1.0, 0, 5, False, dmalloc(35), dmalloc(4 * 35))])
+        raise AssertionError("an empty matrix must be refused")
+    except ValueError:
+        pass
     specs = [dmalloc(C * t * F * 8) for t in frames]
     try:
         ctx.stft_batch(C, audio, lens, specs)
