@@ -221,6 +221,91 @@ ZD void load_par(const float* p, ClassPar<C>& cp) {
     cp.alpha = sgpr(p[PL::ALPHA]);
 }
 
+// ---- packed fp32 (v_pk_*_f32: one instruction on an aligned VGPR pair) -------------------------
+// SETK_CGMM_PK=1: the frames phases hold a complex sample as a pair (re, im) and the two classes'
+// accumulators of one outer-product entry as a pair (class 0, class 1).  A complex multiply-
+// accumulate of the forward substitution is two packed instructions where the plain form needs
+// four, x_i conj(x_j) two instead of four, the two classes' weighted sums of one entry ONE
+// instead of two; broadcasts, swaps and signs ride in op_sel / neg (inline assembly: the compiler
+// folds broadcasts but not the mixed negations; not volatile, so it schedules freely).  The waves
+// of this kernel are issue-limited one by one (section 5 of DESIGN.md), which is where a packed
+// instruction pays: round 2 measured none at the occupancy of the streaming kernels.
+#ifndef SETK_CGMM_PK
+#define SETK_CGMM_PK 1
+#endif
+typedef float pk2 __attribute__((ext_vector_type(2)));
+// t - (l.x + i l.y) * y with a uniform l (an SGPR pair): the step of y = L^-1 x
+ZD pk2 pk_cmsub_s(pk2 t, pk2 l, pk2 y) {
+    pk2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+        : "=v"(r) : "s"(l), "v"(y), "v"(t));                      // r = t - l.x (y.x, y.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
+        : "=v"(t) : "s"(l), "v"(y), "v"(r));                      // t = r + l.y (y.y, -y.x)
+    return t;
+}
+// a * conj(w) = (a.x w.x + a.y w.y, a.y w.x - a.x w.y)
+ZD pk2 pk_cmulc(pk2 a, pk2 w) {
+    pk2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));      // (a.x w.x, a.y w.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));                                        // + (a.y w.y, -a.x w.y)
+    return r;
+}
+// c + (p.x, p.x) * w   /   c + (p.y, p.y) * w
+ZD pk2 pk_fma_bc_lo(pk2 p, pk2 w, pk2 c) {
+    pk2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(p), "v"(w), "v"(c));
+    return r;
+}
+ZD pk2 pk_fma_bc_hi(pk2 p, pk2 w, pk2 c) {
+    pk2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(p), "v"(w), "v"(c));
+    return r;
+}
+// t * (s.x, s.x) / t * (s.y, s.y) with a uniform s
+ZD pk2 pk_scale_s_lo(pk2 t, pk2 s) {
+    pk2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "s"(s), "v"(t));
+    return r;
+}
+ZD pk2 pk_scale_s_hi(pk2 t, pk2 s) {
+    pk2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "s"(s), "v"(t));
+    return r;
+}
+
+// the packed form of ClassPar: (L_ij.re, L_ij.im) and (1 / L_ii, 1 / L_i+1,i+1) as uniform pairs
+template <int C>
+struct ClassParPk {
+    static constexpr int NPO = C * (C - 1) / 2;
+    pk2 l[NPO > 0 ? NPO : 1];
+    pk2 rd[(C + 1) / 2];
+};
+template <int C>
+ZD void load_par_pk(const float* p, ClassParPk<C>& cp) {
+    typedef ParLayout<C> PL;
+#pragma unroll
+    for (int e = 0; e < PL::NPO; ++e) cp.l[e] = (pk2){sgpr(p[PL::LRE + e]), sgpr(p[PL::LIM + e])};
+#pragma unroll
+    for (int i = 0; i < (C + 1) / 2; ++i)
+        cp.rd[i] = (pk2){sgpr(p[PL::RD + 2 * i]), (2 * i + 1 < C) ? sgpr(p[PL::RD + 2 * i + 1]) : 0.f};
+}
+// q = | L^-1 x |^2, the operations of quad_form pair by pair
+template <int C>
+ZD float quad_form_pk(const pk2 (&x)[C], const ClassParPk<C>& cp) {
+    pk2 y[C];
+    pk2 q2 = (pk2){0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        pk2 t = x[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) t = pk_cmsub_s(t, cp.l[i * (i - 1) / 2 + j], y[j]);
+        y[i] = (i & 1) ? pk_scale_s_hi(t, cp.rd[i / 2]) : pk_scale_s_lo(t, cp.rd[i / 2]);
+        q2 = __builtin_elementwise_fma(y[i], y[i], q2);
+    }
+    return q2.x + q2.y;
+}
+
 // q = | L^-1 x |^2 by forward substitution
 template <int C>
 ZD float quad_form(const cf (&x)[C], const ClassPar<C>& cp) {
@@ -669,6 +754,15 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
             for (int c = 0; c < C; ++c) x[c] = Xs[c * Tlp + tid + NT * (u - RF)];
         }
     };
+    constexpr bool PK = SETK_CGMM_PK != 0;
+    auto getxp = [&](auto uc, pk2 (&x)[C]) {
+        constexpr int u = decltype(uc)::value;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const cf v = (u < RF) ? xr[u < RF ? u : 0][c] : Xs[c * Tlp + tid + NT * (u < RF ? 0 : u - RF)];
+            x[c] = (pk2){v.x, v.y};
+        }
+    };
     float w0[U], w1[U];
     float sg0 = 0.f, sg1 = 0.f;
     long long* tm = a.timing ? a.timing + (size_t)f * kTimingSlots : nullptr;
@@ -694,36 +788,39 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
         }
     } else {
         float q0[U], q1[U];
-        {
-            ClassPar<C> p;
-            load_par<C>(sm.par[0], p);
-            static_for<U>([&](auto uc) {
-                constexpr int u = decltype(uc)::value;
-                q0[u] = 1.f;
-                if (tid + NT * u < T) {
-                    cf x[C];
-                    getx(uc, x);
-                    q0[u] = quad_form<C>(x, p);
-                }
-                reload_fence();
-            });
-        }
+        auto e_phase = [&](const float* par, float (&q)[U]) __attribute__((always_inline)) {
+            if constexpr (PK) {
+                ClassParPk<C> p;
+                load_par_pk<C>(par, p);
+                static_for<U>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    q[u] = 1.f;
+                    if (tid + NT * u < T) {
+                        pk2 x[C];
+                        getxp(uc, x);
+                        q[u] = quad_form_pk<C>(x, p);
+                    }
+                    reload_fence();
+                });
+            } else {
+                ClassPar<C> p;
+                load_par<C>(par, p);
+                static_for<U>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    q[u] = 1.f;
+                    if (tid + NT * u < T) {
+                        cf x[C];
+                        getx(uc, x);
+                        q[u] = quad_form<C>(x, p);
+                    }
+                    reload_fence();
+                });
+            }
+        };
+        e_phase(sm.par[0], q0);
         reload_fence();
         PH(tm, tid == 0, 8);
-        {
-            ClassPar<C> p;
-            load_par<C>(sm.par[1], p);
-            static_for<U>([&](auto uc) {
-                constexpr int u = decltype(uc)::value;
-                q1[u] = 1.f;
-                if (tid + NT * u < T) {
-                    cf x[C];
-                    getx(uc, x);
-                    q1[u] = quad_form<C>(x, p);
-                }
-                reload_fence();
-            });
-        }
+        e_phase(sm.par[1], q1);
         reload_fence();
         PH(tm, tid == 0, 9);
         constexpr float kLog2e = 1.4426950408889634f;
@@ -762,6 +859,100 @@ ZD void frames_pass(BinSmem<C, NT>& sm, const int tid, const int T, const cf (&x
     const int wave = tid >> 6, lane = tid & 63;
     float* row = sm.red[wave];
     const bool wr = lane >= 60;
+    // ---- packed form: the entries (i <= j) in two row groups (as many registers as the plain
+    //      phases hold); per group ONE pass over the frames for both parts and both classes: an
+    //      entry's two class sums are a pair, x_i conj(x_j) gives real and imaginary part at once ----
+    if constexpr (PK) {
+        // rows [0, RS) hold at least half of the NP entries
+        constexpr int RS = [] {
+            int n = 0, r = 0;
+            while (r < C && 2 * n < NP) n += C - r++;
+            return r;
+        }();
+        auto group = [&](auto lo_c, auto hi_c, auto last_c) __attribute__((always_inline)) {
+            constexpr int ILO = decltype(lo_c)::value, IHI = decltype(hi_c)::value;
+            constexpr bool LAST = decltype(last_c)::value;
+            // entries of rows [ILO, IHI): e in [ELO, ELO + NR), off-diagonal eo in [OLO, OLO + NI)
+            constexpr int ELO = ILO * C - ILO * (ILO - 1) / 2, EHI = IHI * C - IHI * (IHI - 1) / 2;
+            constexpr int NR = EHI - ELO, NIo = NR - (IHI - ILO);
+            constexpr int OLO = ELO - ILO;
+            constexpr int NVAL = 2 * NR + 2 * NIo + (LAST ? 2 : 0);
+            if constexpr (NR > 0) {
+                pk2 accR[NR], accI[NIo > 0 ? NIo : 1];
+#pragma unroll
+                for (int e = 0; e < NR; ++e) accR[e] = (pk2){0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < (NIo > 0 ? NIo : 1); ++e) accI[e] = (pk2){0.f, 0.f};
+                static_for<U>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    if (tid + NT * u < T) {
+                        pk2 x[C];
+                        getxp(uc, x);
+                        const pk2 w = (pk2){w0[u], w1[u]};
+                        int e = 0, eo = 0;
+#pragma unroll
+                        for (int i = ILO; i < IHI; ++i)
+#pragma unroll
+                            for (int j = i; j < C; ++j) {
+                                if (i == j) {
+                                    const pk2 t2 = x[i] * x[i];
+                                    pk2 pp;
+                                    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(pp) : "v"(t2));
+                                    accR[e] = __builtin_elementwise_fma(pp, w, accR[e]);
+                                } else {
+                                    const pk2 pq = pk_cmulc(x[i], x[j]);
+                                    accR[e] = pk_fma_bc_lo(pq, w, accR[e]);
+                                    accI[eo] = pk_fma_bc_hi(pq, w, accI[eo]);
+                                    ++eo;
+                                }
+                                ++e;
+                            }
+                    }
+                    reload_fence();
+                });
+                PH(tm, tid == 0, LAST ? 13 : 11);
+                // [re class 0 | re class 1 | im class 0 | im class 1 | the two posterior sums]
+                float v[NVAL];
+#pragma unroll
+                for (int e = 0; e < NR; ++e) {
+                    v[e] = accR[e].x;
+                    v[NR + e] = accR[e].y;
+                }
+#pragma unroll
+                for (int e = 0; e < NIo; ++e) {
+                    v[2 * NR + e] = accI[e].x;
+                    v[2 * NR + NIo + e] = accI[e].y;
+                }
+                if constexpr (LAST) {
+                    v[NVAL - 2] = sg0;
+                    v[NVAL - 1] = sg1;
+                }
+                float tot[Bfly<NVAL>::N2];
+                butterfly_sum<NVAL>(v, tot, lane);
+                if (wr) {
+#pragma unroll
+                    for (int r = 0; r < Bfly<NVAL>::N2; ++r) {
+                        const int i = butterfly_index<NVAL>(lane & 3, r);
+                        if (i >= 0) {
+                            int dst;
+                            if (i < NR) dst = ELO + i;
+                            else if (i < 2 * NR) dst = NV + ELO + (i - NR);
+                            else if (i < 2 * NR + NIo) dst = NP + OLO + (i - 2 * NR);
+                            else if (i < 2 * NR + 2 * NIo) dst = NV + NP + OLO + (i - 2 * NR - NIo);
+                            else dst = (i == NVAL - 2) ? NV - 1 : 2 * NV - 1;
+                            row[dst] = tot[r];
+                        }
+                    }
+                }
+                PH(tm, tid == 0, LAST ? 14 : 12);
+            }
+        };
+        group(std::integral_constant<int, 0>{}, std::integral_constant<int, RS>{}, std::integral_constant<bool, RS == C>{});
+        reload_fence();
+        if constexpr (RS < C)
+            group(std::integral_constant<int, RS>{}, std::integral_constant<int, C>{}, std::integral_constant<bool, true>{});
+        return;
+    }
     // ---- real parts: sum_t w_k Re(x_i conj x_j), i <= j (class k at k NP + e) ----
     {
         float acc[2 * NP];

@@ -7,9 +7,11 @@ import numpy as np
 
 NAMES = {0: "frames pass (all phases)", 2: "barrier wait after the frames", 3: "solve (wave 0 = class 0)",
          4: "barrier wait after the solve", 8: "E0  q_0 = |L_0^-1 x|^2, 8 frames", 9: "E1  q_1",
-         10: "P   log2 / exp2 / rcp posterior + weights", 11: "R   21 real outer-product sums x 2 classes",
-         12: "R   halving butterfly + row store", 13: "I   15 imaginary sums x 2 classes",
-         14: "I   butterfly (+ the two posterior sums) + store", 16: "solve: float64 sums of the 4 wave rows",
+         10: "P   log2 / exp2 / rcp posterior + weights",
+         11: "A1  weighted outer products, first row group (plain build: R, the 21 real sums x 2 classes)",
+         12: "A1  halving butterfly + row store",
+         13: "A2  second row group (plain build: I, the 15 imaginary sums x 2 classes)",
+         14: "A2  butterfly (+ the two posterior sums) + store", 16: "solve: float64 sums of the 4 wave rows",
          17: "solve: trace, power-of-two scale", 18: "solve: Cholesky on lanes (6 LDS round trips)",
          19: "solve: L^-1 columns, eigenvalue-floor certificate", 20: "solve: log det, factor write (fast path)",
          21: "solve: exact path (Jacobi), when taken"}
