@@ -502,8 +502,10 @@ def build_roofline(C, b_k1, b_k2, stage_ms, pmc, rates=None):
         roof.update(ceiling_ms=p1["ceiling_ms"], ceiling_is=p1["ceiling_is"], frac_of_ceiling=p1["frac_of_ceiling"],
                     valu_insts=p1["valu_issue"]["insts"], clock_ghz=p1["valu_issue"]["clock_ghz"])
         if p1["ceiling_is"] != "hbm":
-            roof["bound"] = "valu_issue"
-            roof["bound_note"] = ("achieved / peak / frac stay the contract's HBM figures; the kernel's own "
+            # (`bound` keeps the contract's vocabulary -- hbm | mfma -- and the HBM figures; what binds
+            #  the kernel before HBM does is named beside it)
+            roof["co_limit"] = "valu_issue"
+            roof["bound_note"] = ("bound / achieved / peak / frac are the contract's HBM figures; the kernel's own "
                                   "instruction stream needs ceiling_ms at full issue, more than the HBM time of "
                                   "its bytes (DESIGN section 5)")
     return roof

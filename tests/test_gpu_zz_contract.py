@@ -60,6 +60,7 @@ def test_bench_contract_single_rank():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "kernel_ms"):
         assert k in roof, k
     assert roof["peak"] == 8000.0 and roof["unit"] == "GB/s" and roof["kernel_ms"] > 0
+    assert roof["bound"] in ("hbm", "mfma")     # the contract's vocabulary; what binds first: roof["co_limit"]
     assert abs(roof["achieved"] - roof["alg_bytes_per_launch"] / (roof["kernel_ms"] * 1e-3) / 1e9) \
         <= 0.01 * roof["achieved"] + 0.1
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
