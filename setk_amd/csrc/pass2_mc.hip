@@ -311,8 +311,13 @@ __global__ __launch_bounds__(p2mc_threads(PCM), SETK_P2MC_WAVES_PER_SIMD) void b
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = pk[e];
                 }
+#ifdef SETK_P2MC_ABL_L2  // ablation: every wave reads the same 1 MB (L2 resident) -- wrong results
+                const auto x = (gcshort_p)gptr(a.utts[0].audio) + (size_t)c * a.utts[0].ch_stride;
+                const int s0 = (min(t, T - 1) & 127) * hop + 4096 + 256, o = 64 * g + c16;
+#else
                 const auto x = chan(c);
                 const int s0 = min(t, T - 1) * hop - a.g.pad + 256, o = 64 * g + c16;
+#endif
                 if (!decltype(edge)::value) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[4 + e] = x[s0 + o + 16 * e];
@@ -364,8 +369,13 @@ __global__ __launch_bounds__(p2mc_threads(PCM), SETK_P2MC_WAVES_PER_SIMD) void b
     // the same half as raw 16-bit samples (CARRY): converted and packed for the carry where consumed
     auto load_half_raw = [&](int (&r)[4], int t, int c, auto edge) __attribute__((always_inline)) {
         if constexpr (PCM) {
+#ifdef SETK_P2MC_ABL_L2
+            const auto x = (gcshort_p)gptr(a.utts[0].audio) + (size_t)c * a.utts[0].ch_stride;
+            const int s0 = (min(t, T - 1) & 127) * hop + 4096 + 512, o = 64 * g + c16;
+#else
             const auto x = chan(c);
             const int s0 = min(t, T - 1) * hop - a.g.pad + 256, o = 64 * g + c16;
+#endif
             if (!decltype(edge)::value) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[e] = x[s0 + o + 16 * e];
