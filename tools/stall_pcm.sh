@@ -1,3 +1,7 @@
+#!/usr/bin/env bash
+# The SQ stall split (tools/stall_table.sh's three counter groups) of BOTH forms -- float32 and 16-bit PCM -- of
+# both streaming kernels: the bench step with its int16 leg under rocprofv3 --pmc, counters only, one pass per group.
+#   bash tools/stall_pcm.sh   -> gpurun_out/round6_stall/stall_pcm.md
 export TMPDIR=/tmp
 O=gpurun_out/round6_stall; mkdir -p $O
 BENCH="python bench.py --steps 3 --warmup 1 --cpu-sample 0 --pmc 0 --full-batch 0 --e2e-utts 0"
