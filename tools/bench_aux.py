@@ -239,6 +239,9 @@ def cgmm_roofline(args, C, T, U, rates):
                                           "frac": round(floor_ms * cpi / VALU_CYCLES_PER_INST / kms, 4),
                                           "why": "three 256-thread workgroups per CU: 46.5 KB of LDS each, 168 VGPRs"}}
     ent["bound"] = "valu_issue"
+    ent["note"] = ("since round 6 the frames phases issue packed fp32 (v_pk_*_f32): about two thirds of the count are "
+                   "instructions that hold a SIMD's pipe for FOUR cycles, so this 2-cycle floor undercounts the pipe time "
+                   "(the plain form of the same kernel: 8.95e9 instructions, frac 0.55)")
     return ent
 
 
