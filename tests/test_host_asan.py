@@ -107,6 +107,53 @@ def test_streaming_cli_host_side_under_asan(asan_env, tmp_path):
         assert sr == 16000 and y.dtype == np.int16 and y.shape == (256 * (n // 256),)
 
 
+def test_streaming_cli_with_compressed_kaldi_masks_under_asan(asan_env, tmp_path):
+    """The same pipeline fed from a Kaldi archive of CompressedMatrix masks (CM / CM2 / CM3, one stored
+    F x T): the bodies travel as stored and setk_kaldi_cm_decode_batch expands them (round 6).
+    Host side only here -- the table of the decode call, the slab layout with its device-only
+    float32 homes -- under ASAN + UBSan; the arithmetic is the GPU test's."""
+    import json
+    import struct
+    import numpy as np
+    import scipy.io.wavfile
+    from setk_amd.libs import wavio
+    rng = np.random.default_rng(1)
+    td = str(tmp_path)
+    lens, kinds = [16000, 9000, 23456, 12000, 8000], ["CM2", "CM3", "CM2", "CM", "CM3"]
+    with open(f"{td}/wav.scp", "w") as ws, open(f"{td}/masks.ark", "wb") as ark, open(f"{td}/mask.scp", "w") as ms:
+        for i, (n, kind) in enumerate(zip(lens, kinds)):
+            x = (rng.standard_normal((n, 4)) * 1000).astype(np.int16)
+            wavio.write_pcm16(f"{td}/u{i}.wav", x, 16000)
+            T = 1 + n // 256
+            rows, cols = (257, T) if i == 2 else (T, 257)
+            if kind == "CM2":
+                body = rng.integers(0, 65536, size=(rows, cols)).astype("<u2").tobytes()
+            elif kind == "CM3":
+                body = rng.integers(0, 256, size=(rows, cols)).astype(np.uint8).tobytes()
+            else:
+                body = np.sort(rng.integers(0, 65536, size=(cols, 4)).astype("<u2"), axis=1).tobytes() + \
+                    rng.integers(0, 256, size=(cols, rows)).astype(np.uint8).tobytes()
+            ws.write(f"u{i} {td}/u{i}.wav\n")
+            ark.write(f"u{i} ".encode())
+            ms.write(f"u{i} {td}/masks.ark:{ark.tell()}\n")
+            ark.write(b"\0B" + kind.encode() + b" " + struct.pack("<ffii", 0.0, 1.0, rows, cols) + body)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "sptk", "apply_adaptive_beamformer.py"),
+                        "--mask-format", "kaldi", "--batch-utts", "2", "--profile", f"{td}/prof.json",
+                        f"{td}/wav.scp", f"{td}/mask.scp", f"{td}/out"],
+                       capture_output=True, text=True, env=asan_env, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    assert "Processed 5 utterances out of 5" in r.stderr
+    with open(f"{td}/prof.json") as f:
+        st = json.load(f)["stages"]
+    # the archive's bytes went up, not their float32 expansion (4 B per cell)
+    cells = sum((1 + n // 256) * 257 for n in lens)
+    assert st["bytes_in"] < sum(2 * 4 * n for n in lens) + 3 * cells
+    for i, n in enumerate(lens):
+        sr, y = scipy.io.wavfile.read(f"{td}/out/u{i}.wav")
+        assert sr == 16000 and y.dtype == np.int16 and y.shape == (256 * (n // 256),)
+
+
 def test_cgmm_cli_host_side_under_asan(asan_env, tmp_path):
     """estimate_cgmm_masks.py (batched path: CgmmEstimator.estimate on the library's own slabs
     and stream, no torch) against the stand-in, under ASAN + UBSan."""

@@ -268,6 +268,53 @@ def test_kaldi_goldens():
                        g["cm3.decoded"], atol=1e-6)
 
 
+def test_probe_of_compressed_kaldi_matrices(tmp_path):
+    """pipeline.probe_kaldi_compressed: the header of a CompressedMatrix entry (what the streaming
+    pipeline needs to ship its body as stored) -- kind, global header, body range -- and None for
+    everything else; the body it names decodes to what the archive reader returns."""
+    import struct
+    from setk_amd import pipeline
+    from setk_amd.libs import kaldi_io
+    from setk_amd.libs.data_handler import ScriptReader
+    rng = np.random.default_rng(2)
+    td = str(tmp_path)
+    want = {}
+    with open(f"{td}/m.ark", "wb") as ark, open(f"{td}/m.scp", "w") as scp:
+        for key, kind, rows, cols in (("a", "CM2", 7, 5), ("b", "CM3", 3, 9), ("c", "CM", 6, 4)):
+            if kind == "CM2":
+                body = rng.integers(0, 65536, size=(rows, cols)).astype("<u2").tobytes()
+            elif kind == "CM3":
+                body = rng.integers(0, 256, size=(rows, cols)).astype(np.uint8).tobytes()
+            else:
+                body = np.sort(rng.integers(0, 65536, size=(cols, 4)).astype("<u2"), axis=1).tobytes() + \
+                    rng.integers(0, 256, size=(cols, rows)).astype(np.uint8).tobytes()
+            ark.write(f"{key} ".encode())
+            scp.write(f"{key} {td}/m.ark:{ark.tell()}\n")
+            ark.write(b"\0B" + kind.encode() + b" " + struct.pack("<ffii", -0.5, 2.0, rows, cols) + body)
+            want[key] = (kind, rows, cols, body)
+        ark.write(b"d ")
+        scp.write(f"d {td}/m.ark:{ark.tell()}\n")
+        ark.write(b"\0BFM " + b"\x04" + struct.pack("<i", 2) + b"\x04" + struct.pack("<i", 3) +
+                  np.arange(6, dtype="<f4").tobytes())
+    files = pipeline.OpenFiles()
+    rd = ScriptReader(f"{td}/m.scp")
+    try:
+        for key, (kind, rows, cols, body) in want.items():
+            path, off = rd.locate(key)
+            hit = pipeline.probe_kaldi_compressed(files, path, off)
+            assert hit[:5] == (kind, -0.5, 2.0, rows, cols) and hit[6] == len(body)
+            with open(path, "rb") as f:
+                f.seek(hit[5])
+                assert f.read(hit[6]) == body
+            assert pipeline.probe_kaldi_matrix(files, path, off) is None
+            assert np.array_equal(rd[key], kaldi_io.uncompress(body, kind, (-0.5, 2.0, rows, cols)))
+        path, off = rd.locate("d")
+        assert pipeline.probe_kaldi_compressed(files, path, off) is None
+        assert pipeline.probe_kaldi_matrix(files, path, off)[:2] == (2, 3)
+    finally:
+        files.close()
+
+
 def test_kaldi_writer_roundtrip(tmp_path):
     from setk_amd.libs.data_handler import ArchiveWriter, ScriptReader
     rng = np.random.default_rng(0)
